@@ -1,0 +1,289 @@
+"""Synthetic Mars-yard scene in the reference's on-disk formats.
+
+The reference ships none of its terrain assets (``/root/reference/.gitignore:8-22``),
+so the bench, the parity fixtures and the smoke test all run on a scene built here:
+
+* an analytic heightfield triangulated with the diagonal convention of
+  ``utils/terrain_utils/terrain_utils.py:355-367`` (two triangles per grid cell),
+  vertices stored fp16 like ``tasks/utils/rover_utils.py:113``;
+* the "K nearest triangle centroids per 0.1 m cell" map that
+  ``tasks/utils/rover_utils.py:52-118`` builds offline (``map_indices`` [X,Y,K] int32,
+  ``triangles`` [T,3] int32, ``vertices`` [V,3] fp16);
+* a rocks-only map built the same way from the triangles that lie inside the
+  ``stone_info`` discs;
+* ``stone_info`` [S,6] (centre xyz, extents xy, unused) as ``read_stone_info``
+  (``utils/terrain_utils/terrain_utils.py:416-424``) expects to find on disk;
+* the 0.025 m heightfield that ``rover.py:210-213`` loads for spawn / goal z.
+
+Everything is deterministic: the nearest-centroid ranking is done in exact integer
+arithmetic (centroids of a regular grid mesh sit on a 1/3-cell lattice), ties broken
+by triangle id, so CPU and GPU builds of a scene are bit-identical.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+@dataclass
+class KnnMap:
+    """One of the reference's ``knn_terrain`` / ``knn_rocks`` directories, in memory."""
+    map_indices: torch.Tensor   # [X, Y, K] int32 (the layout camera.py:156-158 swaps to)
+    triangles: torch.Tensor     # [T, 3] int32
+    vertices: torch.Tensor      # [V, 3] float16
+    cell_size: float = 0.1
+
+
+@dataclass
+class Scene:
+    terrain: KnnMap
+    rocks: KnnMap
+    stone_info_raw: np.ndarray  # [S, 6] float64, what stone_info.npy holds
+    heightmap: torch.Tensor     # [N0, N1] float32 at 0.025 m
+    horizontal_scale: float = 0.025
+    vertical_scale: float = 1.0
+    shift: tuple = (0.0, 0.0, 0.0)
+
+
+def surface_height(i, j, noise=None):
+    """h[i,j] of SURVEY.md §8d; i, j are vertex indices on the 0.1 m grid."""
+    h = 0.30 * np.sin(0.15 * i) + 0.20 * np.cos(0.11 * j)
+    if noise is not None:
+        h = h + noise
+    return h
+
+
+def grid_mesh(n_vert: int, seed: int = 0):
+    """Vertices/triangles of an n_vert x n_vert heightfield at 0.1 m spacing.
+
+    Triangle order and winding follow terrain_utils.py:355-367:
+    even triangle of cell (i,j) = (ind0, ind3, ind1), odd = (ind0, ind2, ind3).
+    """
+    rng = np.random.default_rng(seed)
+    ii, jj = np.meshgrid(np.arange(n_vert), np.arange(n_vert), indexing="ij")
+    noise = 0.05 * rng.standard_normal((n_vert, n_vert))
+    hf = surface_height(ii.astype(np.float64), jj.astype(np.float64), noise)
+    verts = np.zeros((n_vert * n_vert, 3), dtype=np.float32)
+    verts[:, 0] = (ii * 0.1).reshape(-1)
+    verts[:, 1] = (jj * 0.1).reshape(-1)
+    verts[:, 2] = hf.reshape(-1)
+    nc = n_vert - 1
+    ci, cj = np.meshgrid(np.arange(nc), np.arange(nc), indexing="ij")
+    ind0 = (ci * n_vert + cj).reshape(-1)
+    ind1 = ind0 + 1
+    ind2 = ind0 + n_vert
+    ind3 = ind2 + 1
+    tris = np.empty((2 * nc * nc, 3), dtype=np.int32)
+    tris[0::2, 0] = ind0
+    tris[0::2, 1] = ind3
+    tris[0::2, 2] = ind1
+    tris[1::2, 0] = ind0
+    tris[1::2, 1] = ind2
+    tris[1::2, 2] = ind3
+    return verts, tris, hf
+
+
+def _centroid_lattice(n_vert: int, device):
+    """Integer centroid coordinates (units of 1/3 cell) of every grid-mesh triangle."""
+    nc = n_vert - 1
+    ci, cj = torch.meshgrid(torch.arange(nc, device=device), torch.arange(nc, device=device), indexing="ij")
+    ci = ci.reshape(-1)
+    cj = cj.reshape(-1)
+    cx = torch.stack((3 * ci + 1, 3 * ci + 2), dim=1).reshape(-1)   # even: (i,i+1,i) ; odd: (i,i+1,i+1)
+    cy = torch.stack((3 * cj + 2, 3 * cj + 1), dim=1).reshape(-1)   # even: (j,j+1,j+1) ; odd: (j,j,j+1)
+    return cx.to(torch.int64), cy.to(torch.int64)
+
+
+def knn_map_from_subset(n_cells: int, cx: torch.Tensor, cy: torch.Tensor, tri_ids: torch.Tensor,
+                        k: int, chunk_cells: int = 2048) -> torch.Tensor:
+    """Exact K nearest centroids (xy) per cell among the triangles ``tri_ids``.
+
+    Semantics of rover_utils.py:68-108 (cell (x,y) sits at (x*res, y*res); rank by
+    euclidean distance of the triangle centre), evaluated with integer keys
+    ``d2 * T + local_rank`` so the order is total and device independent.
+    Returns [n_cells, n_cells, k] int32 of *global* triangle ids.
+    """
+    device = cx.device
+    t = tri_ids.numel()
+    if t < k:
+        raise ValueError(f"need at least K={k} triangles, got {t}")
+    sx = cx[tri_ids]
+    sy = cy[tri_ids]
+    out = torch.empty((n_cells * n_cells, k), dtype=torch.int32, device=device)
+    cells = torch.arange(n_cells * n_cells, device=device)
+    for s in range(0, n_cells * n_cells, chunk_cells):
+        c = cells[s:s + chunk_cells]
+        px = (3 * (c // n_cells)).unsqueeze(1)
+        py = (3 * (c % n_cells)).unsqueeze(1)
+        d2 = (sx.unsqueeze(0) - px) ** 2 + (sy.unsqueeze(0) - py) ** 2
+        key = d2 * t + torch.arange(t, device=device).unsqueeze(0)
+        top = torch.topk(key, k, dim=1, largest=False, sorted=True).values
+        out[s:s + chunk_cells] = tri_ids[(top % t)].to(torch.int32)
+    return out.reshape(n_cells, n_cells, k)
+
+
+def knn_map_grid(n_cells: int, n_vert: int, k: int, device, chunk_rows: int = 8) -> torch.Tensor:
+    """Same ranking as :func:`knn_map_from_subset` over ALL triangles of the grid mesh,
+    restricted to a window that provably holds the K nearest (also at the map border)."""
+    nc = n_vert - 1
+    w = 2 * int(math.ceil(math.sqrt(k / (2.0 * math.pi)))) + 2
+    t_total = 2 * nc * nc
+    offs = torch.arange(-w, w + 1, device=device)
+    oi, oj, parity = torch.meshgrid(offs, offs, torch.arange(2, device=device), indexing="ij")
+    oi = oi.reshape(-1)
+    oj = oj.reshape(-1)
+    parity = parity.reshape(-1)
+    out = torch.empty((n_cells, n_cells, k), dtype=torch.int32, device=device)
+    big = torch.iinfo(torch.int64).max
+    ys = torch.arange(n_cells, device=device)
+    for r0 in range(0, n_cells, chunk_rows):
+        xs = torch.arange(r0, min(r0 + chunk_rows, n_cells), device=device)
+        gx, gy = torch.meshgrid(xs, ys, indexing="ij")
+        gx = gx.reshape(-1, 1)
+        gy = gy.reshape(-1, 1)
+        # mesh cell that contains the map cell position (clamped into the mesh)
+        ti = gx.clamp(max=nc - 1) + oi.unsqueeze(0)
+        tj = gy.clamp(max=nc - 1) + oj.unsqueeze(0)
+        valid = (ti >= 0) & (ti < nc) & (tj >= 0) & (tj < nc)
+        tid = 2 * (ti * nc + tj) + parity.unsqueeze(0)
+        ccx = 3 * ti + 1 + parity.unsqueeze(0)
+        ccy = 3 * tj + 2 - parity.unsqueeze(0)
+        d2 = (ccx - 3 * gx) ** 2 + (ccy - 3 * gy) ** 2
+        key = torch.where(valid, d2 * t_total + tid, torch.full_like(d2, big))
+        top = torch.topk(key, k, dim=1, largest=False, sorted=True).values
+        if bool((top[:, -1] == big).any()):
+            raise ValueError("KNN window too small for this K / map size")
+        out[xs[0]:xs[-1] + 1] = (top % t_total).to(torch.int32).reshape(len(xs), n_cells, k)
+    return out
+
+
+def make_stones(n_stones: int, extent_m: float, seed: int = 2) -> np.ndarray:
+    """stone_info.npy content: [S,6] = centre xyz, extents (U(0.2,1.7)) x2, unused."""
+    rng = np.random.default_rng(seed)
+    info = np.zeros((n_stones, 6), dtype=np.float64)
+    info[:, 0:2] = rng.uniform(0.0, extent_m, size=(n_stones, 2))
+    info[:, 3:5] = rng.uniform(0.2, 1.7, size=(n_stones, 2))
+    return info
+
+
+def read_stone_info_array(raw: np.ndarray) -> np.ndarray:
+    """Host half of read_stone_info (terrain_utils.py:416-424): append radius = max(ext)/4."""
+    rs = np.maximum(raw[:, 3], raw[:, 4]) / 4.0
+    return np.concatenate([raw, rs[:, None]], axis=1).astype(np.float32)
+
+
+def make_scene(n_cells: int = 600, k: int = 200, n_stones: int = 1024, device="cpu",
+               heightmap_cells: int | None = None, seed: int = 0) -> Scene:
+    """Bench scene: n_cells x n_cells map cells at 0.1 m, n_cells+1 vertices per side."""
+    device = torch.device(device)
+    n_vert = n_cells + 1
+    verts, tris, _ = grid_mesh(n_vert, seed=seed)
+    vertices = torch.from_numpy(verts).to(torch.float16)
+    triangles = torch.from_numpy(tris)
+    extent = n_cells * 0.1
+
+    terrain_idx = knn_map_grid(n_cells, n_vert, k, device).cpu()
+
+    raw = make_stones(n_stones, extent, seed=2)
+    info = read_stone_info_array(raw)
+    # triangles whose centroid lies inside a stone disc form the rocks-only mesh
+    cx, cy = _centroid_lattice(n_vert, device)
+    px = cx.to(torch.float32) * (0.1 / 3.0)
+    py = cy.to(torch.float32) * (0.1 / 3.0)
+    inside = torch.zeros_like(px, dtype=torch.bool)
+    st = torch.from_numpy(info).to(device)
+    for s0 in range(0, n_stones, 64):
+        blk = st[s0:s0 + 64]
+        d = torch.sqrt((px.unsqueeze(1) - blk[:, 0]) ** 2 + (py.unsqueeze(1) - blk[:, 1]) ** 2)
+        inside |= (d <= blk[:, 6]).any(dim=1)
+    rock_ids = torch.nonzero(inside).squeeze(1)
+    if rock_ids.numel() < k:  # tiny fixtures: top up with the lowest-id triangles
+        extra = torch.arange(cx.numel(), device=device)
+        extra = extra[~inside][: k - rock_ids.numel()]
+        rock_ids = torch.sort(torch.cat([rock_ids, extra])).values
+    rocks_idx = knn_map_from_subset(n_cells, cx, cy, rock_ids, k).cpu()
+
+    # 0.025 m heightfield resampled from the same analytic surface (no noise term:
+    # it is only used for spawn / goal z, rover.py:216-218,582-583)
+    n_h = heightmap_cells if heightmap_cells is not None else n_cells * 4
+    hi = np.arange(n_h, dtype=np.float64) * 0.25
+    hm = surface_height(hi[:, None], hi[None, :]).astype(np.float32)
+
+    return Scene(
+        terrain=KnnMap(terrain_idx, triangles, vertices),
+        rocks=KnnMap(rocks_idx, triangles.clone(), vertices.clone()),
+        stone_info_raw=raw,
+        heightmap=torch.from_numpy(hm),
+    )
+
+
+def quat_from_euler(roll, pitch, yaw):
+    """(w,x,y,z) of the ZYX rotation; inverse of tensor_quat_to_euler.py:17-29."""
+    cr, sr = torch.cos(roll / 2), torch.sin(roll / 2)
+    cp, sp = torch.cos(pitch / 2), torch.sin(pitch / 2)
+    cy, sy = torch.cos(yaw / 2), torch.sin(yaw / 2)
+    return torch.stack((cr * cp * cy + sr * sp * sy,
+                        sr * cp * cy - cr * sp * sy,
+                        cr * sp * cy + sr * cp * sy,
+                        cr * cp * sy - sr * sp * cy), dim=1).to(torch.float32)
+
+
+def make_states(num_envs: int, extent_m: float, seed: int, heightfn=None):
+    """Per-env sim state of SURVEY.md §8d (host tensors, float32 / int64)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    lo, hi = 5.0, extent_m - 5.0
+    if hi <= lo:
+        lo, hi = 0.25 * extent_m, 0.75 * extent_m
+    pos = torch.empty(num_envs, 3)
+    pos[:, 0:2] = lo + (hi - lo) * torch.rand(num_envs, 2, generator=g)
+    i = (pos[:, 0] / 0.1).numpy().astype(np.float64)
+    j = (pos[:, 1] / 0.1).numpy().astype(np.float64)
+    pos[:, 2] = torch.from_numpy(surface_height(i, j)).float() + 0.5
+    roll = 0.1 * torch.randn(num_envs, generator=g)
+    pitch = 0.1 * torch.randn(num_envs, generator=g)
+    yaw = (2 * torch.rand(num_envs, generator=g) - 1) * math.pi
+    quat = quat_from_euler(roll, pitch, yaw)
+    joints = 0.1 * torch.randn(num_envs, 13, generator=g)
+    alpha = 2 * math.pi * torch.rand(num_envs, generator=g)
+    target = pos.clone()
+    target[:, 0] += 8 * torch.cos(alpha)
+    target[:, 1] += 8 * torch.sin(alpha)
+    lin_hist = 2 * torch.rand(num_envs, 3, generator=g) - 1
+    ang_hist = 2 * torch.rand(num_envs, 3, generator=g) - 1
+    progress = torch.randint(0, 3001, (num_envs,), generator=g, dtype=torch.int64)
+    euler_pre = torch.stack((roll, pitch, yaw), dim=1) + 0.01 * torch.randn(num_envs, 3, generator=g)
+    return dict(pos=pos.float(), quat=quat, joints=joints.float(), target=target.float(),
+                lin_hist=lin_hist.float(), ang_hist=ang_hist.float(), progress=progress,
+                euler_pre=euler_pre.float())
+
+
+def ray_distribution(name: str):
+    """Rover-local sample points for the BASELINE.json configs.
+
+    Returns (points [P,3] float64, sparse_idx, dense_idx) in the reference's
+    *post-swap* frame (x forward), i.e. what Heightmap.get_distribution() returns.
+    """
+    z = -0.26878
+    if name == "9":
+        pts = [(x, y, z) for x in (0.5, 1.0, 1.5) for y in (-0.5, 0.0, 0.5)]
+        sparse = list(range(9))
+        dense = []
+    elif name == "37":
+        pts = [(0.2, 0.0, z)]
+        for r in (1.0, 2.0, 3.0):
+            for a in range(12):
+                th = math.radians(-82.5 + 15.0 * a)
+                pts.append((round(r * math.cos(th), 4), round(r * math.sin(th), 4), z))
+        sparse = list(range(37))
+        dense = []
+    elif name == "120":
+        pts = [(round(0.15 + 0.1 * a, 4), round(-0.55 + 0.1 * b, 4), z) for a in range(10) for b in range(12)]
+        sparse = []
+        dense = list(range(120))
+    else:
+        raise ValueError(name)
+    return (np.asarray(pts, dtype=np.float64), np.asarray(sparse, dtype=np.int64),
+            np.asarray(dense, dtype=np.int64))

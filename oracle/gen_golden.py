@@ -1,0 +1,178 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.npz from the reference itself.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Every fixture holds the inputs fed to the reference's own PyTorch code
+(``RoverTask.get_observations / calculate_metrics / is_done`` called unbound, see
+oracle/ref_harness.py) and the outputs it produced.  The scene (terrain / rocks maps,
+stones, heightfield) is NOT stored: it is rebuilt bit-identically by
+``isaac_rover_amd.synth.make_scene`` from the parameters recorded in the fixture, and
+the fixture carries checksums of the scene arrays so a drift is detected.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from isaac_rover_amd import synth  # noqa: E402
+from oracle import ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SCENE_KW = dict(n_cells=128, k=16, n_stones=64)
+
+
+def scene_digest(scene) -> str:
+    h = hashlib.sha256()
+    for t in (scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices.view(torch.int16),
+              scene.rocks.map_indices, scene.heightmap):
+        h.update(t.contiguous().numpy().tobytes())
+    h.update(np.ascontiguousarray(scene.stone_info_raw).tobytes())
+    return h.hexdigest()
+
+
+def edge_states(st, scene):
+    """Hand-placed edge cases on top of the random batch."""
+    st = {k: v.clone() for k, v in st.items()}
+    p = st["pos"]
+    st["target"][0, 0:2] = p[0, 0:2] + torch.tensor([0.1, 0.05])        # d <= 0.18: goal reached (rover.py:506,619)
+    st["target"][1, 0:2] = p[1, 0:2] + torch.tensor([9.0, 7.0])         # d >= 11 (rover.py:618)
+    s = float(np.sqrt(0.5))
+    st["quat"][2] = torch.tensor([s, 0.0, s, 0.0])                      # sinp ~ 1: copysign branch (quat_to_euler:22-24)
+    st["pos"][3, 0:2] = torch.tensor([-1.3, 14.9])                      # outside the map: clamp (camera.py:243)
+    st["euler_pre"][4, 0] = 1.2                                         # pre-physics roll >= 1.17 (rover.py:615)
+    st["euler_pre"][5, 1] = -1.25                                       # pre-physics pitch (rover.py:616)
+    st["progress"][6] = 2999                                            # +1 -> 3000: timeout (rover.py:614)
+    st["lin_hist"][7, 1] = st["lin_hist"][7, 0]                         # no oscillation penalty (rover.py:498)
+    st["ang_hist"][7, 1] = st["ang_hist"][7, 0]
+    info = synth.read_stone_info_array(scene.stone_info_raw)
+    inside = [i for i in range(info.shape[0]) if 1.0 < info[i, 0] < 11.8 and 1.0 < info[i, 1] < 11.8]
+    for n, e in enumerate((8, 9, 10)):                                  # parked on a stone: rock rays hit
+        s_ = info[inside[n]]
+        st["pos"][e, 0] = float(s_[0])
+        st["pos"][e, 1] = float(s_[1])
+        i, j = float(s_[0]) / 0.1, float(s_[1]) / 0.1
+        st["pos"][e, 2] = float(synth.surface_height(np.float64(i), np.float64(j))) + 0.3
+    st["lin_hist"][11, 0] = -0.5                                        # driving backwards (rover.py:486)
+    st["joints"][12, 0:3] = torch.tensor([0.4, -0.5, 0.6])              # bogie angles (rover.py:492; rock_detect:263-264)
+    st["joints"][13, 4:9] = torch.tensor([0.5, 0.0, -0.4, 0.3, -0.6])   # steering (rock_detect.py:248)
+    return st
+
+
+def tonp(d):
+    return {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def step_fixture(name, scene, digest, dist_name, num_envs, seed, fp32=True, edges=False, native=False,
+                 curriculum_level=2, num_envs_global=None):
+    distn = None if native else synth.ray_distribution(dist_name)
+    ref = rh.Reference(scene, fp32=fp32, distribution=distn)
+    if native:
+        distn = (ref.native_distribution.numpy(), ref.native_sparse.numpy(), ref.native_dense.numpy())
+    st = synth.make_states(num_envs, SCENE_KW["n_cells"] * 0.1, seed=seed)
+    if edges:
+        st = edge_states(st, scene)
+    out = ref.step(st, curriculum_level=curriculum_level, num_envs_global=num_envs_global)
+    arrays = {"in_" + k: v for k, v in tonp(st).items()}
+    arrays.update({"out_" + k: v for k, v in tonp(out).items()})
+    if native:
+        arrays.pop("out_ray_sources")       # 157 KB of redundancy; ray_dist + obs pin the native case
+    arrays.update(distribution=np.asarray(distn[0], dtype=np.float64), sparse_idx=np.asarray(distn[1], dtype=np.int64),
+                  dense_idx=np.asarray(distn[2], dtype=np.int64), scene_digest=np.array(digest),
+                  scene_kw=np.array(repr(SCENE_KW)), fp32=np.array(fp32), curriculum_level=np.array(curriculum_level),
+                  num_envs_global=np.array(num_envs_global or num_envs))
+    save(name, **arrays)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    scene = synth.make_scene(**SCENE_KW)
+    digest = scene_digest(scene)
+    print("scene digest", digest)
+
+    # BASELINE.json configs[0]: 256 envs, 9-ray height sample, reference PyTorch task on host CPU
+    step_fixture("step_e256_p9_fp32", scene, digest, "9", 256, seed=0)
+    # configs[1] shape at fixture size: 37-point radial + full reward stack, with edge cases
+    step_fixture("step_e64_p37_fp32", scene, digest, "37", 64, seed=1, edges=True)
+    # configs[4] shape: 120-point dense
+    step_fixture("step_e64_p120_fp32", scene, digest, "120", 64, seed=2, edges=True)
+    # the reference's native 1634-point distribution (heightmap_distribution.py), 1750-float obs
+    step_fixture("step_e8_native_fp32", scene, digest, None, 8, seed=3, native=True)
+    # curriculum level 1: collision term off (rover.py:292,514,645)
+    step_fixture("step_e64_p37_fp32_level1", scene, digest, "37", 64, seed=1, edges=True, curriculum_level=1)
+    # as shipped (fp16 ray maths): informational tolerance only
+    step_fixture("step_e64_p37_fp16_as_shipped", scene, digest, "37", 64, seed=1, fp32=False, edges=True)
+
+    # ---- native distribution table (heightmap_distribution.py:36-115) -----------------------
+    ref = rh.Reference(scene, fp32=True)
+    save("heightmap_native", distribution=ref.native_distribution.numpy(), coarse_idx=ref.native_sparse.numpy(),
+         fine_idx=ref.native_dense.numpy())
+
+    # ---- reset path (rover.py:533-564, 588-608, 649-661) on a sparse stone set ----------------
+    kw2 = dict(n_cells=128, k=16, n_stones=10)
+    scene2 = synth.make_scene(**kw2)
+    ref2 = rh.Reference(scene2, fp32=True)
+    g = torch.Generator().manual_seed(7)
+    n = 96
+    xy = 12.8 * torch.rand(n, 2, generator=g)
+    xy[0] = torch.tensor([-0.7, 3.3])               # clamp low
+    xy[1] = torch.tensor([13.4, 12.79])             # clamp high
+    xy[2] = torch.tensor([0.0125, 0.0375])          # .5 ties: round-half-even (rover.py:594)
+    xy[3] = torch.tensor([0.0625, 0.0875])
+    heights = ref2.get_pos_height(xy)
+    clear = ref2.clearance(xy)
+    spawn = torch.zeros(n, 3)
+    spawn[:, 0:2] = xy
+    shifted = ref2.avoid_pos_rock_collision(spawn)
+    # goals: 24 envs reset out of 32, uniforms supplied
+    e = 32
+    initial = torch.zeros(e, 3)
+    initial[:, 0:2] = 3.0 + 6.8 * torch.rand(e, 2, generator=g)
+    env_ids = torch.tensor([0, 1, 2, 3, 5, 6, 8, 9, 11, 12, 13, 14, 16, 17, 19, 20, 22, 23, 24, 26, 27, 29, 30, 31])
+    env_ids_no0 = env_ids[1:].clone()
+    draws = torch.rand(64, len(env_ids), generator=g)
+    tgt, used = ref2.generate_goals(env_ids, initial, [draws[i] for i in range(draws.shape[0])])
+    draws_b = torch.rand(64, len(env_ids_no0), generator=g)
+    tgt_b, used_b = ref2.generate_goals(env_ids_no0, initial, [draws_b[i] for i in range(draws_b.shape[0])])
+    goal_clear = ref2.clearance(tgt[env_ids][:, 0:2])
+    goal_h = ref2.get_pos_height(tgt[env_ids][:, 0:2])
+    reset_buf = (torch.rand(1000, generator=g) < 0.3).long()
+    save("reset_path", scene_kw=np.array(repr(kw2)), scene_digest=np.array(scene_digest(scene2)),
+         stone_info=ref2.stone_info.numpy(), xy=xy.numpy(), heights=heights.numpy(), clearance=clear.numpy(),
+         spawn_in=spawn.numpy(), spawn_out=shifted.numpy(),
+         goal_initial=initial.numpy(), goal_env_ids=env_ids.numpy(), goal_draws=draws[:used].numpy(),
+         goal_targets=tgt.numpy(), goal_used=np.array(used),
+         goal_env_ids_b=env_ids_no0.numpy(), goal_draws_b=draws_b[:used_b].numpy(), goal_targets_b=tgt_b.numpy(),
+         goal_used_b=np.array(used_b), goal_clearance=goal_clear.numpy(), goal_height=goal_h.numpy(),
+         reset_buf=reset_buf.numpy(), reset_ids=reset_buf.nonzero(as_tuple=False).squeeze(-1).numpy())
+
+    # ---- Ackermann (tasks/utils/kinematics.py:13-67), "next" row f-1 --------------------------
+    lin = 2 * torch.rand(256, generator=g) - 1
+    ang = 2 * torch.rand(256, generator=g) - 1
+    lin[0], ang[0] = 0.0, -2.0          # the reference's own __main__ case (kinematics.py:69-71)
+    lin[1], ang[1] = 0.5, 0.0           # straight line: P = inf
+    lin[2], ang[2] = 0.0, 0.0           # 0/0
+    lin[3], ang[3] = 1.0, 1e-4          # > 1000 m turning radius (kinematics.py:58)
+    lin[4], ang[4] = 0.2, 1.0           # turning point between the wheels (bound 0.45)
+    lin[5], ang[5] = -0.7, 0.3
+    steer, vel = ref2.ackermann(lin, ang)
+    save("ackermann", lin=lin.numpy(), ang=ang.numpy(), steer=steer.numpy(), vel=vel.numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+_scene_cache = {}
+
+
+def scene_for(fixture):
+    """Rebuild the synthetic scene a fixture was captured on and verify its checksum."""
+    import hashlib
+
+    import torch
+    from isaac_rover_amd import synth
+
+    kw = eval(str(fixture["scene_kw"]))  # repr of a plain dict of ints written by oracle/gen_golden.py
+    key = tuple(sorted(kw.items()))
+    if key not in _scene_cache:
+        scene = synth.make_scene(**kw)
+        h = hashlib.sha256()
+        for t in (scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices.view(torch.int16),
+                  scene.rocks.map_indices, scene.heightmap):
+            h.update(t.contiguous().numpy().tobytes())
+        h.update(np.ascontiguousarray(scene.stone_info_raw).tobytes())
+        _scene_cache[key] = (scene, h.hexdigest())
+    scene, digest = _scene_cache[key]
+    assert digest == str(fixture["scene_digest"]), "synthetic scene drifted from the one the golden vectors were captured on"
+    return scene
+
+
+def states_of(fixture):
+    import torch
+    return {k[3:]: torch.from_numpy(v) for k, v in fixture.items() if k.startswith("in_")}
+
+
+STEP_FIXTURES_FP32 = ["step_e256_p9_fp32", "step_e64_p37_fp32", "step_e64_p120_fp32", "step_e8_native_fp32",
+                      "step_e64_p37_fp32_level1"]
+
+# ---- stated parity tolerances, shared by the oracle and the HIP tests ----------
+TOL_SCALAR = 1e-5        # euler / heading / obs[:,0:4] / reward / extras: abs and rel
+TOL_RAY = 2e-3           # ray distances: abs, on >= 99.9 % of rays
+RAY_FLIP_BUDGET = 1e-3   # <= 0.1 % of rays may flip hit<->miss at eps-edges / cell-rounding ties
+
+
+def assert_step_close(got, want, label=""):
+    """Compare one post_physics_step result (dict of arrays) against golden / oracle outputs."""
+    def g(k):
+        v = got[k]
+        return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+
+    for k in ("euler", "heading_diff", "rew_buf"):
+        if k in got and ("out_" + k) in want:
+            np.testing.assert_allclose(g(k), want["out_" + k], rtol=TOL_SCALAR, atol=TOL_SCALAR, equal_nan=True,
+                                       err_msg=f"{label}:{k}")
+    for k in want:
+        if k.startswith("out_extras_") and k[4:] in got:
+            a, b = g(k[4:]), want[k]
+            if b.dtype.kind == "i":
+                np.testing.assert_array_equal(a, b, err_msg=f"{label}:{k}")
+            else:
+                np.testing.assert_allclose(a, b, rtol=TOL_SCALAR, atol=TOL_SCALAR, err_msg=f"{label}:{k}")
+    obs, wobs = g("obs_buf"), want["out_obs_buf"]
+    np.testing.assert_allclose(obs[:, 0:4], wobs[:, 0:4], rtol=TOL_SCALAR, atol=TOL_SCALAR, err_msg=f"{label}:obs[:, :4]")
+    for k, scale in (("ray_dist", 1.0), ("wheel_dist", 1.0), ("body_dist", 1.0)):
+        if k in got and ("out_" + k) in want:
+            d = np.abs(g(k).astype(np.float64) - want["out_" + k].astype(np.float64))
+            frac = float((d > TOL_RAY).mean())
+            assert frac <= RAY_FLIP_BUDGET, f"{label}:{k}: {frac:.4%} of rays differ by > {TOL_RAY}"
+    d = np.abs(obs[:, 4:].astype(np.float64) - wobs[:, 4:].astype(np.float64))
+    assert float((d > TOL_RAY / 2).mean()) <= RAY_FLIP_BUDGET, f"{label}:obs heightmap part"
+    # integer outputs: exact unless the deciding value sits within 1e-3 of its threshold
+    for k in ("rock_collision", "reset_buf", "progress_buf"):
+        if k in got and ("out_" + k) in want:
+            a, b = g(k), want["out_" + k]
+            bad = np.nonzero(a != b)[0]
+            if k == "progress_buf" or len(bad) == 0:
+                np.testing.assert_array_equal(a, b, err_msg=f"{label}:{k}")
+                continue
+            wd, bd = want["out_wheel_dist"], want["out_body_dist"]
+            for e in bad:
+                near = abs(abs(wd[e].min()) - 0.8) < 1e-3 or abs(abs(bd[e].min()) - 0.45) < 1e-3
+                assert near, f"{label}:{k} differs at env {e} away from any threshold"
