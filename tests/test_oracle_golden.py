@@ -67,7 +67,9 @@ def test_reset_path_matches_reference():
     fx = load_golden("reset_path")
     scene = scene_for(fx)
     info = fx["stone_info"]
-    np.testing.assert_allclose(orc.clearance(info, fx["xy"]), fx["clearance"], rtol=1e-6, atol=1e-6)
+    # torch.cdist switches to the |x|^2+|y|^2-2xy matmul form above 25 rows (cancellation ~1e-5 at 13 m,
+    # ~1e-4 at 60 m); the restatement uses the direct form, so the stated tolerance here is 2e-4
+    np.testing.assert_allclose(orc.clearance(info, fx["xy"]), fx["clearance"], rtol=0, atol=2e-4)
     np.testing.assert_array_equal(orc.pos_height(scene.heightmap, fx["xy"]), fx["heights"])
     shifted, _ = orc.shift_spawns(info, fx["spawn_in"])
     np.testing.assert_allclose(shifted, fx["spawn_out"], rtol=0, atol=1e-5)
