@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the rover step hot path (obs + reward + done + done compaction) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused RLTask.post_physics_step (rl_task.py:239-259) over one batch of synthetic sim states
+that are already resident in HBM: get_observations (P terrain rays + 26 rock rays per rover against the
+K triangles of their 0.1 m cell) + calculate_metrics + is_done + done compaction, through the C ABI
+(rover_step).  Default workload = BASELINE.json configs[2] — the config the north star's >= 4 M env-steps/s
+target is quoted on: 65 536 envs per GPU, 37-point radial heightmap + 26 rock-collision rays, 600 x 600 cell
+maps with K = 200.  For N > 1 every rank runs the same number of envs (weak scaling) and
+the step ends with the RCCL gather of (obs, reward, done) to rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the ray-cast kernel: algorithmic bytes (18 B per ray-triangle pair) / HIP-event time vs 8 TB/s
+  cpu_baseline — the CPU oracle (oracle/rover_oracle.c, OpenMP) timed on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--rays", default="37", choices=["9", "37", "120"])
+    ap.add_argument("--cells", type=int, default=600)
+    ap.add_argument("--k", type=int, default=200)
+    ap.add_argument("--stones", type=int, default=1024)
+    ap.add_argument("--validate-goals", action="store_true",
+                    help="configs[4]: also run the reset/spawn-goal validation kernel on the envs flagged done each step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-envs", type=int, default=2048)
+    ap.add_argument("--scene-cache", default=os.environ.get("ROVER_SCENE_CACHE", ""))
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_env_step(p, k, ns, nd, r=26):
+    """B = (P + R) K 18 + 128 + (4 + Ns + Nd) 4 + 56."""
+    return (p + r) * k * 18 + 128 + (4 + ns + nd) * 4 + 56
+
+
+def load_scene(args, device):
+    from isaac_rover_amd import synth
+    key = f"scene_c{args.cells}_k{args.k}_s{args.stones}.pt"
+    path = os.path.join(args.scene_cache, key) if args.scene_cache else ""
+    if path and os.path.exists(path):
+        return torch.load(path, weights_only=False)
+    scene = synth.make_scene(n_cells=args.cells, k=args.k, n_stones=args.stones, device=device)
+    if path:
+        os.makedirs(args.scene_cache, exist_ok=True)
+        torch.save(scene, path)
+    return scene
+
+
+def cpu_baseline(args, scene, distn, states):
+    """Oracle (plain C + OpenMP, kind='port') on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    n = min(args.cpu_sample_envs, states["pos"].shape[0])
+    st = {k: v[:n].cpu() for k, v in states.items()}
+    t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
+    orc.step(t, r, st, *distn)                      # warm-up (page-in, thread pool)
+    best, reps, t_all = float("inf"), 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 20):
+        t0 = time.perf_counter()
+        orc.step(t, r, st, *distn)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": n / best, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {reps} reps of the same workload (P={distn[0].shape[0]}, K={args.k}, "
+                      f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rover step path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from isaac_rover_amd import _lib, synth
+    from isaac_rover_amd.distributed import StepGather
+
+    E = args.envs_per_gpu
+    E_global = E * world
+    scene = load_scene(args, device)
+    distn = synth.ray_distribution(args.rays)
+    eng = _lib.Engine(E, device=local_rank, num_envs_global=E_global, env_offset=rank * E)
+    eng.set_scene(scene, distn)
+    info = eng.info()
+    W = eng.num_observations
+
+    # 4 resident state batches, rotated, so consecutive steps do not replay identical rays
+    batches = []
+    for b in range(4):
+        st = synth.make_states(E, args.cells * 0.1, seed=100 * rank + b)
+        batches.append({k: v.to(device) for k, v in st.items()})
+    gather = StepGather(E, W, device, world, rank)
+    obs, rew, reset = gather.local_views()
+    rock = torch.zeros(E, dtype=torch.int64, device=device)
+    extras = {k: torch.zeros(E, dtype=(torch.int64 if k == "collision_penalty" else torch.float32), device=device)
+              for k in _lib.EXTRAS}
+    reset_ids = torch.zeros(E, dtype=torch.int64, device=device)
+    n_reset = torch.zeros(1, dtype=torch.int32, device=device)
+    sout = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, extras=extras, reset_ids=reset_ids, n_reset=n_reset)
+    sins = [eng.make_in(b["pos"], b["quat"], b["joints"], b["target"], b["lin_hist"], b["ang_hist"], b["euler_pre"],
+                        b["progress"]) for b in batches]
+    if args.validate_goals:
+        n_used = torch.zeros(1, dtype=torch.int32, device=device)
+        initial = [b["pos"].clone() for b in batches]
+
+    def one_step(i):
+        b = i % len(batches)
+        eng.step(sins[b], sout, increment_progress=True, compact=True)
+        if args.validate_goals:
+            # reset/spawn-goal validation for the envs flagged done (configs[4]); the count is read on the host
+            # exactly like rover.py:356-357 does
+            n = int(n_reset.item())
+            if n:
+                ids = reset_ids[:n] - rank * E
+                eng.generate_goals(ids, initial[b], batches[b]["target"], seed=i, max_draws=256, n_draws_used=n_used)
+        gather.gather()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = E_global * args.steps / elapsed
+        ray_ms = prof.raycast_ms / max(prof.launches, 1)
+        ray_bytes = 18.0 * prof.pairs_per_launch                       # algorithmic: 18 B per (ray, triangle)
+        achieved = ray_bytes / (ray_ms * 1e-3) / 1e9 if ray_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"E{E}_P{args.rays}_K{args.k}_C{args.cells}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/sec (obs+reward+done)", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{4 if args.validate_goals else 2}]: {E} envs/GPU x {world} GPU, "
+                                   f"{args.rays}-point heightmap + 26 rock rays, K={args.k}, {args.cells}x{args.cells} "
+                                   f"cells @0.1 m, stones={args.stones}"
+                                   + (", + goal validation" if args.validate_goals else "")
+                                   + (", RCCL gather(obs,rew,done)->rank0" if world > 1 else ""),
+                       "envs_total": E_global, "rays_per_env": int(args.rays) + 26, "obs_dim": W,
+                       "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(int(args.rays), args.k, eng.Ns, eng.Nd),
+                       "table_bytes": int(info.table_bytes[0] + info.table_bytes[1])},
+            "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": ray_ms, "launches": int(prof.launches),
+                         "algorithmic_bytes_per_launch": ray_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, scene, distn, batches[0])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

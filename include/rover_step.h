@@ -1,0 +1,182 @@
+/*
+ * rover_step.h — C ABI of librover_step.so: the MI355X (gfx950) implementation of the rover task's
+ * vectorised env.step() hot path of abmoRobotics/isaac_rover_2.0.
+ *
+ * The reference is pure Python/PyTorch and has no FFI; each entry point below names the reference
+ * function(s) it replaces (paths relative to omniisaacgymenvs/ in the reference repository).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add to call them from
+ * tasks/rover.py.
+ *
+ * Conventions
+ *  - Plain C, no torch types.  All `*_d` / step pointers are DEVICE pointers the caller owns (e.g.
+ *    tensor.data_ptr()); the library borrows them for the duration of the call and never frees them.
+ *  - `set_*` calls take HOST or DEVICE pointers (hipMemcpyDefault), copy into library-owned device memory,
+ *    and synchronise; they are init-time calls.
+ *  - Step calls only enqueue work on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *    do not synchronise.  A ctx belongs to one host thread at a time; distinct ctxs are independent.
+ *  - Every function returns 0 on success or a negative ROVER_E_* code; rover_last_error() gives the text.
+ *    No C++ exception crosses the boundary.
+ *  - float = IEEE binary32, env-major row-major arrays, quaternions (w,x,y,z), int64 flags like the
+ *    reference's torch.long buffers (tasks/base/rl_task.py:98-107).
+ */
+#ifndef ROVER_STEP_H
+#define ROVER_STEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROVER_API __attribute__((visibility("default")))
+
+#define ROVER_OK            0
+#define ROVER_E_INVALID    -1   /* bad argument / shape                         */
+#define ROVER_E_STATE      -2   /* required set_* call missing                  */
+#define ROVER_E_HIP        -3   /* HIP runtime error (text has the HIP message) */
+#define ROVER_E_NOMEM      -4
+
+#define ROVER_MAP_TERRAIN   0   /* tasks/utils/terrain/knn_terrain/{map_indices,triangles,vertices}.pt (camera.py:154-161)      */
+#define ROVER_MAP_ROCKS     1   /* tasks/utils/terrain/knn_rocks/{...}.pt (rock_detect.py:151-158)  */
+
+/* rover_step() flags */
+#define ROVER_STEP_INCREMENT_PROGRESS 1u  /* progress_buf += 1 first (rl_task.py:250)                      */
+#define ROVER_STEP_COMPACT            2u  /* also emit reset_ids / n_reset (rover.py:356)                   */
+
+typedef struct rover_ctx rover_ctx;
+
+/* Constants the reference keeps in cfg/task/Rover.yaml:11,37-46 and hard-codes in rover.py:119,101,353 */
+typedef struct {
+    int32_t num_envs;              /* envs handled by this ctx (this GPU's shard)                         */
+    int32_t num_envs_global;       /* self.num_envs of rover.py:517 (collision_penalty); 0 = num_envs     */
+    int32_t env_offset;            /* global id of local env 0 (compaction emits global ids)              */
+    int32_t device;                /* HIP device ordinal                                                   */
+    int32_t curriculum_level;      /* rover.py:101,353: rock collision active when >= 2                    */
+    int32_t max_episode_length;    /* rover.py:119 (3000)                                                  */
+    float pos_reward;              /* Rover.yaml:39 */
+    float heading_contraint_reward;/* Rover.yaml:43 */
+    float motion_contraint_reward; /* Rover.yaml:44 */
+    float goal_angle_reward;       /* Rover.yaml:45 */
+    float boogie_contraint_reward; /* Rover.yaml:46 */
+} rover_cfg;
+
+/* Sim state in (rover.py:274-275,291,343,470-476; Memory rover.py:60-77).  Device pointers. */
+typedef struct {
+    const float *pos;        /* [E,3]  RoverView.get_world_poses()[0]                                     */
+    const float *quat;       /* [E,4]  RoverView.get_world_poses()[1], (w,x,y,z)                          */
+    const float *joints;     /* [E,13] RoverView.get_joint_positions()  (legend rock_detect.py:175-187)   */
+    const float *target;     /* [E,3]  self.target_positions                                              */
+    const float *lin_hist;   /* [E,3]  linear_velocity.tracker, newest first                              */
+    const float *ang_hist;   /* [E,3]  angular_velocity.tracker                                           */
+    const float *euler_pre;  /* [E,3]  self.rover_rot captured in pre_physics_step (rover.py:343)         */
+    int64_t *progress;       /* [E]    progress_buf (in/out)                                              */
+} rover_step_in;
+
+/* Outputs (rl_task.py:98-107 buffers, rover.py:524-531 extras).  Device pointers; NULL = not wanted
+ * for the optional ones. */
+typedef struct {
+    float *obs;                    /* [E, obs_stride] obs_buf; row = [4 proprio | Ns sparse | Nd dense]   */
+    int64_t obs_stride;            /* elements per obs row; 0 = 4+Ns+Nd                                   */
+    float *rew;                    /* [E] rew_buf                                                         */
+    int64_t *reset;                /* [E] reset_buf                                                       */
+    int64_t *rock_collision;       /* [E] self.rock_collison (rover.py:667-668)                           */
+    float *ex_pos_reward;          /* [E] extras, rover.py:524-531 — all optional                         */
+    int64_t *ex_collision_penalty;
+    float *ex_uprightness_penalty;
+    float *ex_heading_contraint_penalty;
+    float *ex_motion_contraint_penalty;
+    float *ex_goal_angle_penalty;
+    float *ex_torque_penalty_driving;
+    float *ex_torque_penalty_steering;
+    int64_t *reset_ids;            /* [E] ascending global env ids with reset != 0 (ROVER_STEP_COMPACT)   */
+    int32_t *n_reset;              /* [1]                                                                 */
+    float *euler;                  /* optional [E,3] self.rover_rotation (rover.py:275)                   */
+    float *heading_diff;           /* optional [E]   self.heading_diff  (rover.py:283)                    */
+    float *ray_dist;               /* optional [E,P] Camera.get_depths distances (camera.py:145)          */
+    float *wheel_dist;             /* optional [E,24] rock_detect.py:146                                  */
+    float *body_dist;              /* optional [E,2]  rock_detect.py:147                                  */
+} rover_step_out;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+ROVER_API int rover_create(const rover_cfg *cfg, rover_ctx **out);        /* RoverTask.__init__ rover.py:81-185 */
+ROVER_API void rover_destroy(rover_ctx *ctx);
+ROVER_API const char *rover_last_error(const rover_ctx *ctx);             /* ctx may be NULL: last create error */
+ROVER_API const char *rover_version(void);
+
+/* ---- init-time tables ------------------------------------------------------------------------------ */
+/* Camera._load_triangles_with_indices camera.py:154-161 / Rock_Detection rock_detect.py:151-158.
+ * map_idx [X][Y][K] int32 (the layout after the two swapaxes), tris [T][3] int32, verts [V][3] IEEE half bits.
+ * The library re-packs the three tables into one per-cell contiguous fp16 block [X*Y][9][K8]. */
+ROVER_API int rover_set_knn_map(rover_ctx *ctx, int which, const int32_t *map_idx, int32_t X, int32_t Y, int32_t K,
+                                const int32_t *tris, int32_t T, const uint16_t *verts_f16, int32_t V,
+                                float cell_size, float shift_x, float shift_y);
+/* Heightmap (heightmap_distribution.py:11-134): points [P][3] float64 in the post-swap frame, index lists */
+ROVER_API int rover_set_distribution(rover_ctx *ctx, const double *points, int32_t P, const int64_t *sparse_idx,
+                                     int32_t Ns, const int64_t *dense_idx, int32_t Nd);
+/* heightmap_tensor.pt, rover.py:210-213 */
+ROVER_API int rover_set_heightfield(rover_ctx *ctx, const float *hm, int32_t N0, int32_t N1, float horizontal_scale,
+                                    float vertical_scale, float shift_x, float shift_y);
+/* read_stone_info output [S][7] float32 (utils/terrain_utils/terrain_utils.py:416-424) */
+ROVER_API int rover_set_stones(rover_ctx *ctx, const float *info7, int32_t S);
+ROVER_API int rover_set_curriculum_level(rover_ctx *ctx, int32_t level);  /* rover.py:353 */
+
+/* ---- per-step hot path ----------------------------------------------------------------------------- */
+/* One fused RLTask.post_physics_step (rl_task.py:239-259): get_observations + calculate_metrics + is_done
+ * (+ progress increment, + done compaction), same dataflow and order as the reference. */
+ROVER_API int rover_step(rover_ctx *ctx, const rover_step_in *in, const rover_step_out *out, uint32_t flags, void *stream);
+/* The same three stages as separate calls, for a task that keeps the reference's method split:
+ * RoverTask.get_observations rover.py:272-336 (writes obs, rock_collision, optional intermediates) */
+ROVER_API int rover_get_observations(rover_ctx *ctx, const rover_step_in *in, const rover_step_out *out, void *stream);
+/* RoverTask.calculate_metrics rover.py:460-531 (reads out->rock_collision and the heading/position state
+ * left by the last rover_get_observations on this ctx; writes rew + extras) */
+ROVER_API int rover_calculate_metrics(rover_ctx *ctx, const rover_step_in *in, const rover_step_out *out, void *stream);
+/* RoverTask.is_done rover.py:610-647 (writes reset) */
+ROVER_API int rover_is_done(rover_ctx *ctx, const rover_step_in *in, const rover_step_out *out, void *stream);
+/* reset_buf.nonzero() rover.py:356 without the host sync: ids ascending (+env_offset), count to n_reset[0] */
+ROVER_API int rover_compact_resets(rover_ctx *ctx, const int64_t *reset, int64_t *reset_ids, int32_t *n_reset, void *stream);
+/* tensor_quat_to_eul tasks/utils/math/tensor_quat_to_euler.py:6-31 */
+ROVER_API int rover_quat_to_euler(rover_ctx *ctx, const float *quat, float *euler, int32_t n, void *stream);
+
+/* ---- reset / spawn / goal validation (rover.py:533-564, 588-608, 649-661) ---------------------------- */
+/* nearest_rock = min_s(|p - stone_s| - r_s)  (rover.py:536-538,655-658); xy [n][2] -> out [n] */
+ROVER_API int rover_clearance(rover_ctx *ctx, const float *xy, int32_t n, float *out, void *stream);
+/* avoid_pos_rock_collision rover.py:649-661: per env, x += 0.05 while clearance <= 1.4; pos [n][3] in place */
+ROVER_API int rover_shift_spawns(rover_ctx *ctx, float *pos3, int32_t n, int32_t max_iter, void *stream);
+/* get_pos_height rover.py:588-608: xy [n][2] -> out [n] */
+ROVER_API int rover_sample_height(rover_ctx *ctx, const float *xy, int32_t n, float *out, void *stream);
+/* generate_goals + random_goals + check_goal_collision rover.py:533-564, radius 8 (rover.py:578), then the
+ * goal z lookup of set_targets rover.py:582-583.  env_ids [n] int64 (local ids into target3/initial_pos3);
+ * draws = [max_draws][n] uniforms in [0,1) replacing torch.rand (NULL = library Philox stream seeded by
+ * `seed`); reproduces the env_ids = mask*env_ids aliasing of rover.py:540.  n_draws_used[0] (optional)
+ * receives the number of draws consumed, or -1 if max_draws ran out before every goal was clear. */
+ROVER_API int rover_generate_goals(rover_ctx *ctx, const int64_t *env_ids, int32_t n, const float *initial_pos3,
+                                   float *target3, float radius, const float *draws, int32_t max_draws, uint64_t seed,
+                                   int32_t *n_draws_used, void *stream);
+
+/* ---- action side ("next" row f-1): Ackermann tasks/utils/kinematics.py:13-67 --------------------------- */
+/* lin, ang [n] -> steering [n][6], velocities [n][6] in wheel order FL,FR,ML,MR,RL,RR */
+ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang, int32_t n, float *steering,
+                              float *velocities, void *stream);
+
+/* ---- introspection (bench / roofline) ---------------------------------------------------------------- */
+typedef struct {
+    int32_t P, Ns, Nd, rays_per_env_padded;
+    int32_t K[2], K8[2], X[2], Y[2];
+    uint64_t table_bytes[2];       /* re-packed per-cell fp16 tables */
+    uint64_t workspace_bytes;
+} rover_info;
+ROVER_API int rover_get_info(const rover_ctx *ctx, rover_info *info);
+/* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with
+ * hipEvents on the caller's stream (ring of 256 pairs).  rover_get_profile synchronises those events and
+ * returns the summed ray-cast time and launch count since the last rover_set_profiling(ctx, 1). */
+typedef struct { double raycast_ms; int32_t launches; uint64_t pairs_per_launch; } rover_profile;
+ROVER_API int rover_set_profiling(rover_ctx *ctx, int32_t enable);
+ROVER_API int rover_get_profile(rover_ctx *ctx, rover_profile *out);
+/* Launch ONLY the ray-cast kernel on the ray records left by the last step (for hipEvent timing of the
+ * roofline kernel in isolation; results are rewritten identically). */
+ROVER_API int rover_replay_raycast(rover_ctx *ctx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROVER_STEP_H */

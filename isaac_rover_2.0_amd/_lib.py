@@ -1,0 +1,364 @@
+"""ctypes binding of librover_step.so (C ABI in include/rover_step.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this module raises.
+Tensors are PyTorch-ROCm tensors; only their ``data_ptr()`` crosses the boundary, and work is
+enqueued on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librover_step.so")
+
+MAP_TERRAIN, MAP_ROCKS = 0, 1
+STEP_INCREMENT_PROGRESS, STEP_COMPACT = 1, 2
+
+EXTRAS = ("pos_reward", "collision_penalty", "uprightness_penalty", "heading_contraint_penalty",
+          "motion_contraint_penalty", "goal_angle_penalty", "torque_penalty_driving", "torque_penalty_steering")
+
+
+class RoverError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_envs_global", C.c_int32), ("env_offset", C.c_int32),
+                ("device", C.c_int32), ("curriculum_level", C.c_int32), ("max_episode_length", C.c_int32),
+                ("pos_reward", C.c_float), ("heading_contraint_reward", C.c_float),
+                ("motion_contraint_reward", C.c_float), ("goal_angle_reward", C.c_float),
+                ("boogie_contraint_reward", C.c_float)]
+
+
+class StepIn(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pos", "quat", "joints", "target", "lin_hist", "ang_hist", "euler_pre",
+                                          "progress")]
+
+
+class StepOut(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("obs_stride", C.c_int64), ("rew", C.c_void_p), ("reset", C.c_void_p),
+                ("rock_collision", C.c_void_p), ("ex_pos_reward", C.c_void_p), ("ex_collision_penalty", C.c_void_p),
+                ("ex_uprightness_penalty", C.c_void_p), ("ex_heading_contraint_penalty", C.c_void_p),
+                ("ex_motion_contraint_penalty", C.c_void_p), ("ex_goal_angle_penalty", C.c_void_p),
+                ("ex_torque_penalty_driving", C.c_void_p), ("ex_torque_penalty_steering", C.c_void_p),
+                ("reset_ids", C.c_void_p), ("n_reset", C.c_void_p), ("euler", C.c_void_p),
+                ("heading_diff", C.c_void_p), ("ray_dist", C.c_void_p), ("wheel_dist", C.c_void_p),
+                ("body_dist", C.c_void_p)]
+
+
+class Info(C.Structure):
+    _fields_ = [("P", C.c_int32), ("Ns", C.c_int32), ("Nd", C.c_int32), ("rays_per_env_padded", C.c_int32),
+                ("K", C.c_int32 * 2), ("K8", C.c_int32 * 2), ("X", C.c_int32 * 2), ("Y", C.c_int32 * 2),
+                ("table_bytes", C.c_uint64 * 2), ("workspace_bytes", C.c_uint64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("raycast_ms", C.c_double), ("launches", C.c_int32), ("pairs_per_launch", C.c_uint64)]
+
+
+# every symbol include/rover_step.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "rover_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(_P)]),
+    "rover_destroy": (None, [_P]),
+    "rover_last_error": (C.c_char_p, [_P]),
+    "rover_version": (C.c_char_p, []),
+    "rover_set_knn_map": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
+                                    C.c_float, C.c_float, C.c_float]),
+    "rover_set_distribution": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32]),
+    "rover_set_heightfield": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "rover_set_stones": (C.c_int, [_P, _P, C.c_int32]),
+    "rover_set_curriculum_level": (C.c_int, [_P, C.c_int32]),
+    "rover_step": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), C.c_uint32, _P]),
+    "rover_get_observations": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), _P]),
+    "rover_calculate_metrics": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), _P]),
+    "rover_is_done": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), _P]),
+    "rover_compact_resets": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rover_quat_to_euler": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "rover_clearance": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "rover_shift_spawns": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "rover_sample_height": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "rover_generate_goals": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_float, _P, C.c_int32, C.c_uint64, _P, _P]),
+    "rover_ackermann": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
+    "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
+    "rover_replay_raycast": (C.c_int, [_P, _P]),
+    "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
+    "rover_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_internal.h")]
+    srcs.append(os.path.join(os.path.dirname(_CSRC), "..", "include", "rover_step.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["bash", os.path.join(_CSRC, "build.sh")])
+    return LIB_PATH
+
+
+def load():
+    """dlopen librover_step.so and bind every declared symbol; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RoverError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback for the rover step path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)      # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _host(a, dtype):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    """One rover_ctx: owns the device tables, launches the step kernels on torch's current stream."""
+
+    def __init__(self, num_envs, device=0, num_envs_global=0, env_offset=0, curriculum_level=2,
+                 max_episode_length=3000, rewards=None):
+        self.lib = load()
+        rw = dict(pos_reward=1.0, heading_contraint_reward=0.05, motion_contraint_reward=-0.01,
+                  goal_angle_reward=0.3, boogie_contraint_reward=0.5)
+        rw.update({k: v for k, v in (rewards or {}).items() if k in rw})
+        if isinstance(device, torch.device):
+            device = device.index or 0
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", int(device))
+        self.cfg = Cfg(self.num_envs, int(num_envs_global), int(env_offset), int(device), int(curriculum_level),
+                       int(max_episode_length), rw["pos_reward"], rw["heading_contraint_reward"],
+                       rw["motion_contraint_reward"], rw["goal_angle_reward"], rw["boogie_contraint_reward"])
+        h = C.c_void_p()
+        rc = self.lib.rover_create(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise RoverError(f"rover_create failed ({rc}): {self.lib.rover_last_error(None).decode()}")
+        self._h = h
+        self.P = self.Ns = self.Nd = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.rover_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RoverError(f"{what} failed ({rc}): {self.lib.rover_last_error(self._h).decode()}")
+
+    # ---- tables -------------------------------------------------------------------------------
+    def set_knn_map(self, which, map_indices, triangles, vertices, cell_size=0.1, shift=(0.0, 0.0)):
+        idx = _host(map_indices, np.int32)
+        tris = _host(triangles, np.int32)
+        v = vertices.detach().cpu().numpy() if isinstance(vertices, torch.Tensor) else np.asarray(vertices)
+        verts = np.ascontiguousarray(v.astype(np.float16)).view(np.uint16)
+        if idx.ndim != 3 or tris.ndim != 2 or tris.shape[1] != 3 or verts.ndim != 2 or verts.shape[1] != 3:
+            raise RoverError("set_knn_map: expected map_indices [X,Y,K], triangles [T,3], vertices [V,3]")
+        x, y, k = idx.shape
+        self._check(self.lib.rover_set_knn_map(self._h, which, idx.ctypes.data, x, y, k, tris.ctypes.data,
+                                               tris.shape[0], verts.ctypes.data, verts.shape[0], cell_size,
+                                               float(shift[0]), float(shift[1])), "rover_set_knn_map")
+
+    def set_distribution(self, points, sparse_idx, dense_idx):
+        pts = _host(points, np.float64)
+        sp = _host(sparse_idx, np.int64)
+        de = _host(dense_idx, np.int64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise RoverError("set_distribution: points must be [P,3]")
+        self._check(self.lib.rover_set_distribution(self._h, pts.ctypes.data, pts.shape[0], sp.ctypes.data, len(sp),
+                                                    de.ctypes.data, len(de)), "rover_set_distribution")
+        self.P, self.Ns, self.Nd = pts.shape[0], len(sp), len(de)
+
+    def set_heightfield(self, heightmap, horizontal_scale=0.025, vertical_scale=1.0, shift=(0.0, 0.0)):
+        hm = _host(heightmap, np.float32)
+        self._check(self.lib.rover_set_heightfield(self._h, hm.ctypes.data, hm.shape[0], hm.shape[1],
+                                                   horizontal_scale, vertical_scale, float(shift[0]), float(shift[1])),
+                    "rover_set_heightfield")
+
+    def set_stones(self, info7):
+        info = _host(info7, np.float32)
+        if info.ndim != 2 or info.shape[1] != 7:
+            raise RoverError("set_stones: expected [S,7] (read_stone_info output)")
+        self._check(self.lib.rover_set_stones(self._h, info.ctypes.data, info.shape[0]), "rover_set_stones")
+
+    def set_curriculum_level(self, level):
+        self._check(self.lib.rover_set_curriculum_level(self._h, int(level)), "rover_set_curriculum_level")
+
+    def set_scene(self, scene, distribution):
+        """Convenience: load a synth.Scene + (points, sparse_idx, dense_idx)."""
+        from . import synth
+        sh = scene.shift[0:2]
+        self.set_knn_map(MAP_TERRAIN, scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices,
+                         scene.terrain.cell_size, sh)
+        self.set_knn_map(MAP_ROCKS, scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices,
+                         scene.rocks.cell_size, sh)
+        self.set_distribution(*distribution)
+        self.set_heightfield(scene.heightmap, scene.horizontal_scale, scene.vertical_scale, sh)
+        self.set_stones(synth.read_stone_info_array(scene.stone_info_raw))
+
+    @property
+    def num_observations(self):
+        return 4 + self.Ns + self.Nd
+
+    def info(self):
+        i = Info()
+        self._check(self.lib.rover_get_info(self._h, C.byref(i)), "rover_get_info")
+        return i
+
+    # ---- step ---------------------------------------------------------------------------------
+    def _chk(self, t, shape, dtype, name):
+        if t is None:
+            return
+        if not t.is_cuda or t.device != self.device:
+            raise RoverError(f"{name}: expected a tensor on {self.device}, got {t.device}")
+        if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise RoverError(f"{name}: expected contiguous {dtype} {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+
+    def make_in(self, pos, quat, joints, target, lin_hist, ang_hist, euler_pre, progress):
+        e, f = self.num_envs, torch.float32
+        for t, s, n in ((pos, (e, 3), "pos"), (quat, (e, 4), "quat"), (joints, (e, 13), "joints"),
+                        (target, (e, 3), "target"), (lin_hist, (e, 3), "lin_hist"), (ang_hist, (e, 3), "ang_hist"),
+                        (euler_pre, (e, 3), "euler_pre")):
+            self._chk(t, s, f, n)
+        self._chk(progress, (e,), torch.int64, "progress")
+        return StepIn(*[_ptr(t) for t in (pos, quat, joints, target, lin_hist, ang_hist, euler_pre, progress)])
+
+    def make_out(self, obs, rew=None, reset=None, rock_collision=None, extras=None, reset_ids=None, n_reset=None,
+                 euler=None, heading_diff=None, ray_dist=None, wheel_dist=None, body_dist=None):
+        e, f, i64 = self.num_envs, torch.float32, torch.int64
+        stride = 0
+        if obs is not None:
+            if obs.dim() != 2 or obs.shape[0] != e or obs.shape[1] != self.num_observations or obs.stride(1) != 1:
+                raise RoverError(f"obs: expected [{e},{self.num_observations}] float32 rows, got {tuple(obs.shape)}")
+            if obs.dtype != f or not obs.is_cuda:
+                raise RoverError("obs: expected float32 on the GPU")
+            stride = obs.stride(0)
+        self._chk(rew, (e,), f, "rew")
+        self._chk(reset, (e,), i64, "reset")
+        self._chk(rock_collision, (e,), i64, "rock_collision")
+        self._chk(reset_ids, (e,), i64, "reset_ids")
+        self._chk(n_reset, (1,), torch.int32, "n_reset")
+        self._chk(euler, (e, 3), f, "euler")
+        self._chk(heading_diff, (e,), f, "heading_diff")
+        self._chk(ray_dist, (e, self.P), f, "ray_dist")
+        self._chk(wheel_dist, (e, 24), f, "wheel_dist")
+        self._chk(body_dist, (e, 2), f, "body_dist")
+        ex = extras or {}
+        for k in EXTRAS:
+            self._chk(ex.get(k), (e,), i64 if k == "collision_penalty" else f, "extras." + k)
+        return StepOut(_ptr(obs), stride, _ptr(rew), _ptr(reset), _ptr(rock_collision),
+                       *[_ptr(ex.get(k)) for k in EXTRAS], _ptr(reset_ids), _ptr(n_reset), _ptr(euler),
+                       _ptr(heading_diff), _ptr(ray_dist), _ptr(wheel_dist), _ptr(body_dist))
+
+    def step(self, sin: StepIn, sout: StepOut, increment_progress=True, compact=False):
+        flags = (STEP_INCREMENT_PROGRESS if increment_progress else 0) | (STEP_COMPACT if compact else 0)
+        self._check(self.lib.rover_step(self._h, C.byref(sin), C.byref(sout), flags, _stream()), "rover_step")
+
+    def get_observations(self, sin, sout):
+        self._check(self.lib.rover_get_observations(self._h, C.byref(sin), C.byref(sout), _stream()),
+                    "rover_get_observations")
+
+    def calculate_metrics(self, sin, sout):
+        self._check(self.lib.rover_calculate_metrics(self._h, C.byref(sin), C.byref(sout), _stream()),
+                    "rover_calculate_metrics")
+
+    def is_done(self, sin, sout):
+        self._check(self.lib.rover_is_done(self._h, C.byref(sin), C.byref(sout), _stream()), "rover_is_done")
+
+    def compact_resets(self, reset, reset_ids, n_reset):
+        self._chk(reset, (self.num_envs,), torch.int64, "reset")
+        self._chk(reset_ids, (self.num_envs,), torch.int64, "reset_ids")
+        self._chk(n_reset, (1,), torch.int32, "n_reset")
+        self._check(self.lib.rover_compact_resets(self._h, _ptr(reset), _ptr(reset_ids), _ptr(n_reset), _stream()),
+                    "rover_compact_resets")
+
+    def quat_to_euler(self, quat, out=None):
+        n = quat.shape[0]
+        self._chk(quat, (n, 4), torch.float32, "quat")
+        out = torch.empty(n, 3, device=self.device) if out is None else out
+        self._chk(out, (n, 3), torch.float32, "euler")
+        self._check(self.lib.rover_quat_to_euler(self._h, _ptr(quat), _ptr(out), n, _stream()), "rover_quat_to_euler")
+        return out
+
+    def set_profiling(self, enable=True):
+        self._check(self.lib.rover_set_profiling(self._h, 1 if enable else 0), "rover_set_profiling")
+
+    def get_profile(self):
+        p = Profile()
+        self._check(self.lib.rover_get_profile(self._h, C.byref(p)), "rover_get_profile")
+        return p
+
+    def replay_raycast(self, stream=None):
+        s = _stream() if stream is None else C.c_void_p(stream)
+        self._check(self.lib.rover_replay_raycast(self._h, s), "rover_replay_raycast")
+
+    # ---- reset path ----------------------------------------------------------------------------
+    def clearance(self, xy):
+        n = xy.shape[0]
+        self._chk(xy, (n, 2), torch.float32, "xy")
+        out = torch.empty(n, device=self.device)
+        self._check(self.lib.rover_clearance(self._h, _ptr(xy), n, _ptr(out), _stream()), "rover_clearance")
+        return out
+
+    def shift_spawns(self, pos3, max_iter=100000):
+        n = pos3.shape[0]
+        self._chk(pos3, (n, 3), torch.float32, "pos3")
+        self._check(self.lib.rover_shift_spawns(self._h, _ptr(pos3), n, int(max_iter), _stream()), "rover_shift_spawns")
+        return pos3
+
+    def sample_height(self, xy):
+        n = xy.shape[0]
+        self._chk(xy, (n, 2), torch.float32, "xy")
+        out = torch.empty(n, device=self.device)
+        self._check(self.lib.rover_sample_height(self._h, _ptr(xy), n, _ptr(out), _stream()), "rover_sample_height")
+        return out
+
+    def generate_goals(self, env_ids, initial_pos3, target3, radius=8.0, draws=None, max_draws=64, seed=0,
+                       n_draws_used=None):
+        n = env_ids.shape[0]
+        self._chk(env_ids, (n,), torch.int64, "env_ids")
+        self._chk(initial_pos3, (self.num_envs, 3), torch.float32, "initial_pos3")
+        self._chk(target3, (self.num_envs, 3), torch.float32, "target3")
+        if draws is not None:
+            self._chk(draws, (draws.shape[0], n), torch.float32, "draws")
+            max_draws = draws.shape[0]
+        self._chk(n_draws_used, (1,), torch.int32, "n_draws_used")
+        self._check(self.lib.rover_generate_goals(self._h, _ptr(env_ids), n, _ptr(initial_pos3), _ptr(target3),
+                                                  float(radius), _ptr(draws), int(max_draws), int(seed),
+                                                  _ptr(n_draws_used), _stream()), "rover_generate_goals")
+
+    def ackermann(self, lin, ang):
+        n = lin.shape[0]
+        self._chk(lin, (n,), torch.float32, "lin")
+        self._chk(ang, (n,), torch.float32, "ang")
+        steer = torch.empty(n, 6, device=self.device)
+        vel = torch.empty(n, 6, device=self.device)
+        self._check(self.lib.rover_ackermann(self._h, _ptr(lin), _ptr(ang), n, _ptr(steer), _ptr(vel), _stream()),
+                    "rover_ackermann")
+        return steer, vel

@@ -1,0 +1,480 @@
+// rover_capi.cpp — C-ABI layer of librover_step.so (include/rover_step.h): context, library-owned device
+// tables, argument checks, kernel sequencing.  No torch, no exceptions across the boundary.
+#include "../../include/rover_step.h"
+#include "rover_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rover;
+
+struct rover_ctx {
+    rover_cfg cfg{};
+    std::string err;
+    // re-packed maps
+    KnnDev map[2]{};
+    uint64_t table_bytes[2]{0, 0};
+    bool have_map[2]{false, false};
+    // distribution
+    double* d_dist = nullptr;       // [P][3]
+    int32_t* d_obs_idx = nullptr;   // [Ns+Nd]
+    int32_t P = 0, Ns = 0, Nd = 0;
+    bool have_dist = false;
+    // heightfield / stones
+    HeightDev hf{};
+    bool have_hf = false;
+    float* d_stones = nullptr;
+    int32_t S = 0;
+    bool have_stones = false;
+    // per-step workspace
+    uint32_t R8 = 0;
+    RayRec* d_rays = nullptr;
+    float* d_dist_out = nullptr;    // [E*R8]
+    float* d_euler = nullptr;       // [E,3]
+    float* d_heading = nullptr;     // [E]
+    int64_t* d_ids_work = nullptr;  // [E]
+    uint64_t workspace_bytes = 0;
+    bool rays_valid = false;
+    // in-situ ray-cast timing (rover_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev0, ev1;
+    int32_t prof_launches = 0;
+    double prof_ms = 0.0;
+    int32_t prof_pending = 0;
+};
+
+static const int kProfRing = 256;
+
+static int prof_drain(rover_ctx* c) {
+    for (int i = 0; i < c->prof_pending; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(c->ev1[i]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]);
+        if (e != hipSuccess) { c->prof_pending = 0; return ROVER_E_HIP; }
+        c->prof_ms += ms;
+    }
+    c->prof_pending = 0;
+    return ROVER_OK;
+}
+
+static thread_local std::string g_create_err;
+
+static int fail(rover_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) return fail((c), ROVER_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+static int use_device(rover_ctx* c) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return ROVER_OK;
+}
+
+template <typename T>
+static void dfree(T*& p) {
+    if (p) { (void)hipFree((void*)p); p = nullptr; }
+}
+
+static int alloc_workspace(rover_ctx* c) {
+    dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
+    const uint64_t E = (uint64_t)c->cfg.num_envs;
+    c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
+    const uint64_t n = E * c->R8;
+    if (n > 0xffffffffull) return fail(c, ROVER_E_INVALID, "num_envs * rays_per_env = %llu exceeds 2^32", (unsigned long long)n);
+    HIP_TRY(c, hipMalloc((void**)&c->d_rays, n * sizeof(RayRec)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_dist_out, n * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_euler, E * 3 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_ids_work, E * sizeof(int64_t)));
+    HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
+    HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
+    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float)) + E * (4 * sizeof(float) + sizeof(int64_t));
+    c->rays_valid = false;
+    return ROVER_OK;
+}
+
+extern "C" {
+
+const char* rover_version(void) { return "rover_step 0.1 (gfx950)"; }
+
+const char* rover_last_error(const rover_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int rover_create(const rover_cfg* cfg, rover_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, ROVER_E_INVALID, "rover_create: null argument");
+    if (cfg->num_envs <= 0) return fail(nullptr, ROVER_E_INVALID, "rover_create: num_envs must be > 0 (got %d)", cfg->num_envs);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, ROVER_E_HIP, "rover_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, ROVER_E_INVALID, "rover_create: device %d out of range (have %d)", cfg->device, ndev);
+    rover_ctx* c = new (std::nothrow) rover_ctx();
+    if (!c) return fail(nullptr, ROVER_E_NOMEM, "rover_create: out of host memory");
+    c->cfg = *cfg;
+    if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
+    if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { delete c; return fail(nullptr, ROVER_E_HIP, "hipSetDevice: %s", hipGetErrorString(e)); }
+    *out = c;
+    return ROVER_OK;
+}
+
+void rover_destroy(rover_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); }
+    dfree(c->d_dist); dfree(c->d_obs_idx);
+    { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
+    dfree(c->d_stones);
+    dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
+    for (auto& e : c->ev0) (void)hipEventDestroy(e);
+    for (auto& e : c->ev1) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X, int32_t Y, int32_t K, const int32_t* tris,
+                      int32_t T, const uint16_t* verts, int32_t V, float cell, float shift_x, float shift_y) {
+    if (!c) return ROVER_E_INVALID;
+    if (which != ROVER_MAP_TERRAIN && which != ROVER_MAP_ROCKS) return fail(c, ROVER_E_INVALID, "set_knn_map: which=%d", which);
+    if (!map_idx || !tris || !verts) return fail(c, ROVER_E_INVALID, "set_knn_map: null table pointer");
+    if (X <= 0 || Y <= 0 || K <= 0 || T <= 0 || V <= 0 || !(cell > 0.0f))
+        return fail(c, ROVER_E_INVALID, "set_knn_map: bad shape X=%d Y=%d K=%d T=%d V=%d cell=%g", X, Y, K, T, V, (double)cell);
+    if ((uint64_t)X * (uint64_t)Y > 0xffffffffull) return fail(c, ROVER_E_INVALID, "set_knn_map: X*Y exceeds 2^32 cells");
+    if (int r = use_device(c)) return r;
+    const uint64_t n_cells = (uint64_t)X * Y;
+    const uint32_t K8 = (uint32_t)((K + 7) / 8 * 8);
+    const uint64_t bytes = n_cells * 9ull * K8 * sizeof(uint16_t);
+    int32_t *d_idx = nullptr, *d_tris = nullptr;
+    uint16_t *d_verts = nullptr, *d_table = nullptr;
+    auto cleanup = [&]() { dfree(d_idx); dfree(d_tris); dfree(d_verts); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_idx, n_cells * K * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_tris, (uint64_t)T * 3 * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_verts, (uint64_t)V * 3 * sizeof(uint16_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_table, bytes)) != hipSuccess) {
+        cleanup(); dfree(d_table);
+        return fail(c, ROVER_E_NOMEM, "set_knn_map: hipMalloc (%llu B table): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    if ((e = hipMemcpy(d_idx, map_idx, n_cells * K * sizeof(int32_t), hipMemcpyDefault)) != hipSuccess ||
+        (e = hipMemcpy(d_tris, tris, (uint64_t)T * 3 * sizeof(int32_t), hipMemcpyDefault)) != hipSuccess ||
+        (e = hipMemcpy(d_verts, verts, (uint64_t)V * 3 * sizeof(uint16_t), hipMemcpyDefault)) != hipSuccess ||
+        (e = launch_repack(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, (uint32_t)V, d_table, nullptr)) != hipSuccess ||
+        (e = hipDeviceSynchronize()) != hipSuccess) {
+        cleanup(); dfree(d_table);
+        return fail(c, ROVER_E_HIP, "set_knn_map: %s", hipGetErrorString(e));
+    }
+    cleanup();
+    uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
+    dfree(old);
+    c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y};
+    c->table_bytes[which] = bytes;
+    c->have_map[which] = true;
+    c->rays_valid = false;
+    return ROVER_OK;
+}
+
+int rover_set_distribution(rover_ctx* c, const double* pts, int32_t P, const int64_t* sparse_idx, int32_t Ns,
+                           const int64_t* dense_idx, int32_t Nd) {
+    if (!c) return ROVER_E_INVALID;
+    if (!pts || P <= 0 || Ns < 0 || Nd < 0 || (Ns > 0 && !sparse_idx) || (Nd > 0 && !dense_idx))
+        return fail(c, ROVER_E_INVALID, "set_distribution: bad arguments (P=%d Ns=%d Nd=%d)", P, Ns, Nd);
+    if (int r = use_device(c)) return r;
+    std::vector<double> hp((size_t)P * 3);
+    std::vector<int64_t> hs((size_t)Ns), hd((size_t)Nd);
+    HIP_TRY(c, hipMemcpy(hp.data(), pts, hp.size() * sizeof(double), hipMemcpyDefault));
+    if (Ns) HIP_TRY(c, hipMemcpy(hs.data(), sparse_idx, hs.size() * sizeof(int64_t), hipMemcpyDefault));
+    if (Nd) HIP_TRY(c, hipMemcpy(hd.data(), dense_idx, hd.size() * sizeof(int64_t), hipMemcpyDefault));
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)Ns + Nd);
+    for (int64_t v : hs) idx.push_back((int32_t)v);
+    for (int64_t v : hd) idx.push_back((int32_t)v);
+    for (int32_t v : idx)
+        if (v < 0 || v >= P) return fail(c, ROVER_E_INVALID, "set_distribution: index %d outside [0,%d)", v, P);
+    dfree(c->d_dist); dfree(c->d_obs_idx);
+    HIP_TRY(c, hipMalloc((void**)&c->d_dist, hp.size() * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(c->d_dist, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void**)&c->d_obs_idx, (idx.size() + 1) * sizeof(int32_t)));
+    if (!idx.empty()) HIP_TRY(c, hipMemcpy(c->d_obs_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->P = P; c->Ns = Ns; c->Nd = Nd;
+    c->have_dist = true;
+    return alloc_workspace(c);
+}
+
+int rover_set_heightfield(rover_ctx* c, const float* hm, int32_t N0, int32_t N1, float hscale, float vscale, float sx, float sy) {
+    if (!c) return ROVER_E_INVALID;
+    if (!hm || N0 <= 0 || N1 <= 0 || !(hscale > 0.0f)) return fail(c, ROVER_E_INVALID, "set_heightfield: bad arguments");
+    if (int r = use_device(c)) return r;
+    float* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, (uint64_t)N0 * N1 * sizeof(float)));
+    hipError_t e = hipMemcpy(d, hm, (uint64_t)N0 * N1 * sizeof(float), hipMemcpyDefault);
+    if (e != hipSuccess) { dfree(d); return fail(c, ROVER_E_HIP, "set_heightfield: %s", hipGetErrorString(e)); }
+    float* old = const_cast<float*>(c->hf.hm);
+    dfree(old);
+    c->hf = HeightDev{d, N0, N1, hscale, vscale, sx, sy};
+    c->have_hf = true;
+    return ROVER_OK;
+}
+
+int rover_set_stones(rover_ctx* c, const float* info7, int32_t S) {
+    if (!c) return ROVER_E_INVALID;
+    if (S < 0 || (S > 0 && !info7)) return fail(c, ROVER_E_INVALID, "set_stones: bad arguments");
+    if (int r = use_device(c)) return r;
+    dfree(c->d_stones);
+    HIP_TRY(c, hipMalloc((void**)&c->d_stones, ((uint64_t)S * 7 + 1) * sizeof(float)));
+    if (S) HIP_TRY(c, hipMemcpy(c->d_stones, info7, (uint64_t)S * 7 * sizeof(float), hipMemcpyDefault));
+    c->S = S;
+    c->have_stones = true;
+    return ROVER_OK;
+}
+
+int rover_set_curriculum_level(rover_ctx* c, int32_t level) {
+    if (!c) return ROVER_E_INVALID;
+    c->cfg.curriculum_level = level;
+    return ROVER_OK;
+}
+
+// ---- step ------------------------------------------------------------------------------------------
+static int check_ready(rover_ctx* c) {
+    if (!c->have_map[0] || !c->have_map[1]) return fail(c, ROVER_E_STATE, "terrain and rocks maps must be set (rover_set_knn_map)");
+    if (!c->have_dist) return fail(c, ROVER_E_STATE, "ray distribution must be set (rover_set_distribution)");
+    return ROVER_OK;
+}
+
+static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, hipStream_t s) {
+    if (!in->pos || !in->quat || !in->joints || !in->target || !in->lin_hist || !in->ang_hist)
+        return fail(c, ROVER_E_INVALID, "get_observations: null input pointer");
+    if (!out->obs) return fail(c, ROVER_E_INVALID, "get_observations: obs is required");
+    const uint32_t E = (uint32_t)c->cfg.num_envs, W = (uint32_t)(4 + c->Ns + c->Nd);
+    const int64_t stride = out->obs_stride ? out->obs_stride : (int64_t)W;
+    if (stride < (int64_t)W) return fail(c, ROVER_E_INVALID, "obs_stride %lld < row width %u", (long long)stride, W);
+    PrepArgs p{};
+    p.E = E; p.P = (uint32_t)c->P; p.R8 = c->R8;
+    p.pos = in->pos; p.quat = in->quat; p.joints = in->joints; p.target = in->target;
+    p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
+    p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading;
+    HIP_TRY(c, launch_prep(p, s));
+    if (c->profiling) {
+        if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
+        HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
+    }
+    HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
+                              (uint32_t)c->map[1].K8, c->d_dist_out, s));
+    if (c->profiling) {
+        HIP_TRY(c, hipEventRecord(c->ev1[c->prof_pending], s));
+        ++c->prof_pending;
+        ++c->prof_launches;
+    }
+    c->rays_valid = true;
+    ObsArgs o{};
+    o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
+    o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
+    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs;
+    HIP_TRY(c, launch_assemble_obs(o, s));
+    if (out->ray_dist || out->wheel_dist || out->body_dist)
+        HIP_TRY(c, launch_export_dist(c->d_dist_out, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
+    if (out->euler) HIP_TRY(c, hipMemcpyAsync(out->euler, c->d_euler, (uint64_t)E * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->heading_diff) HIP_TRY(c, hipMemcpyAsync(out->heading_diff, c->d_heading, (uint64_t)E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return ROVER_OK;
+}
+
+static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, int inc, int coll, int met, int done,
+                      hipStream_t s) {
+    if (!in->pos || !in->target) return fail(c, ROVER_E_INVALID, "metrics/done: null input pointer");
+    if ((inc || met || done) && !in->progress) return fail(c, ROVER_E_INVALID, "metrics/done: progress is required");
+    if (!out->rock_collision) return fail(c, ROVER_E_INVALID, "metrics/done: rock_collision is required");
+    if (met && (!in->joints || !in->lin_hist || !in->ang_hist || !out->rew))
+        return fail(c, ROVER_E_INVALID, "calculate_metrics: joints, lin_hist, ang_hist and rew are required");
+    if (done && (!in->euler_pre || !out->reset)) return fail(c, ROVER_E_INVALID, "is_done: euler_pre and reset are required");
+    MetricsArgs m{};
+    m.E = (uint32_t)c->cfg.num_envs; m.R8 = c->R8;
+    m.curriculum_level = c->cfg.curriculum_level; m.max_episode_length = c->cfg.max_episode_length;
+    m.num_envs_global = c->cfg.num_envs_global;
+    m.do_increment = inc; m.do_collision = coll; m.do_metrics = met; m.do_done = done;
+    m.pos_reward = c->cfg.pos_reward; m.heading_contraint_reward = c->cfg.heading_contraint_reward;
+    m.motion_contraint_reward = c->cfg.motion_contraint_reward; m.goal_angle_reward = c->cfg.goal_angle_reward;
+    m.boogie_contraint_reward = c->cfg.boogie_contraint_reward;
+    m.pos = in->pos; m.target = in->target; m.joints = in->joints; m.lin_hist = in->lin_hist; m.ang_hist = in->ang_hist;
+    m.euler_pre = in->euler_pre; m.heading = c->d_heading; m.dist = c->d_dist_out;
+    m.progress = in->progress; m.rock_collision = out->rock_collision; m.rew = out->rew; m.reset = out->reset;
+    m.ex_pos_reward = out->ex_pos_reward; m.ex_collision = out->ex_collision_penalty; m.ex_upright = out->ex_uprightness_penalty;
+    m.ex_heading = out->ex_heading_contraint_penalty; m.ex_motion = out->ex_motion_contraint_penalty;
+    m.ex_goal_angle = out->ex_goal_angle_penalty; m.ex_lin = out->ex_torque_penalty_driving; m.ex_ang = out->ex_torque_penalty_steering;
+    HIP_TRY(c, launch_metrics_done(m, s));
+    return ROVER_OK;
+}
+
+int rover_get_observations(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!in || !out) return fail(c, ROVER_E_INVALID, "get_observations: null struct");
+    if (int r = check_ready(c)) return r;
+    if (int r = use_device(c)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if (int r = do_observations(c, in, out, s)) return r;
+    if (!out->rock_collision) return ROVER_OK;
+    // check_collision (rover.py:292-293) is part of get_observations: run only the collision stage
+    return do_metrics(c, in, out, 0, 1, 0, 0, s);
+}
+
+int rover_calculate_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!in || !out) return fail(c, ROVER_E_INVALID, "calculate_metrics: null struct");
+    if (int r = check_ready(c)) return r;
+    if (!c->rays_valid) return fail(c, ROVER_E_STATE, "calculate_metrics: call rover_get_observations first (rover.py:479 reads self.heading_diff)");
+    if (int r = use_device(c)) return r;
+    return do_metrics(c, in, out, 0, 0, 1, 0, (hipStream_t)stream);
+}
+
+int rover_is_done(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!in || !out) return fail(c, ROVER_E_INVALID, "is_done: null struct");
+    if (int r = check_ready(c)) return r;
+    if (int r = use_device(c)) return r;
+    return do_metrics(c, in, out, 0, 0, 0, 1, (hipStream_t)stream);
+}
+
+int rover_compact_resets(rover_ctx* c, const int64_t* reset, int64_t* ids, int32_t* n_reset, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!reset || !ids || !n_reset) return fail(c, ROVER_E_INVALID, "compact_resets: null pointer");
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_compact(reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, ids, n_reset, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_step(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, uint32_t flags, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!in || !out) return fail(c, ROVER_E_INVALID, "step: null struct");
+    if (int r = check_ready(c)) return r;
+    if (int r = use_device(c)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if ((flags & ROVER_STEP_COMPACT) && (!out->reset_ids || !out->n_reset))
+        return fail(c, ROVER_E_INVALID, "step: ROVER_STEP_COMPACT needs reset_ids and n_reset");
+    if (int r = do_observations(c, in, out, s)) return r;
+    if (int r = do_metrics(c, in, out, (flags & ROVER_STEP_INCREMENT_PROGRESS) ? 1 : 0, 1, 1, 1, s)) return r;
+    if (flags & ROVER_STEP_COMPACT)
+        HIP_TRY(c, launch_compact(out->reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, out->reset_ids, out->n_reset, s));
+    return ROVER_OK;
+}
+
+int rover_quat_to_euler(rover_ctx* c, const float* quat, float* euler, int32_t n, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!quat || !euler || n < 0) return fail(c, ROVER_E_INVALID, "quat_to_euler: bad arguments");
+    if (n == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_quat_to_euler(quat, euler, (uint32_t)n, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+// ---- reset path ------------------------------------------------------------------------------------
+int rover_clearance(rover_ctx* c, const float* xy, int32_t n, float* out, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!c->have_stones) return fail(c, ROVER_E_STATE, "clearance: rover_set_stones first");
+    if (n < 0 || (n > 0 && (!xy || !out))) return fail(c, ROVER_E_INVALID, "clearance: bad arguments");
+    if (n == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_clearance(c->d_stones, (uint32_t)c->S, xy, (uint32_t)n, out, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_shift_spawns(rover_ctx* c, float* pos3, int32_t n, int32_t max_iter, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!c->have_stones) return fail(c, ROVER_E_STATE, "shift_spawns: rover_set_stones first");
+    if (n < 0 || (n > 0 && !pos3) || max_iter < 0) return fail(c, ROVER_E_INVALID, "shift_spawns: bad arguments");
+    if (n == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_shift_spawns(c->d_stones, (uint32_t)c->S, pos3, (uint32_t)n, max_iter, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_sample_height(rover_ctx* c, const float* xy, int32_t n, float* out, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!c->have_hf) return fail(c, ROVER_E_STATE, "sample_height: rover_set_heightfield first");
+    if (n < 0 || (n > 0 && (!xy || !out))) return fail(c, ROVER_E_INVALID, "sample_height: bad arguments");
+    if (n == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_sample_height(c->hf, xy, (uint32_t)n, out, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_generate_goals(rover_ctx* c, const int64_t* env_ids, int32_t n, const float* initial_pos3, float* target3, float radius,
+                         const float* draws, int32_t max_draws, uint64_t seed, int32_t* n_draws_used, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!c->have_stones || !c->have_hf) return fail(c, ROVER_E_STATE, "generate_goals: rover_set_stones and rover_set_heightfield first");
+    if (n < 0 || n > c->cfg.num_envs || (n > 0 && (!env_ids || !initial_pos3 || !target3)) || max_draws <= 0)
+        return fail(c, ROVER_E_INVALID, "generate_goals: bad arguments (n=%d, max_draws=%d)", n, max_draws);
+    if (n == 0) return ROVER_OK;
+    if (!c->d_ids_work) return fail(c, ROVER_E_STATE, "generate_goals: rover_set_distribution first (allocates the workspace)");
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_generate_goals(c->d_stones, (uint32_t)c->S, c->hf, env_ids, c->d_ids_work, (uint32_t)n, initial_pos3, target3,
+                                     radius, draws, max_draws, seed, n_draws_used, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_ackermann(rover_ctx* c, const float* lin, const float* ang, int32_t n, float* steering, float* velocities, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (n < 0 || (n > 0 && (!lin || !ang || !steering || !velocities))) return fail(c, ROVER_E_INVALID, "ackermann: bad arguments");
+    if (n == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_ackermann(lin, ang, (uint32_t)n, steering, velocities, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_get_info(const rover_ctx* c, rover_info* info) {
+    if (!c || !info) return ROVER_E_INVALID;
+    memset(info, 0, sizeof *info);
+    info->P = c->P; info->Ns = c->Ns; info->Nd = c->Nd; info->rays_per_env_padded = (int32_t)c->R8;
+    for (int w = 0; w < 2; ++w) {
+        info->K[w] = c->map[w].K; info->K8[w] = c->map[w].K8; info->X[w] = c->map[w].X; info->Y[w] = c->map[w].Y;
+        info->table_bytes[w] = c->table_bytes[w];
+    }
+    info->workspace_bytes = c->workspace_bytes;
+    return ROVER_OK;
+}
+
+int rover_set_profiling(rover_ctx* c, int32_t enable) {
+    if (!c) return ROVER_E_INVALID;
+    if (int r = use_device(c)) return r;
+    if (enable && c->ev0.empty()) {
+        c->ev0.resize(kProfRing); c->ev1.resize(kProfRing);
+        for (int i = 0; i < kProfRing; ++i) { HIP_TRY(c, hipEventCreate(&c->ev0[i])); HIP_TRY(c, hipEventCreate(&c->ev1[i])); }
+    }
+    if (c->prof_pending) (void)prof_drain(c);
+    c->profiling = enable != 0;
+    if (enable) { c->prof_ms = 0.0; c->prof_launches = 0; }
+    return ROVER_OK;
+}
+
+int rover_get_profile(rover_ctx* c, rover_profile* out) {
+    if (!c || !out) return ROVER_E_INVALID;
+    if (int r = use_device(c)) return r;
+    if (prof_drain(c)) return fail(c, ROVER_E_HIP, "get_profile: event drain failed");
+    out->raycast_ms = c->prof_ms;
+    out->launches = c->prof_launches;
+    out->pairs_per_launch = (uint64_t)c->cfg.num_envs * ((uint64_t)c->P * (uint64_t)c->map[0].K + 26ull * (uint64_t)c->map[1].K);
+    return ROVER_OK;
+}
+
+int rover_replay_raycast(rover_ctx* c, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (int r = check_ready(c)) return r;
+    if (!c->rays_valid) return fail(c, ROVER_E_STATE, "replay_raycast: no ray records yet (run a step first)");
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
+                              (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// rover_internal.h — structs shared by the kernels (rover_kernels.hip) and the C-ABI layer (rover_capi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rover {
+
+// One ray as the ray-cast kernel consumes it (32 B, two 16-byte loads).
+struct RayRec {
+    float sx, sy, sz;    // origin
+    uint32_t cell;       // ix * Y + iy into the map the flags select
+    float dx, dy, dz;    // -normalize(direction), ray_casting.py:31
+    uint32_t flags;      // bit0: rocks map, bit1: valid
+};
+static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
+
+// One re-packed KNN map: per-cell contiguous fp16 block [X*Y][9][K8]
+struct KnnDev {
+    const uint16_t* table;
+    int32_t X, Y, K, K8;
+    float cell, shift_x, shift_y;
+};
+
+struct HeightDev {
+    const float* hm;
+    int32_t N0, N1;
+    float hscale, vscale, shift_x, shift_y;
+};
+
+struct PrepArgs {
+    uint32_t E, P, R8;
+    const float *pos, *quat, *joints, *target;
+    const double* dist;          // [P][3]
+    KnnDev terrain, rocks;
+    RayRec* rays;                // [E*R8]
+    float *euler, *heading;      // [E,3], [E]
+};
+
+struct ObsArgs {
+    uint32_t E, W, R8;
+    int64_t obs_stride;
+    const float *pos, *target, *heading, *lin_hist, *ang_hist, *dist;
+    const int32_t* obs_idx;      // [Ns+Nd] ray index per heightmap column
+    float* obs;
+};
+
+struct MetricsArgs {
+    uint32_t E, R8;
+    int32_t curriculum_level, max_episode_length;
+    int64_t num_envs_global;
+    int do_increment, do_collision, do_metrics, do_done;
+    float pos_reward, heading_contraint_reward, motion_contraint_reward, goal_angle_reward, boogie_contraint_reward;
+    const float *pos, *target, *joints, *lin_hist, *ang_hist, *euler_pre, *heading, *dist;
+    int64_t* progress;
+    int64_t* rock_collision;
+    float* rew;
+    int64_t* reset;
+    float* ex_pos_reward; int64_t* ex_collision; float *ex_upright, *ex_heading, *ex_motion, *ex_goal_angle, *ex_lin, *ex_ang;
+};
+
+hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
+                         uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s);
+hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
+hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* tab0, const uint16_t* tab1, uint32_t kp0,
+                          uint32_t kp1, float* out, hipStream_t s);
+hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
+hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
+                              hipStream_t s);
+hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s);
+hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, int64_t* ids, int32_t* count, hipStream_t s);
+hipError_t launch_quat_to_euler(const float* q, float* eul, uint32_t n, hipStream_t s);
+hipError_t launch_clearance(const float* info7, uint32_t S, const float* xy, uint32_t n, float* out, hipStream_t s);
+hipError_t launch_shift_spawns(const float* info7, uint32_t S, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s);
+hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n, float* out, hipStream_t s);
+hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t* ids_work,
+                                 uint32_t n, const float* initial_pos3, float* target3, float radius, const float* draws,
+                                 int32_t max_draws, uint64_t seed, int32_t* n_draws_used, hipStream_t s);
+hipError_t launch_ackermann(const float* lin, const float* ang, uint32_t n, float* steer, float* vel, hipStream_t s);
+
+}  // namespace rover

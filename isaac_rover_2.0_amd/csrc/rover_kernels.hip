@@ -1,0 +1,687 @@
+// rover_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the rover env.step() hot path.
+//
+// Reference (pure PyTorch; paths relative to omniisaacgymenvs/):
+//   tasks/rover.py:272-336 get_observations, :460-531 calculate_metrics, :610-647 is_done, :663-668 check_collision
+//   tasks/utils/camera/camera.py:60-145,165-212,233-264     (terrain ray cast)
+//   tasks/utils/camera/ray_casting.py:3-66                   (ray/triangle)
+//   tasks/utils/rock_detection/rock_detect.py:52-149,160-371 (wheel/body rays)
+//   tasks/utils/math/tensor_quat_to_euler.py:6-31
+//
+// Built with -ffp-contract=off: every f32 +,-,*,/ and sqrt is one IEEE rounding, in the reference's own
+// evaluation order, so that given identical rays the ray kernel agrees bit for bit with the CPU oracle and
+// differs from the reference's fp32 mode only through sin/cos/atan2/asin ulps.
+//
+// Kernels:
+//   repack_knn_kernel      init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8]
+//   prep_rays_kernel       1 thread / (env, ray slot): pose -> ray origin, unit direction, cell id   (G1,G2,G3,G6)
+//   raycast_kernel         32 lanes / ray, 8 triangles / lane / pass, 16-B loads, wave shuffle min   (G4,G5,G7)  <- roofline kernel
+//   assemble_obs_kernel    1 thread / obs element, coalesced row writes                              (A1)
+//   metrics_done_kernel    1 thread / env: collision mask, reward, extras, done                      (G8,G9,G10)
+//   compact_kernel         ballot/popc ordered stream compaction of reset ids                        (G11)
+//   clearance / shift_spawns / sample_height / generate_goals kernels                                (G12)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rover_internal.h"
+
+namespace rover {
+
+// ---------------------------------------------------------------------------------------------------
+// shared device maths (same operation order as oracle/rover_oracle.c, which cites the reference lines)
+// ---------------------------------------------------------------------------------------------------
+#define RAY_NEG_EPS (-0.0999755859375f)   // fp16(-0.1), ray_casting.py:25
+#define RAY_ONE_EPS (1.099609375f)        // fp16(1.1),  ray_casting.py:26
+#define RAY_MISS    (11.0f)               // fp16(1.1)*10, ray_casting.py:27
+
+__device__ __forceinline__ void quat_to_euler(const float* __restrict__ q, float& roll, float& pitch, float& yaw) {
+    const float half_pi = 3.1415927410125732f / 2.0f;
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float sinr = 2.0f * (w * x + y * z);
+    float cosr = 1.0f - (2.0f * (x * x + y * y));
+    roll = atan2f(sinr, cosr);
+    float sinp = 2.0f * (w * y - z * x);
+    float t = sinp - 1.0f;
+    pitch = (t >= 0.0f) ? copysignf(half_pi, sinp) : asinf(sinp);
+    float siny = 2.0f * (w * z + x * y);
+    float cosy = 1.0f - (2.0f * (y * y + z * z));
+    yaw = atan2f(siny, cosy);
+}
+
+struct Trig6 { float sx, cx, sy, cy, sz, cz; };
+
+__device__ __forceinline__ Trig6 euler_trig(float roll, float pitch, float yaw) {
+    Trig6 t;
+    t.sx = sinf(-roll);  t.cx = cosf(-roll);
+    t.sy = sinf(-pitch); t.cy = cosf(-pitch);
+    t.sz = sinf(-yaw);   t.cz = cosf(-yaw);
+    return t;
+}
+
+// rock_detect.py:305-307 / :356-358 — f32 body transform
+__device__ __forceinline__ void body_xf(float x, float y, float z, const Trig6& t, float px, float py, float pz,
+                                        float& ox, float& oy, float& oz) {
+    float A = y * t.cx + z * t.sx;
+    float C = z * t.cx - y * t.sx;
+    float B = x * t.cy - t.sy * C;
+    ox = px + t.sz * A + t.cz * B;
+    oy = py + t.cz * A - t.sz * B;
+    oz = pz + x * t.sy + t.cy * C;
+}
+
+// rock_detect.py:256-258,275-277 then body_xf: wheel-local point -> world (translations zeroed for directions)
+__device__ __forceinline__ void wheel_chain(float x, float y, float z, const float* t0, const float* t1,
+                                            float sst, float cst, float ssx, float csx, float ssy, float csy,
+                                            const Trig6& t, float px, float py, float pz,
+                                            float& ox, float& oy, float& oz) {
+    float x1 = t0[0] + x * cst + y * sst;
+    float y1 = t0[1] + y * cst - x * sst;
+    float z1 = t0[2] + z;
+    float c1 = z1 * csx - y1 * ssx;
+    float x2 = t1[0] + x1 * csy - ssy * c1;
+    float y2 = t1[1] + y1 * csx + z1 * ssx;
+    float z2 = t1[2] + x1 * ssy + csy * c1;
+    body_xf(x2, y2, z2, t, px, py, pz, ox, oy, oz);
+}
+
+// camera.py:241-253: clamp bound is the dim-0 size for both axes; torch.round is half-to-even
+__device__ __forceinline__ uint32_t cell_coord(float v, float shift, float cell, int32_t dim0) {
+    float s = (v - shift) / cell;
+    float hi = (float)(dim0 - 1);
+    s = (s < 0.0f) ? 0.0f : s;
+    s = (s > hi) ? hi : s;
+    s = rintf(s);
+    if (!(s == s)) return 0u;          // NaN pose: the reference raises; map to cell 0 (all tests then miss)
+    return (uint32_t)s;
+}
+
+// -(F.normalize(dir)), ray_casting.py:31
+__device__ __forceinline__ void neg_normalize(float dx, float dy, float dz, float& ox, float& oy, float& oz) {
+    float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    ox = -(dx / nrm); oy = -(dy / nrm); oz = -(dz / nrm);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// init: re-pack the reference's three tables into per-cell contiguous fp16 blocks [cell][9][K8]
+// component q = 3*vertex + coord; padding triangles (K..K8) are NaN so every test on them fails.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) repack_knn_kernel(const int32_t* __restrict__ map_idx, const int32_t* __restrict__ tris,
+                                                         const uint16_t* __restrict__ verts, uint64_t n_cells, uint32_t K,
+                                                         uint32_t K8, uint32_t T, uint32_t V, uint16_t* __restrict__ table) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (cell, k8)
+    if (i >= n_cells * K8) return;
+    uint64_t cell = i / K8;
+    uint32_t k = (uint32_t)(i % K8);
+    uint16_t v[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) v[q] = 0x7e00u;                         // fp16 NaN
+    if (k < K) {
+        uint32_t t = (uint32_t)map_idx[cell * K + k];
+        if (t < T) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                uint32_t vi = (uint32_t)tris[3 * (uint64_t)t + a];
+                if (vi < V) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[3 * a + c] = verts[3 * (uint64_t)vi + c];
+                }
+            }
+        }
+    }
+    uint16_t* dst = table + cell * 9ull * K8 + k;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dst[(uint64_t)q * K8] = v[q];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prep: one thread per (env, slot).  slots 0..23 wheel rays, 24..25 body rays, 26..26+P-1 terrain rays,
+// rest padding to a multiple of 8 (a ray-cast workgroup then never straddles two envs).
+// ---------------------------------------------------------------------------------------------------
+__constant__ float c_wheel_ray[5][3] = {{0.215 / 2, 0.130 / 2, 0.1}, {0.215 / 2, -0.130 / 2, 0.1},
+                                        {-0.215 / 2, 0.130 / 2, 0.1}, {-0.215 / 2, -0.130 / 2, 0.1}, {0, 0, -1}};
+__constant__ float c_wp0[6][3] = {{0.286, 0.385, -0.197}, {0.286, -0.385, -0.197}, {-0.146, 0.447, -0.197},
+                                  {-0.146, -0.447, -0.197}, {-0.440, 0.385, -0.197}, {-0.440, -0.385, -0.197}};
+__constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, -0.0, 0.03},
+                                  {0, 0, 0.03}, {0, 0, 0.03}};
+__constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
+
+__global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t e = gid / a.R8, slot = gid % a.R8;
+    if (e >= a.E) return;
+    RayRec rec;
+    rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
+    const uint32_t n_real = 26u + a.P;
+    if (slot < n_real) {
+        const float* pos = a.pos + 3ull * e;
+        float roll, pitch, yaw;
+        quat_to_euler(a.quat + 4ull * e, roll, pitch, yaw);
+        if (slot == 0) {
+            a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
+            // heading_diff, rover.py:279-283
+            float dx = cosf(yaw), dy = sinf(yaw);
+            float tx = a.target[3ull * e] - pos[0], ty = a.target[3ull * e + 1] - pos[1];
+            a.heading[e] = -atan2f(tx * dy - ty * dx, tx * dx + ty * dy);
+        }
+        Trig6 t = euler_trig(roll, pitch, yaw);
+        float sx, sy, sz, ux, uy, uz;      // origin, un-normalised direction
+        const KnnDev* m;
+        if (slot < 24u) {                   // rock_detect.py:160-319
+            const float* j = a.joints + 13ull * e;
+            uint32_t w = slot >> 2, r = slot & 3u;
+            float steer = (w == 0) ? j[4] : (w == 1) ? j[6] : (w == 4) ? -j[7] : (w == 5) ? j[8] : 0.0f;
+            float susY = (w == 0 || w == 2) ? -j[0] : (w == 1 || w == 3) ? j[1] : 0.0f;
+            float susX = (w >= 4) ? -j[2] : 0.0f;
+            float sst = sinf(-steer), cst = cosf(-steer);
+            float ssx = sinf(susX), csx = cosf(susX);
+            float ssy = sinf(susY), csy = cosf(susY);
+            const float zero3[3] = {0.0f, 0.0f, 0.0f};
+            wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[w], c_wp1[w], sst, cst, ssx, csx,
+                        ssy, csy, t, pos[0], pos[1], pos[2], sx, sy, sz);
+            wheel_chain(c_wheel_ray[4][0], c_wheel_ray[4][1], c_wheel_ray[4][2], zero3, zero3, sst, cst, ssx, csx,
+                        ssy, csy, t, 0.0f, 0.0f, 0.0f, ux, uy, uz);
+            m = &a.rocks;
+            rec.flags = 3u;
+        } else if (slot < 26u) {            // rock_detect.py:321-371
+            uint32_t r = slot - 24u;
+            body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, pos[0], pos[1], pos[2], sx, sy, sz);
+            float qx, qy, qz;
+            body_xf(0.0f, 1.0f, 0.0f, t, pos[0], pos[1], pos[2], qx, qy, qz);
+            ux = qx - pos[0]; uy = qy - pos[1]; uz = qz - pos[2];
+            m = &a.rocks;
+            rec.flags = 3u;
+        } else {                            // camera.py:165-212, float64 like the distribution tensor
+            uint32_t p = slot - 26u;
+            double x = a.dist[3ull * p], y = a.dist[3ull * p + 1], z = a.dist[3ull * p + 2];
+            double dsx = (double)t.sx, dcx = (double)t.cx, dsy = (double)t.sy, dcy = (double)t.cy,
+                   dsz = (double)t.sz, dcz = (double)t.cz;
+            double X = (double)pos[0], Y = (double)pos[1], Z = (double)pos[2];
+            {
+                double A = y * dcx + z * dsx, C = z * dcx - y * dsx, B = x * dcy - dsy * C;
+                sx = (float)(X + dsz * A + dcz * B);
+                sy = (float)(Y + dcz * A - dsz * B);
+                sz = (float)(Z + x * dsy + dcy * C);
+            }
+            {   // the appended (0,0,-1) point, camera.py:179-181,202-204
+                double xn = 0.0, yn = 0.0, zn = -1.0;
+                double A = yn * dcx + zn * dsx, C = zn * dcx - yn * dsx, B = xn * dcy - dsy * C;
+                ux = (float)((X + dsz * A + dcz * B) - X);
+                uy = (float)((Y + dcz * A - dsz * B) - Y);
+                uz = (float)((Z + xn * dsy + dcy * C) - Z);
+            }
+            m = &a.terrain;
+            rec.flags = 2u;
+        }
+        rec.sx = sx; rec.sy = sy; rec.sz = sz;
+        neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
+        uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->X);
+        uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->X);
+        if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
+        rec.cell = ix * (uint32_t)m->Y + iy;
+    }
+    float4* dst = reinterpret_cast<float4*>(a.rays + gid);
+    dst[0] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
+    dst[1] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ray cast — the roofline kernel.  32 lanes per ray; a lane owns 8 consecutive triangles of the cell per
+// pass: nine 16-byte loads (one per vertex component) straight to VGPRs, fp16 -> f32, Möller–Trumbore with
+// the reference's padded barycentric test, running min; 5-step shuffle min over the 32 lanes.
+// Algorithmic traffic: 18 B per (ray, triangle).
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float tri_test(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
+                                          float ax, float ay, float az, float sx, float sy, float sz,
+                                          float dx, float dy, float dz) {
+    // ray_casting.py:34-59; a = v2
+    float bx = v1x - ax, by = v1y - ay, bz = v1z - az;
+    float cx = v0x - ax, cy = v0y - ay, cz = v0z - az;
+    float gx = sx - ax, gy = sy - ay, gz = sz - az;
+    float bcx = by * cz - bz * cy, bcy = bz * cx - bx * cz, bcz = bx * cy - by * cx;
+    float det = bcx * dx + bcy * dy + bcz * dz;
+    float gcx = gy * cz - gz * cy, gcy = gz * cx - gx * cz, gcz = gx * cy - gy * cx;
+    float n = (gcx * dx + gcy * dy + gcz * dz) / det;
+    float bgx = by * gz - bz * gy, bgy = bz * gx - bx * gz, bgz = bx * gy - by * gx;
+    float m = (bgx * dx + bgy * dy + bgz * dz) / det;
+    float k = (bcx * gx + bcy * gy + bcz * gz) / det;
+    bool ok = (n >= RAY_NEG_EPS) && (m >= RAY_NEG_EPS) && (n + m <= RAY_ONE_EPS)
+              && (det != RAY_NEG_EPS) && (det != RAY_ONE_EPS);       // :46,:51,:56 guards
+    return ok ? k : RAY_MISS;
+}
+
+__global__ void __launch_bounds__(256) raycast_kernel(const RayRec* __restrict__ rays, uint32_t n_rays,
+                                                      const _Float16* __restrict__ tab0, const _Float16* __restrict__ tab1,
+                                                      uint32_t kp0, uint32_t kp1, float* __restrict__ out) {
+    const uint32_t ray = (blockIdx.x * 256u + threadIdx.x) >> 5;
+    const uint32_t l = threadIdx.x & 31u;
+    float best = __builtin_inff();
+    const bool active = ray < n_rays;
+    if (active) {
+        const float4* rp = reinterpret_cast<const float4*>(rays + ray);
+        const float4 ra = rp[0], rb = rp[1];
+        const uint32_t cell = __float_as_uint(ra.w), flags = __float_as_uint(rb.w);
+        if (flags & 2u) {
+            const uint32_t kp = (flags & 1u) ? kp1 : kp0;
+            const _Float16* base = ((flags & 1u) ? tab1 : tab0) + (size_t)cell * 9u * kp;
+            for (uint32_t c = l * 8u; c < kp; c += 256u) {
+                half8 v[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = *reinterpret_cast<const half8*>(base + (size_t)q * kp + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float r = tri_test((float)v[0][j], (float)v[1][j], (float)v[2][j], (float)v[3][j], (float)v[4][j],
+                                       (float)v[5][j], (float)v[6][j], (float)v[7][j], (float)v[8][j],
+                                       ra.x, ra.y, ra.z, rb.x, rb.y, rb.z);
+                    best = (r < best) ? r : best;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        float o = __shfl_xor(best, off, 32);
+        best = (o < best) ? o : best;
+    }
+    if (active && l == 0u) out[ray] = best;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// obs assembly: one thread per obs element -> coalesced row writes (rover.py:320-325)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = (uint64_t)a.E * a.W;
+    if (i >= total) return;
+    uint32_t e = (uint32_t)(i / a.W), col = (uint32_t)(i % a.W);
+    float v;
+    if (col >= 4u) {
+        int32_t p = a.obs_idx[col - 4u];                       // sparse then dense, heightmap_distribution.py:126-133
+        v = a.dist[(uint64_t)e * a.R8 + 26u + (uint32_t)p] / 2.0f;
+    } else if (col == 0u) {
+        float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
+        v = sqrtf(tx * tx + ty * ty) / 9.0f;                   // :320
+    } else if (col == 1u) {
+        v = a.heading[e] / 3.14159265358979323846f;            // :321
+    } else if (col == 2u) {
+        v = a.lin_hist[3ull * e];                              // :322
+    } else {
+        v = a.ang_hist[3ull * e];                              // :323
+    }
+    a.obs[(uint64_t)e * a.obs_stride + col] = v;
+}
+
+// optional intermediates for parity tests
+__global__ void __launch_bounds__(256) export_dist_kernel(const float* __restrict__ dist, uint32_t E, uint32_t R8, uint32_t P,
+                                                          float* __restrict__ ray_dist, float* __restrict__ wheel,
+                                                          float* __restrict__ body) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = 26u + P;
+    if (i >= (uint64_t)E * n) return;
+    uint32_t e = (uint32_t)(i / n), s = (uint32_t)(i % n);
+    float v = dist[(uint64_t)e * R8 + s];
+    if (s < 24u) { if (wheel) wheel[24ull * e + s] = v; }
+    else if (s < 26u) { if (body) body[2ull * e + (s - 24u)] = v; }
+    else if (ray_dist) ray_dist[(uint64_t)e * P + (s - 26u)] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// collision mask + reward + extras + done: one thread per env (rover.py:663-668, 460-531, 610-647)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.E) return;
+    int64_t progress = (a.do_increment | a.do_metrics | a.do_done) ? a.progress[e] : 0;
+    if (a.do_increment) { progress += 1; a.progress[e] = progress; }       // rl_task.py:250
+    int64_t coll;
+    if (a.do_collision) {                                                   // check_collision, rover.py:663-668
+        coll = 0;
+        if (a.curriculum_level >= 2) {
+            const float* d = a.dist + (uint64_t)e * a.R8;
+            float mw = d[0];
+#pragma unroll
+            for (int r = 1; r < 24; ++r) mw = (d[r] < mw) ? d[r] : mw;
+            float mb = (d[25] < d[24]) ? d[25] : d[24];
+            coll = (fabsf(mw) < 0.8f) ? 1 : 0;
+            if (fabsf(mb) < 0.45f) coll = 1;
+        }
+        a.rock_collision[e] = coll;
+    } else {
+        coll = a.rock_collision[e];
+    }
+    float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
+    float td = sqrtf(tx * tx + ty * ty);                                    // :482 / :617
+    if (a.do_metrics) {
+        float hd = a.heading[e];
+        const float* jn = a.joints + 13ull * e;
+        float lin = a.lin_hist[3ull * e], lin_prev = a.lin_hist[3ull * e + 1];
+        float ang = a.ang_hist[3ull * e], ang_prev = a.ang_hist[3ull * e + 1];
+        float heading_pen = ((lin < 0.0f) ? -1.0f : 0.0f) * a.heading_contraint_reward;           // :486
+        float boogie = (fabsf(jn[0]) + fabsf(jn[1]) + fabsf(jn[2])) * a.boogie_contraint_reward;   // :492
+        float goal_pen = (fabsf(hd) > 2.0f) ? -fabsf(hd * 0.3f * a.goal_angle_reward) : 0.0f;      // :495
+        float dl = fabsf(lin * 3.0f - 3.0f * lin_prev), da = fabsf(ang * 3.0f - 3.0f * ang_prev);
+        float p1 = (dl > 0.05f) ? dl * dl : 0.0f;                                                  // :498
+        float p2 = (da > 0.05f) ? da * da : 0.0f;                                                  // :499
+        float motion = (p1 * p1) * a.motion_contraint_reward;                                      // :500
+        motion = motion + (p2 * p2) * a.motion_contraint_reward;                                   // :502
+        float pos_rew = (1.0f / (1.0f + ((float)(0.33 * 0.33) * td) * td)) * a.pos_reward;         // :505
+        if (td <= 0.18f) pos_rew = 1.03f * (float)((int64_t)a.max_episode_length - progress);      // :506
+        float reward = pos_rew + heading_pen + motion + goal_pen;                                  // :512
+        int64_t tracker = 0;
+        if (a.curriculum_level >= 2 && coll == 1) { tracker = a.num_envs_global; reward = reward - 300.0f; }  // :517-519
+        reward = reward / 3000.0f;                                                                 // :522
+        a.rew[e] = reward;
+        if (a.ex_pos_reward) a.ex_pos_reward[e] = pos_rew;
+        if (a.ex_collision) a.ex_collision[e] = tracker;
+        if (a.ex_upright) a.ex_upright[e] = boogie;
+        if (a.ex_heading) a.ex_heading[e] = heading_pen;
+        if (a.ex_motion) a.ex_motion[e] = motion;
+        if (a.ex_goal_angle) a.ex_goal_angle[e] = goal_pen;
+        if (a.ex_lin) a.ex_lin[e] = lin;
+        if (a.ex_ang) a.ex_ang[e] = ang;
+    }
+    if (a.do_done) {                                                        // is_done, rover.py:610-647
+        const float* ep = a.euler_pre + 3ull * e;
+        const float tilt = (float)(0.78 * 1.5);
+        int64_t reset = (progress >= (int64_t)a.max_episode_length) ? 1 : 0;
+        if (fabsf(ep[0]) >= tilt) reset = 1;
+        if (fabsf(ep[1]) >= tilt) reset = 1;
+        if (td >= 11.0f) reset = 1;
+        if (td <= 0.18f) reset = 1;
+        if (a.curriculum_level >= 2 && coll == 1) reset = 1;
+        a.reset[e] = reset;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// done compaction: nonzero(reset_buf) ascending, no host sync.  One 1024-thread workgroup sweeps the
+// flags; per 64-lane wave a ballot + popcount gives the in-wave rank, a 16-entry LDS scan the wave base.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) compact_kernel(const int64_t* __restrict__ reset, uint32_t n, int64_t offset,
+                                                       int64_t* __restrict__ ids, int32_t* __restrict__ count) {
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n; start += 1024u) {
+        uint32_t i = start + tid;
+        bool flag = (i < n) && (reset[i] != 0);
+        unsigned long long ballot = __ballot(flag);
+        uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[w] = __popcll(ballot);
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < 16u; ++v) { uint32_t c = wave_cnt[v]; woff += (v < w) ? c : 0u; total += c; }
+        uint32_t b = base;
+        if (flag) ids[b + woff + rank] = offset + (int64_t)i;
+        __syncthreads();
+        if (tid == 0) base = b + total;
+        __syncthreads();
+    }
+    if (tid == 0) *count = (int32_t)base;
+}
+
+__global__ void __launch_bounds__(256) quat_to_euler_kernel(const float* __restrict__ q, float* __restrict__ eul, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r, p, y;
+    quat_to_euler(q + 4ull * i, r, p, y);
+    eul[3ull * i] = r; eul[3ull * i + 1] = p; eul[3ull * i + 2] = y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reset path.  Stones are staged through LDS in tiles of STONE_TILE (x, y, r) triples.
+// ---------------------------------------------------------------------------------------------------
+#define STONE_TILE 1024
+
+__device__ __forceinline__ float clearance_tiles(const float* __restrict__ info7, uint32_t S, float x, float y, bool live,
+                                                 float* sx, float* sy, float* sr) {
+    float best = __builtin_inff();
+    for (uint32_t s0 = 0; s0 < S; s0 += STONE_TILE) {
+        uint32_t cnt = min((uint32_t)STONE_TILE, S - s0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float* r = info7 + 7ull * (s0 + i);
+            sx[i] = r[0]; sy[i] = r[1]; sr[i] = r[6];
+        }
+        __syncthreads();
+        if (live) {
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float dx = x - sx[i], dy = y - sy[i];
+                float d = sqrtf(dx * dx + dy * dy) - sr[i];                 // rover.py:536-537 / :655-656
+                best = (d < best) ? d : best;
+            }
+        }
+    }
+    return best;
+}
+
+__global__ void __launch_bounds__(256) clearance_kernel(const float* __restrict__ info7, uint32_t S, const float* __restrict__ xy,
+                                                        uint32_t n, float* __restrict__ out) {
+    __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    float x = live ? xy[2ull * i] : 0.0f, y = live ? xy[2ull * i + 1] : 0.0f;
+    float c = clearance_tiles(info7, S, x, y, live, sx, sy, sr);
+    if (live) out[i] = c;
+}
+
+// avoid_pos_rock_collision rover.py:649-661.  Workgroup-uniform loop: iterate while any env of the group moves.
+__global__ void __launch_bounds__(256) shift_spawns_kernel(const float* __restrict__ info7, uint32_t S, float* __restrict__ pos3,
+                                                           uint32_t n, int32_t max_iter) {
+    __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
+    __shared__ int any_moved;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    float x = live ? pos3[3ull * i] : 0.0f, y = live ? pos3[3ull * i + 1] : 0.0f;
+    bool moving = live;
+    for (int32_t it = 0; it < max_iter; ++it) {
+        if (threadIdx.x == 0) any_moved = 0;
+        float c = clearance_tiles(info7, S, x, y, moving, sx, sy, sr);     // has barriers: all threads call it
+        if (moving) {
+            if (c <= 1.4f) { x = x + 0.05f; any_moved = 1; }               // :660
+            else moving = false;
+        }
+        __syncthreads();
+        if (!any_moved) break;
+        __syncthreads();
+    }
+    if (live) pos3[3ull * i] = x;
+}
+
+// get_pos_height rover.py:588-608
+__global__ void __launch_bounds__(256) sample_height_kernel(HeightDev h, const float* __restrict__ xy, uint32_t n,
+                                                            float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ix = cell_coord(xy[2ull * i], h.shift_x, h.hscale, h.N0);
+    uint32_t iy = cell_coord(xy[2ull * i + 1], h.shift_y, h.hscale, h.N0);
+    if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
+    out[i] = h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), used when the caller supplies no uniforms
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t draw, uint32_t idx) {
+    uint32_t c0 = idx, c1 = draw, c2 = 0u, c3 = 0u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);                        // [0,1) with 24 bits, like torch.rand f32
+}
+
+// generate_goals rover.py:544-549 as ONE workgroup (resets per step are few): draw -> write -> check -> mask,
+// with the env_ids = mask*env_ids aliasing (:540).  Duplicate id-0 writers resolve "last entry wins", the
+// order a sequential index_put gives.  ids_work [n] is scratch.
+__global__ void __launch_bounds__(1024) generate_goals_kernel(const float* __restrict__ info7, uint32_t S, HeightDev h,
+                                                              const int64_t* __restrict__ env_ids, int64_t* __restrict__ ids_work,
+                                                              uint32_t n, const float* __restrict__ initial_pos3,
+                                                              float* __restrict__ target3, float radius,
+                                                              const float* __restrict__ draws, int32_t max_draws, uint64_t seed,
+                                                              int32_t* __restrict__ n_draws_used) {
+    __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
+    __shared__ int bad, last_zero;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += blockDim.x) ids_work[i] = env_ids[i];
+    __syncthreads();
+    int32_t used = 0;
+    bool failed = false;
+    while (true) {
+        if (used >= max_draws) { failed = true; break; }
+        if (tid == 0) { bad = 0; last_zero = -1; }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += blockDim.x)
+            if (ids_work[i] == 0) atomicMax(&last_zero, (int)i);
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += blockDim.x) {                    // random_goals :554-564
+            int64_t id = ids_work[i];
+            if (id == 0 && (int)i != last_zero) continue;
+            float u = draws ? draws[(uint64_t)used * n + i] : philox_uniform(seed, (uint32_t)used, i);
+            float alpha = (float)(2 * 3.14159265358979323846) * u;
+            float x = radius * cosf(alpha) + 0.0f, y = radius * sinf(alpha) + 0.0f;
+            target3[3ull * id] = x + initial_pos3[3ull * id];
+            target3[3ull * id + 1] = y + initial_pos3[3ull * id + 1];
+        }
+        __threadfence_block();
+        __syncthreads();
+        ++used;
+        for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {                   // check_goal_collision :533-542
+            uint32_t i = i0 + tid;
+            bool live = i < n;
+            int64_t id = live ? ids_work[i] : 0;
+            float x = live ? target3[3ull * id] : 0.0f, y = live ? target3[3ull * id + 1] : 0.0f;
+            float c = clearance_tiles(info7, S, x, y, live, sx, sy, sr);
+            if (live) {
+                bool m = c <= 1.0f;
+                ids_work[i] = m ? id : 0;
+                if (m) atomicAdd(&bad, 1);
+            }
+        }
+        __syncthreads();
+        int b = bad;
+        __syncthreads();
+        if (b == 0) break;
+    }
+    // goal z, set_targets rover.py:581-583 (over the ORIGINAL env ids)
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        int64_t id = env_ids[i];
+        uint32_t ix = cell_coord(target3[3ull * id], h.shift_x, h.hscale, h.N0);
+        uint32_t iy = cell_coord(target3[3ull * id + 1], h.shift_y, h.hscale, h.N0);
+        if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
+        target3[3ull * id + 2] = h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
+    }
+    if (tid == 0 && n_draws_used) *n_draws_used = failed ? -1 : used;
+}
+
+// Ackermann, tasks/utils/kinematics.py:13-67
+__global__ void __launch_bounds__(256) ackermann_kernel(const float* __restrict__ lin_in, const float* __restrict__ ang_in,
+                                                        uint32_t n, float* __restrict__ steer, float* __restrict__ vel) {
+    const float wl[6][2] = {{-0.385, 0.438}, {0.385, 0.438}, {-0.447, 0.0}, {0.447, 0.0}, {-0.385, -0.411}, {0.385, -0.411}};
+    const float side[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lin = lin_in[i], ang = ang_in[i];
+    float Px = copysignf(lin / ang, -ang);
+    Px = (fabsf(Px) > 0.45f) ? Px : 0.0f;
+    lin = (Px != 0.0f) ? lin : 0.0f;
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        float dx = Px - wl[w][0], dy = 0.0f - wl[w][1];
+        float dist = sqrtf(dx * dx + dy * dy);
+        float av = (lin != 0.0f) ? copysignf(ang, lin) : ang * side[w];
+        float mv = dist * av;
+        if (dist > 1000.0f) mv = lin;
+        vel[6ull * i + w] = mv / 0.2f;
+        float sa = atan2f(wl[w][1], wl[w][0] - Px);
+        if (sa < (float)(-3.14 / 2)) sa = sa + 3.14159265358979323846f;
+        if (sa > (float)(3.14 / 2)) sa = sa - 3.14159265358979323846f;
+        steer[6ull * i + w] = sa;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers (host)
+// ---------------------------------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
+
+hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
+                         uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s) {
+    uint64_t n = n_cells * K8;
+    hipLaunchKernelGGL(repack_knn_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, map_idx, tris, verts, n_cells, K, K8, T, V, table);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
+    uint64_t n = (uint64_t)a.E * a.R8;
+    hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* tab0, const uint16_t* tab1, uint32_t kp0,
+                          uint32_t kp1, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(raycast_kernel, dim3(blocks_for(n_rays, 8)), dim3(256), 0, s, rays, n_rays,
+                       reinterpret_cast<const _Float16*>(tab0), reinterpret_cast<const _Float16*>(tab1), kp0, kp1, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(assemble_obs_kernel, dim3(blocks_for((uint64_t)a.E * a.W, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, E, R8, P,
+                       ray_dist, wheel, body);
+    return hipGetLastError();
+}
+
+hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(metrics_done_kernel, dim3(blocks_for(a.E, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, int64_t* ids, int32_t* count, hipStream_t s) {
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, reset, n, offset, ids, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_quat_to_euler(const float* q, float* eul, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(quat_to_euler_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, q, eul, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_clearance(const float* info7, uint32_t S, const float* xy, uint32_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(clearance_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, info7, S, xy, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_shift_spawns(const float* info7, uint32_t S, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s) {
+    hipLaunchKernelGGL(shift_spawns_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, info7, S, pos3, n, max_iter);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sample_height_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, h, xy, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t* ids_work,
+                                 uint32_t n, const float* initial_pos3, float* target3, float radius, const float* draws,
+                                 int32_t max_draws, uint64_t seed, int32_t* n_draws_used, hipStream_t s) {
+    hipLaunchKernelGGL(generate_goals_kernel, dim3(1), dim3(1024), 0, s, info7, S, h, env_ids, ids_work, n, initial_pos3, target3,
+                       radius, draws, max_draws, seed, n_draws_used);
+    return hipGetLastError();
+}
+
+hipError_t launch_ackermann(const float* lin, const float* ang, uint32_t n, float* steer, float* vel, hipStream_t s) {
+    hipLaunchKernelGGL(ackermann_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, lin, ang, n, steer, vel);
+    return hipGetLastError();
+}
+
+}  // namespace rover
