@@ -1,0 +1,301 @@
+"""RoverTask — the reference's rover navigation task with its per-step compute on HIP.
+
+Drop-in for ``omniisaacgymenvs/tasks/rover.py`` (``RoverTask`` :80-672) on the env.step() path: same method
+names, argument meaning, buffers and call order, so ``train.py``-style loops and a PPO learner see the same
+task.  Every tensor computation of ``get_observations`` / ``calculate_metrics`` / ``is_done`` /
+``pre_physics_step``'s done compaction / ``set_targets`` / ``avoid_pos_rock_collision`` /
+``get_pos_height`` runs in ``librover_step.so`` (hand-written HIP, gfx950) through ``_lib.Engine``; this
+class is host-side bookkeeping only and raises if the library or a GPU is missing (no CPU fallback).
+
+What is NOT here: USD stage building (:187-270), the dead teacher/student loaders (:169-172),
+teacher-data dumps (:298-317), evaluation bookkeeping (:620-641).
+
+Deviations from the reference, all deliberate and tested:
+  * ``post_physics_step`` is ONE fused ``rover_step`` launch sequence (``fused=True``, default); with
+    ``fused=False`` the base-class path calls the three methods like ``rl_task.py:250-257``.  Same results.
+  * the done compaction (``reset_buf.nonzero()``, :356) happens on the device inside the fused step; only
+    the count is read on the host (the reference's ``len()`` is the same sync).
+  * ``reset_idx`` draws its yaw on the device RNG instead of Python's ``random`` (RNG streams cannot match).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import _lib, synth
+from ..config import SimConfig
+from ..views import RigidPrimView, RoverView
+from .base.rl_task import RLTask
+from .utils.heightmap_distribution import Heightmap
+
+
+class Memory:
+    """3-deep action history (``rover.py:60-77``) kept in ONE persistent [E, horizon] tensor, newest first,
+    so the kernels can borrow its pointer; ``input_state`` shifts in place instead of ``torch.cat``."""
+
+    def __init__(self, num_envs, num_states, horizon, device) -> None:
+        assert num_states == 1
+        self.tracker = torch.zeros((num_envs, horizon), device=device)
+        self.device, self.num_envs, self.num_states, self.horizon = device, num_envs, num_states, horizon
+
+    def get_state(self, timestep):
+        return self.tracker[:, timestep]
+
+    def input_state(self, state):
+        self.tracker[:, 1:] = self.tracker[:, :-1].clone()
+        self.tracker[:, 0] = state.reshape(self.num_envs)
+
+
+class _Camera:
+    """What the task reads from ``self.Camera`` (``rover.py:92-99``): the Heightmap and the ray count."""
+
+    def __init__(self, heightmap: Heightmap):
+        self.heightmap = heightmap
+        self.heightmap_distribution = heightmap.get_distribution()
+        self.num_exteroceptive = self.heightmap_distribution.shape[0]
+
+    def get_num_exteroceptive(self):
+        return self.num_exteroceptive
+
+
+class RoverTask(RLTask):
+    def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
+                 num_envs_global=None, env_offset=0) -> None:
+        """``scene``: a ``synth.Scene`` (or ``assets.load_reference_assets(root)``) with the terrain / rocks KNN maps,
+        stone list and heightfield the reference loads from disk (:92-94,:144,:210).  ``distribution``: optional
+        (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set."""
+        if scene is None:
+            raise ValueError("RoverTask needs the terrain assets: pass scene=assets.load_reference_assets(root) "
+                             "or a synth.Scene")
+        if not isinstance(sim_config, SimConfig) and not hasattr(sim_config, "task_config"):
+            raise TypeError("sim_config must expose .config and .task_config (rover.py:103-106)")
+        self.vis_rocks = False
+        self._sim_config = sim_config
+        self._cfg = sim_config.config
+        self._task_cfg = sim_config.task_config
+        self._device = self._cfg["sim_device"]
+        if not str(self._device).startswith("cuda"):
+            raise _lib.RoverError("RoverTask computes on the GPU only (sim_device must be cuda:N)")
+        self._scene = scene
+        self.shift = torch.tensor(list(scene.shift), device=self._device, dtype=torch.float32)   # :91
+        hm = Heightmap(self._device) if distribution is None else Heightmap(self._device, *distribution)
+        self.Camera = _Camera(hm)
+        self.num_exteroceptive = self.Camera.get_num_exteroceptive()
+        self.global_step = 0
+        self._num_proprioceptive = 4                                                      # :98
+        self._num_observations = self._num_proprioceptive + hm.get_num_sparse_vector() + hm.get_num_dense_vector()
+        self._num_actions = 2                                                             # :100
+        self.curriculum_level = 1                                                         # :101
+        self._num_envs = self._task_cfg["env"]["numEnvs"]                                # :113
+        self._env_spacing = self._task_cfg["env"]["envSpacing"]
+        self._rover_positions = torch.tensor([27.0, 30.0, 0.0])                           # :115
+        self._reset_dist = self._task_cfg["env"]["resetDist"]
+        self.max_episode_length = 3000                                                    # :119
+        self.curriculum = self._task_cfg["env"]["terrain"]["curriculum"]
+        self.is_evaluation = False
+        self.target_positions = torch.zeros((self._num_envs, 3), device=self._device, dtype=torch.float32)   # :142
+        self.stone_info = torch.from_numpy(synth.read_stone_info_array(scene.stone_info_raw)).to(self._device)  # :144
+        self.save_teacher_data = self._task_cfg["collect_data"]
+        self.linear_velocity = Memory(self._num_envs, 1, 3, self._device)                 # :154-155
+        self.angular_velocity = Memory(self._num_envs, 1, 3, self._device)
+        self.rew_scales = self._task_cfg["rewards"]                                       # :158
+        self.actions_nn = torch.zeros((self._num_envs, self._num_actions, 3), device=self._device)   # :183
+        self.horizontal_scale = scene.horizontal_scale                                    # :212
+        self.vertical_scale = scene.vertical_scale                                        # :213
+        self.heightmap = scene.heightmap.to(self._device)                                 # :210
+        self._fused = bool(fused)
+        RLTask.__init__(self, name, env)                                                  # :184
+
+        dev_index = torch.device(self._device).index or 0
+        self._engine = _lib.Engine(self._num_envs, device=dev_index, num_envs_global=num_envs_global or 0,
+                                   env_offset=env_offset, curriculum_level=self.curriculum_level,
+                                   max_episode_length=self.max_episode_length, rewards=self.rew_scales)
+        self._engine.set_scene(scene, (hm.distribution, hm.coarse_idx, hm.fine_idx))
+        self._env_offset = int(env_offset)
+
+        # persistent side-state the three methods hand to each other (:274-283, :343, :667)
+        e, dev = self._num_envs, self._device
+        self.rover_rotation = torch.zeros(e, 3, device=dev)
+        self.heading_diff = torch.zeros(e, device=dev)
+        self.rover_rot = torch.zeros(e, 3, device=dev)
+        self.rock_collison = torch.zeros(e, dtype=torch.long, device=dev)
+        self.reset_env_ids_buf = torch.zeros(e, dtype=torch.long, device=dev)
+        self._n_reset = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._compaction_fresh = False
+        for k in _lib.EXTRAS:                                                             # :524-531
+            self.extras[k] = torch.zeros(e, device=dev, dtype=torch.long if k == "collision_penalty" else torch.float32)
+        self.initial_pos = torch.zeros(e, 3, device=dev)
+        self.base_pos = torch.zeros(e, 3, device=dev)
+        self._rover = None
+        self._balls = None
+        self._sin = self._sout = None
+
+    # ------------------------------------------------------------------------------------------------
+    # scene / views (rover.py:196-230, 455-458) — USD is out of scope; views are host pose feeders
+    # ------------------------------------------------------------------------------------------------
+    def set_up_scene(self, scene=None, spawn_positions=None) -> None:
+        """Creates the views and the spawn poses: ``avoid_pos_rock_collision`` + heightfield z + 0.5 (:208-220).
+        ``spawn_positions`` [E,3] replaces the cloner grid positions (default: a grid around :115's origin)."""
+        e, dev = self._num_envs, self._device
+        self._rover = RoverView(e, dev, name="rover_view")
+        self._balls = RigidPrimView(e, dev, name="targets_view")
+        if spawn_positions is None:
+            side = int(math.ceil(math.sqrt(e)))
+            ix = torch.arange(e, device=dev) // side
+            iy = torch.arange(e, device=dev) % side
+            spawn_positions = torch.stack((self._rover_positions[0] + (ix - side / 2) * self._env_spacing,
+                                           self._rover_positions[1] + (iy - side / 2) * self._env_spacing,
+                                           torch.zeros(e, device=dev)), dim=1).float()
+        positions = self.avoid_pos_rock_collision(spawn_positions.to(dev).float().contiguous().clone())   # :215
+        height = self.get_pos_height(self.heightmap, positions[:, 0:2], self.horizontal_scale, self.vertical_scale,
+                                     self.shift[0:2])                                     # :216
+        self.position_z_offset = torch.ones(height.shape, device=dev) * 0.5              # :217
+        positions[:, 2] = height + self.position_z_offset                                 # :218
+        self.initial_pos = positions
+        self._rover.set_world_poses(self.initial_pos, self._rover.get_world_poses()[1])  # :220
+        self._bind()
+
+    def _bind(self):
+        """(Re)build the C-ABI argument structs over the persistent tensors."""
+        pos, quat = self._rover.get_world_poses()
+        eng = self._engine
+        self._sin = eng.make_in(pos, quat, self._rover.get_joint_positions(), self.target_positions,
+                                self.linear_velocity.tracker, self.angular_velocity.tracker, self.rover_rot,
+                                self.progress_buf)
+        self._sout = eng.make_out(self.obs_buf, rew=self.rew_buf, reset=self.reset_buf, rock_collision=self.rock_collison,
+                                  extras=self.extras, reset_ids=self.reset_env_ids_buf, n_reset=self._n_reset,
+                                  euler=self.rover_rotation, heading_diff=self.heading_diff)
+        self.rover_positions = pos
+
+    def reset(self):
+        RLTask.reset(self)
+        self._compaction_fresh = False
+
+    def post_reset(self):
+        self.base_pos = torch.zeros((self.num_envs, 3), dtype=torch.float, device=self._device)     # :456
+        self.initial_root_pos, self.initial_root_rot = self._rover.get_world_poses(clone=True)
+        self.initial_ball_pos, self.initial_ball_rot = self._balls.get_world_poses(clone=True)
+
+    # ------------------------------------------------------------------------------------------------
+    # the hot path
+    # ------------------------------------------------------------------------------------------------
+    def get_observations(self) -> dict:
+        """rover.py:272-336 → rover_get_observations (prep + ray cast + collision mask + obs assembly)."""
+        self.rover_positions = self._rover.get_world_poses()[0]
+        self._engine.get_observations(self._sin, self._sout)
+        return {self._rover.name: {"obs_buf": self.obs_buf}}
+
+    def calculate_metrics(self) -> None:
+        """rover.py:460-531 → rover_calculate_metrics (rew_buf + the 8 extras, in place)."""
+        self._engine.calculate_metrics(self._sin, self._sout)
+
+    def is_done(self) -> None:
+        """rover.py:610-647 → rover_is_done (tilt from the PRE-physics euler ``self.rover_rot``)."""
+        self._engine.is_done(self._sin, self._sout)
+        self._compaction_fresh = False
+
+    def post_physics_step(self):
+        if not self._fused:
+            return RLTask.post_physics_step(self)
+        if self._is_playing():
+            self.rover_positions = self._rover.get_world_poses()[0]
+            self._engine.step(self._sin, self._sout, increment_progress=True, compact=True)
+            self._compaction_fresh = True
+        else:
+            self.progress_buf[:] += 1
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def check_collision(self, wheel_dists, body_dists):
+        """rover.py:663-668, kept for API parity on caller-supplied distances (the step path computes the mask
+        inside the kernels)."""
+        nearest_wheel = torch.min(wheel_dists, dim=1)[0]
+        nearest_body = torch.min(body_dists, dim=1)[0]
+        rc = torch.where(torch.abs(nearest_wheel) < 0.8, torch.ones_like(self.reset_buf), torch.zeros_like(self.reset_buf))
+        self.rock_collison.copy_(torch.where(torch.abs(nearest_body) < 0.45, torch.ones_like(self.reset_buf), rc))
+
+    # ------------------------------------------------------------------------------------------------
+    # action side + resets (rover.py:338-453)
+    # ------------------------------------------------------------------------------------------------
+    def pre_physics_step(self, actions, reset_yaw_deg=None) -> None:
+        self.global_step += 1
+        self.rover_loc = self._rover.get_world_poses()[0]
+        self._engine.quat_to_euler(self._rover.get_world_poses()[1], out=self.rover_rot)          # :343
+        if self.global_step == 10:                                                               # :344-353
+            self.curriculum_level = 2
+            self._engine.set_curriculum_level(2)
+        # done compaction (:356) — already produced by the fused step unless reset_buf was touched since
+        if not self._compaction_fresh:
+            self._engine.compact_resets(self.reset_buf, self.reset_env_ids_buf, self._n_reset)
+        self._compaction_fresh = False
+        n = int(self._n_reset.item())                      # the reference's len(reset_env_ids) is the same host sync
+        if n > 0:
+            reset_env_ids = self.reset_env_ids_buf[:n] - self._env_offset
+            self.reset_idx(reset_env_ids, yaw_deg=reset_yaw_deg)
+            self.set_targets(reset_env_ids)
+        _actions = actions.to(self._device)
+        self.linear_velocity.input_state(_actions[:, 0])                                         # :379-380
+        self.angular_velocity.input_state(_actions[:, 1])
+        self.actions_nn = torch.cat((torch.reshape(_actions, (self.num_envs, self._num_actions, 1)), self.actions_nn), 2)[:, :, 0:3]
+        steering_angles, motor_velocities = self._engine.ackermann(_actions[:, 0].contiguous(), _actions[:, 1].contiguous())  # :391
+        positions = torch.zeros((self._rover.count, 4), dtype=torch.float32, device=self._device)
+        velocities = torch.zeros((self._rover.count, 6), dtype=torch.float32, device=self._device)
+        positions[:, 0] = steering_angles[:, 1]            # FR  (:400-409)
+        positions[:, 1] = steering_angles[:, 5]            # RR
+        positions[:, 2] = steering_angles[:, 0]            # FL
+        positions[:, 3] = steering_angles[:, 4]            # RL
+        velocities[:, 0] = motor_velocities[:, 1]          # FR
+        velocities[:, 1] = motor_velocities[:, 3]          # CR
+        velocities[:, 2] = motor_velocities[:, 5]          # RR
+        velocities[:, 3] = motor_velocities[:, 0]          # FL
+        velocities[:, 4] = motor_velocities[:, 2]          # CL
+        velocities[:, 5] = motor_velocities[:, 4]          # RL
+        self._rover.set_joint_position_targets(positions, indices=None, joint_indices=self._rover.actuated_pos_indices)
+        self._rover.set_joint_velocity_targets(velocities, indices=None, joint_indices=self._rover.actuated_vel_indices)
+
+    def reset_idx(self, env_ids, yaw_deg=None):
+        """rover.py:416-453.  The reference builds scipy's (x,y,z,w) quaternion of a rotation about x and feeds
+        it to Isaac as (w,x,y,z) (:429-431,:449), i.e. w = sin(d/2), z = cos(d/2): a pure yaw of (180° − d).
+        Reproduced as is; ``yaw_deg`` replaces ``random.randint(0, 360)`` when given."""
+        num_resets = len(env_ids)
+        if yaw_deg is None:
+            yaw_deg = torch.randint(0, 361, (num_resets,), device=self._device)
+        half = torch.deg2rad(yaw_deg.to(self._device).float()) / 2
+        reset_orientation = torch.stack((torch.sin(half), torch.zeros_like(half), torch.zeros_like(half), torch.cos(half)), dim=1)
+        dof = torch.zeros((num_resets, 13), device=self._device)
+        self._rover.set_joint_positions(dof, indices=env_ids)
+        self._rover.set_joint_velocities(dof, indices=env_ids)
+        self.base_pos[env_ids] = self.initial_pos[env_ids]
+        self._rover.set_world_poses(self.base_pos[env_ids], reset_orientation.float(), env_ids)
+        self.reset_buf[env_ids] = 0                                                               # :452-453
+        self.progress_buf[env_ids] = 0
+
+    def set_targets(self, env_ids, draws=None):
+        """rover.py:566-584: goals at radius 8 validated against the stone list, goal z from the heightfield."""
+        self.generate_goals(env_ids, radius=8, draws=draws)
+        envs_long = env_ids.long()
+        self._balls.set_world_poses(self.target_positions[envs_long], self.initial_ball_rot[envs_long].clone(), indices=env_ids)
+
+    def generate_goals(self, env_ids, radius, draws=None):
+        """rover.py:544-549 (+ random_goals :554-564, check_goal_collision :533-542, goal z :582-583) as ONE
+        kernel, including the reference's ``env_ids = mask*env_ids`` aliasing.  ``draws`` [n_draws, n] replaces
+        ``torch.rand``; otherwise the library's Philox stream keyed by the global step."""
+        self._engine.generate_goals(env_ids.long().contiguous(), self.initial_pos, self.target_positions, radius=radius,
+                                    draws=draws, max_draws=256, seed=self.global_step)
+
+    def check_goal_collision(self, env_ids):
+        """rover.py:533-542."""
+        c = self._engine.clearance(self.target_positions[env_ids][:, 0:2].contiguous())
+        mask = (c <= 1.0).to(env_ids.dtype)
+        return mask * env_ids, int(mask.sum().item())
+
+    def get_pos_height(self, heightmap, depth_points, horizontal_scale, vertical_scale, shift):
+        """rover.py:588-608 on the heightfield loaded into the engine (arguments kept for signature parity)."""
+        return self._engine.sample_height(depth_points.contiguous().float())
+
+    def avoid_pos_rock_collision(self, curr_pos):
+        """rover.py:649-661: per env, x += 0.05 while the stone clearance is <= 1.4."""
+        return self._engine.shift_spawns(curr_pos)
+
+    def close(self):
+        self._engine.close()

@@ -1,0 +1,126 @@
+"""GPU (-m gpu): the RoverTask / RLTask / VecEnv mirror of the reference API, driven like the reference's own
+post_physics_step (rl_task.py:239-259) and pre_physics_step (rover.py:338-414)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_step_close, load_golden, scene_for, states_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_task(fx, fused, level=2):
+    from isaac_rover_amd.config import SimConfig
+    from isaac_rover_amd.tasks.rover import RoverTask
+    from isaac_rover_amd.vec_env import VecEnv
+    scene = scene_for(fx)
+    st = states_of(fx)
+    e = st["pos"].shape[0]
+    cfg = SimConfig(num_envs=e, device="cuda:0")
+    env = VecEnv(headless=True)
+    task = RoverTask("Rover", cfg, env, scene=scene, distribution=(fx["distribution"], fx["sparse_idx"], fx["dense_idx"]),
+                     fused=fused)
+    env.set_task(task, sim_params={"dt": 0.05}, spawn_positions=st["pos"].clone())
+    # feed the captured sim state (the reference harness does the same on its SimpleNamespace)
+    dev = task.device
+    task._rover.feed(st["pos"].to(dev), st["quat"].to(dev), st["joints"].to(dev))
+    task.target_positions.copy_(st["target"].to(dev))
+    task.linear_velocity.tracker.copy_(st["lin_hist"].to(dev))
+    task.angular_velocity.tracker.copy_(st["ang_hist"].to(dev))
+    task.rover_rot.copy_(st["euler_pre"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.curriculum_level = level
+    task._engine.set_curriculum_level(level)
+    return task, env
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["step_e64_p37_fp32", "step_e8_native_fp32", "step_e64_p37_fp32_level1"])
+def test_post_physics_step_matches_reference(name, fused):
+    fx = load_golden(name)
+    task, env = _make_task(fx, fused, level=int(fx["curriculum_level"]))
+    obs, rew, reset, extras = task.post_physics_step()
+    assert obs is task.obs_buf and rew is task.rew_buf and reset is task.reset_buf      # same objects every step
+    assert obs.dtype == torch.float32 and reset.dtype == torch.int64 and task.progress_buf.dtype == torch.int64
+    got = dict(obs_buf=obs, rew_buf=rew, reset_buf=reset, progress_buf=task.progress_buf, euler=task.rover_rotation,
+               heading_diff=task.heading_diff, rock_collision=task.rock_collison)
+    got.update({"extras_" + k: v for k, v in extras.items()})
+    torch.cuda.synchronize()
+    assert_step_close(got, fx, name)
+    assert set(extras) == {"pos_reward", "collision_penalty", "uprightness_penalty", "heading_contraint_penalty",
+                           "motion_contraint_penalty", "goal_angle_penalty", "torque_penalty_driving",
+                           "torque_penalty_steering"}
+    env.close()
+
+
+def test_native_observation_layout():
+    """1634 rays -> 1750-float observation = [4 | 634 sparse | 1112 dense] (learning/model.py:186-192)."""
+    fx = load_golden("step_e8_native_fp32")
+    task, env = _make_task(fx, True)
+    assert task.num_observations == 1750 and task.num_actions == 2
+    assert task.observation_space.shape == (1750,) and task.action_space.shape == (2,)
+    assert task.Camera.heightmap.get_num_sparse_vector() == 634 and task.Camera.heightmap.get_num_dense_vector() == 1112
+    env.close()
+
+
+def test_pre_physics_step_reset_branch():
+    """rover.py:356-361,416-453,566-584: compaction order, reset bookkeeping, goal validity."""
+    fx = load_golden("step_e64_p37_fp32")
+    task, env = _make_task(fx, True)
+    task.post_physics_step()
+    reset_before = task.reset_buf.clone()
+    ids = reset_before.nonzero(as_tuple=False).squeeze(-1)
+    assert len(ids) > 0
+    task.global_step = 20
+    actions = torch.zeros(task.num_envs, 2, device=task.device)
+    actions[:, 0] = 0.5
+    hist_before = task.linear_velocity.tracker.clone()
+    task.pre_physics_step(actions)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(task.reset_env_ids_buf[: len(ids)].cpu().numpy(), ids.cpu().numpy())
+    assert int(task.reset_buf[ids].sum()) == 0 and int(task.progress_buf[ids].sum()) == 0
+    keep = (reset_before == 0).nonzero().squeeze(-1)
+    assert bool((task.progress_buf[keep] > 0).all())
+    # goals: 8 m from the spawn, clearance > 1.0, z on the heightfield
+    tgt = task.target_positions[ids]
+    r = (tgt[:, 0:2] - task.initial_pos[ids][:, 0:2]).norm(dim=1)
+    if 0 not in ids.tolist():
+        np.testing.assert_allclose(r.cpu().numpy(), 8.0, atol=1e-4)
+    assert bool((task._engine.clearance(tgt[:, 0:2].contiguous()) > 1.0).all())
+    np.testing.assert_array_equal(tgt[:, 2].cpu().numpy(), task._engine.sample_height(tgt[:, 0:2].contiguous()).cpu().numpy())
+    # rovers back at their spawn, joints zeroed, history shifted (Memory, rover.py:60-77)
+    pos, quat = task._rover.get_world_poses()
+    np.testing.assert_array_equal(pos[ids].cpu().numpy(), task.initial_pos[ids].cpu().numpy())
+    np.testing.assert_allclose(quat[ids].norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
+    assert float(task._rover.get_joint_positions()[ids].abs().sum()) == 0.0
+    np.testing.assert_array_equal(task.linear_velocity.tracker[:, 0].cpu().numpy(), actions[:, 0].cpu().numpy())
+    np.testing.assert_array_equal(task.linear_velocity.tracker[:, 1:].cpu().numpy(), hist_before[:, :2].cpu().numpy())
+    env.close()
+
+
+def test_vec_env_rollout():
+    """train.py-style loop: reset, then env.step(actions) for a while; curriculum flips at global step 10."""
+    from isaac_rover_amd import synth
+    from isaac_rover_amd.config import SimConfig
+    from isaac_rover_amd.vec_env import VecEnv, initialize_task
+    scene = synth.make_scene(n_cells=128, k=16, n_stones=10)
+    cfg = SimConfig(num_envs=128, device="cuda:0")
+    env = VecEnv(headless=True)
+    g = torch.Generator().manual_seed(3)
+    spawn = torch.zeros(128, 3)
+    spawn[:, 0:2] = 4.0 + 4.8 * torch.rand(128, 2, generator=g)
+    from isaac_rover_amd.tasks.rover import RoverTask
+    task = RoverTask("Rover", cfg, env, scene=scene, distribution=synth.ray_distribution("37"))
+    env.set_task(task, sim_params={"dt": 0.05}, spawn_positions=spawn)
+    obs = env.reset()
+    assert obs.shape == (128, 41)
+    n_resets = 0
+    for i in range(30):
+        actions = 2 * torch.rand(128, 2, generator=g) - 1
+        obs, rew, done, info = env.step(actions.cuda())
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        assert float(obs.abs().max()) <= 5.0                     # clipObservations, Rover.yaml:16
+        n_resets += int(done.sum())
+    assert task.curriculum_level == 2 and task.global_step == 31
+    assert int(task.progress_buf.max()) <= 31
+    env.close()
