@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--validate-goals", action="store_true",
                     help="configs[4]: also run the reset/spawn-goal validation kernel on the envs flagged done each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-timing", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     ap.add_argument("--scene-cache", default=os.environ.get("ROVER_SCENE_CACHE", ""))
     return ap.parse_args()
@@ -157,15 +158,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Event timing is switched on BEFORE the warm-up: the first timed hipEventRecord on a stream makes the runtime
+    # enable queue profiling once (tens of ms); the warm-up absorbs that, then the counters are reset.
+    eng.set_profiling(True)
     for i in range(args.warmup):
         one_step(i)
     fence()
     eng.set_profiling(True)
     t0 = time.perf_counter()
+    stamps = []
     for i in range(args.steps):
         one_step(args.warmup + i)
+        if args.debug_timing:
+            stamps.append(time.perf_counter())
+    t_enq = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    if args.debug_timing and rank == 0:
+        d = [1e6 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps)]
+        print("enqueue us/step:", " ".join(f"{x:.0f}" for x in d), "| enqueue total ms", 1e3 * (t_enq - t0),
+              "| fence ms", 1e3 * (elapsed - (t_enq - t0)), file=sys.stderr)
     prof = eng.get_profile()
     eng.set_profiling(False)
     if world > 1:

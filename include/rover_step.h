@@ -158,6 +158,13 @@ ROVER_API int rover_generate_goals(rover_ctx *ctx, const int64_t *env_ids, int32
 ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang, int32_t n, float *steering,
                               float *velocities, void *stream);
 
+/* ---- tuning knobs ------------------------------------------------------------------------------------- */
+/* name = "raycast_variant": 1 = one half-wave per ray in env order; 2 = rays counting-sorted by (map, cell), one wave
+ *        per run of sorted rays with the cell's triangles held in registers (default when K8 <= 256 on both maps).
+ *        Both give bit-identical results.
+ * name = "raycast_run": sorted rays per wave for variant 2 (default 16). */
+ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
+
 /* ---- introspection (bench / roofline) ---------------------------------------------------------------- */
 typedef struct {
     int32_t P, Ns, Nd, rays_per_env_padded;

@@ -87,6 +87,7 @@ SYMBOLS = {
     "rover_ackermann": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "rover_replay_raycast": (C.c_int, [_P, _P]),
+    "rover_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
     "rover_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
 }
@@ -305,6 +306,9 @@ class Engine:
         self._chk(out, (n, 3), torch.float32, "euler")
         self._check(self.lib.rover_quat_to_euler(self._h, _ptr(quat), _ptr(out), n, _stream()), "rover_quat_to_euler")
         return out
+
+    def set_option(self, name, value):
+        self._check(self.lib.rover_set_option(self._h, name.encode(), int(value)), "rover_set_option")
 
     def set_profiling(self, enable=True):
         self._check(self.lib.rover_set_profiling(self._h, 1 if enable else 0), "rover_set_profiling")

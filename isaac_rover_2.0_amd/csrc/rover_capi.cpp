@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +38,14 @@ struct rover_ctx {
     float* d_euler = nullptr;       // [E,3]
     float* d_heading = nullptr;     // [E]
     int64_t* d_ids_work = nullptr;  // [E]
+    // ray binning (raycast variant 2)
+    uint32_t* d_bin_cursor = nullptr;   // [n_bins] histogram -> cursors
+    uint32_t* d_block_sums = nullptr;   // [8192]
+    uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
+    uint32_t n_bins = 0;
+    int variant = 0;                    // 0 = auto
+    int last_variant = 1;
+    uint32_t run = 16;
     uint64_t workspace_bytes = 0;
     bool rays_valid = false;
     // in-situ ray-cast timing (rover_set_profiling)
@@ -89,8 +98,27 @@ static void dfree(T*& p) {
     if (p) { (void)hipFree((void*)p); p = nullptr; }
 }
 
+static int effective_variant(const rover_ctx* c) {
+    if (c->variant == 1 || c->variant == 2) {
+        if (c->variant == 2 && (c->map[0].K8 > 256 || c->map[1].K8 > 256)) return 1;
+        return c->variant;
+    }
+    return (c->map[0].K8 <= 256 && c->map[1].K8 <= 256) ? 2 : 1;
+}
+
+static int alloc_bins(rover_ctx* c) {
+    if (!c->have_map[0] || !c->have_map[1]) return ROVER_OK;
+    const uint64_t nb = (uint64_t)c->map[0].X * c->map[0].Y + (uint64_t)c->map[1].X * c->map[1].Y;
+    if (nb > 0xffffffffull) return fail(c, ROVER_E_INVALID, "too many map cells for ray binning");
+    dfree(c->d_bin_cursor); dfree(c->d_block_sums);
+    HIP_TRY(c, hipMalloc((void**)&c->d_bin_cursor, nb * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_block_sums, 8192 * sizeof(uint32_t)));
+    c->n_bins = (uint32_t)nb;
+    return ROVER_OK;
+}
+
 static int alloc_workspace(rover_ctx* c) {
-    dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
+    dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work); dfree(c->d_sorted);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
     c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
     const uint64_t n = E * c->R8;
@@ -100,9 +128,10 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_euler, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_ids_work, E * sizeof(int64_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
-    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float)) + E * (4 * sizeof(float) + sizeof(int64_t));
+    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + sizeof(uint32_t)) + E * (4 * sizeof(float) + sizeof(int64_t));
     c->rays_valid = false;
     return ROVER_OK;
 }
@@ -127,6 +156,8 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
+    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) c->variant = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
+    if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete c; return fail(nullptr, ROVER_E_HIP, "hipSetDevice: %s", hipGetErrorString(e)); }
     *out = c;
@@ -141,6 +172,7 @@ void rover_destroy(rover_ctx* c) {
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
+    dfree(c->d_bin_cursor); dfree(c->d_block_sums); dfree(c->d_sorted);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -184,7 +216,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     c->table_bytes[which] = bytes;
     c->have_map[which] = true;
     c->rays_valid = false;
-    return ROVER_OK;
+    return alloc_bins(c);
 }
 
 int rover_set_distribution(rover_ctx* c, const double* pts, int32_t P, const int64_t* sparse_idx, int32_t Ns,
@@ -266,18 +298,33 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.pos = in->pos; p.quat = in->quat; p.joints = in->joints; p.target = in->target;
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
     p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading;
+    const int variant = effective_variant(c);
+    const uint32_t n_valid = E * (26u + (uint32_t)c->P);
+    if (variant == 2) {
+        p.bin_count = c->d_bin_cursor;
+        p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
+        HIP_TRY(c, hipMemsetAsync(c->d_bin_cursor, 0, (uint64_t)c->n_bins * sizeof(uint32_t), s));
+    }
     HIP_TRY(c, launch_prep(p, s));
+    if (variant == 2)
+        HIP_TRY(c, launch_bin_rays(c->d_rays, E * c->R8, c->d_bin_cursor, c->n_bins, p.rocks_bin_offset, c->d_block_sums,
+                                   c->d_sorted, s));
     if (c->profiling) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
     }
-    HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
-                              (uint32_t)c->map[1].K8, c->d_dist_out, s));
+    if (variant == 2)
+        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
+                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->run, c->d_dist_out, s));
+    else
+        HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
+                                  (uint32_t)c->map[1].K8, c->d_dist_out, s));
     if (c->profiling) {
         HIP_TRY(c, hipEventRecord(c->ev1[c->prof_pending], s));
         ++c->prof_pending;
         ++c->prof_launches;
     }
+    c->last_variant = variant;
     c->rays_valid = true;
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
@@ -444,6 +491,22 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
     return ROVER_OK;
 }
 
+int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return ROVER_E_INVALID;
+    if (!strcmp(name, "raycast_variant")) {
+        if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 or 2");
+        c->variant = (int)value;
+        c->rays_valid = false;
+        return ROVER_OK;
+    }
+    if (!strcmp(name, "raycast_run")) {
+        if (value < 1 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be in [1, 4096]");
+        c->run = (uint32_t)value;
+        return ROVER_OK;
+    }
+    return fail(c, ROVER_E_INVALID, "unknown option '%s'", name);
+}
+
 int rover_set_profiling(rover_ctx* c, int32_t enable) {
     if (!c) return ROVER_E_INVALID;
     if (int r = use_device(c)) return r;
@@ -472,8 +535,13 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (int r = check_ready(c)) return r;
     if (!c->rays_valid) return fail(c, ROVER_E_STATE, "replay_raycast: no ray records yet (run a step first)");
     if (int r = use_device(c)) return r;
-    HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
-                              (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, (hipStream_t)stream));
+    if (c->last_variant == 2)
+        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P),
+                                         c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8,
+                                         c->run, c->d_dist_out, (hipStream_t)stream));
+    else
+        HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
+                                  (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, (hipStream_t)stream));
     return ROVER_OK;
 }
 

@@ -34,6 +34,8 @@ struct PrepArgs {
     KnnDev terrain, rocks;
     RayRec* rays;                // [E*R8]
     float *euler, *heading;      // [E,3], [E]
+    uint32_t* bin_count;         // optional [n_bins]: rays per (map, cell) histogram for the binned ray cast
+    uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
 };
 
 struct ObsArgs {
@@ -63,6 +65,10 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* tab0, const uint16_t* tab1, uint32_t kp0,
                           uint32_t kp1, float* out, hipStream_t s);
+hipError_t launch_bin_rays(const RayRec* rays, uint32_t n_slots, uint32_t* cursor, uint32_t n_bins, uint32_t rocks_bin_offset,
+                           uint32_t* block_sums, uint32_t* sorted, hipStream_t s);
+hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
+                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, float* out, hipStream_t s);
 hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
 hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
                               hipStream_t s);

@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->X);
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
         rec.cell = ix * (uint32_t)m->Y + iy;
+        if (a.bin_count) atomicAdd(a.bin_count + ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell, 1u);
     }
     float4* dst = reinterpret_cast<float4*>(a.rays + gid);
     dst[0] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
@@ -605,6 +606,216 @@ __global__ void __launch_bounds__(256) ackermann_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ray binning: counting sort of the step's rays by (map, cell).  At 65 536 envs every cell of the spawn area
+// is hit by ~10 rays per step; sorted, the 3.6 KB cell block is fetched from HBM once and served from
+// registers / L1 / the XCD's L2 to the other rays.  Results do not depend on the order
+// inside a bin, so the atomics do not make the step non-deterministic.
+//   prep_rays_kernel        histogram (atomicAdd per ray)
+//   scan_*_kernel           exclusive scan of the bin counts -> bin cursors (3 small launches)
+//   scatter_rays_kernel     sorted[cursor[bin]++] = ray slot
+// ---------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+// exclusive scan of one value per thread across a workgroup of NW waves; returns the exclusive prefix, total via ref
+template <int NW>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /*[NW]*/, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63u) lds[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { uint32_t c = lds[i]; wbase += ((uint32_t)i < w) ? c : 0u; tot += c; }
+    __syncthreads();
+    total = tot;
+    return wbase + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_block_sums_kernel(const uint32_t* __restrict__ cnt, uint32_t n,
+                                                                     uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) sum += (base + i < n) ? cnt[base + i] : 0u;
+    uint32_t total;
+    (void)block_exclusive_scan<SCAN_BLOCK / 64>(sum, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan in place of up to 1024*SCAN_ITEMS block sums
+__global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t* __restrict__ block_sums, uint32_t nb) {
+    __shared__ uint32_t lds[16];
+    uint32_t base = threadIdx.x * SCAN_ITEMS, v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < nb) ? block_sums[base + i] : 0u; sum += v[i]; }
+    uint32_t total, run = block_exclusive_scan<16>(sum, lds, total);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < nb) block_sums[base + i] = run; run += v[i]; }
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __restrict__ cnt, uint32_t n,
+                                                                const uint32_t* __restrict__ block_offsets) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? cnt[base + i] : 0u; sum += v[i]; }
+    uint32_t total, run = block_exclusive_scan<SCAN_BLOCK / 64>(sum, lds, total) + block_offsets[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) cnt[base + i] = run; run += v[i]; }
+}
+
+__global__ void __launch_bounds__(256) scatter_rays_kernel(const RayRec* __restrict__ rays, uint32_t n_slots,
+                                                           uint32_t* __restrict__ cursor, uint32_t rocks_bin_offset,
+                                                           uint32_t* __restrict__ sorted) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_slots) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(rays + gid);
+    uint32_t cell = w[3], flags = w[7];
+    if (!(flags & 2u)) return;
+    uint32_t pos = atomicAdd(cursor + ((flags & 1u) ? rocks_bin_offset : 0u) + cell, 1u);
+    sorted[pos] = gid;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ray cast over the binned rays.  One wave walks RUN consecutive sorted rays.  When the cell changes the
+// wave loads the cell block (4 triangles per lane, 9 x 8-byte loads) and sets up a, b = v1-a, c = v0-a, b x c
+// in registers; every further ray of the same cell only pays the ray-dependent part of ray_casting.py:37-59.
+// The three quotients share one reciprocal refinement: the exact instruction sequence of the IEEE f32
+// division expansion without its range scaling (den and quotients here are far from the f32 range ends),
+// so results stay bit-identical to n = N/det, m = M/det, k = K/det.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));       // two triangles side by side -> v_pk_{mul,add,fma}_f32
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct Quot3 { f2 n, m, k; };
+
+// n = nn/det, m = mn/det, k = kn/det for two triangles at once.  Per element this is the instruction sequence of
+// the IEEE-754 f32 division expansion (rcp, two Newton steps on the reciprocal, quotient, two residual
+// corrections) minus its range scaling / fix-up, which only act when |det| or a quotient is near the ends of
+// the f32 range — and every such case fails the barycentric test below either way.
+__device__ __forceinline__ Quot3 div3_ieee(f2 det, f2 nn, f2 mn, f2 kn) {
+    f2 r = {__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
+    const f2 one = {1.0f, 1.0f};
+    f2 e = fma2(-det, r, one);
+    r = fma2(e, r, r);
+    Quot3 q;
+#define ROVER_Q(num, dst)                 \
+    {                                     \
+        f2 t = (num) * r;                 \
+        f2 rem = fma2(-det, t, (num));    \
+        t = fma2(rem, r, t);              \
+        rem = fma2(-det, t, (num));       \
+        dst = fma2(rem, r, t);            \
+    }
+    ROVER_Q(nn, q.n) ROVER_Q(mn, q.m) ROVER_Q(kn, q.k)
+#undef ROVER_Q
+    return q;
+}
+
+__device__ __forceinline__ float accept1(float n, float m, float k, float det) {
+    bool ok = (n >= RAY_NEG_EPS) && (m >= RAY_NEG_EPS) && (n + m <= RAY_ONE_EPS)
+              && (det != RAY_NEG_EPS) && (det != RAY_ONE_EPS);       // ray_casting.py:46,51,56,59
+    return ok ? k : RAY_MISS;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float o = __shfl_xor(v, off, 64);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
+                                                             uint32_t n_sorted, const _Float16* __restrict__ tab0,
+                                                             const _Float16* __restrict__ tab1, uint32_t kp0, uint32_t kp1,
+                                                             uint32_t run, uint32_t n_blocks, uint32_t nb8,
+                                                             float* __restrict__ out) {
+    // XCD-aware order: blocks b, b+8, b+16.. run on one XCD (round-robin dispatch) -> give each XCD one
+    // contiguous eighth of the sorted rays so a cell's rays meet in one L2.  Speed only, never correctness.
+    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    if (lb >= n_blocks) return;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t i = wave * run;
+    if (i >= n_sorted) return;
+    const uint32_t i_end = min(i + run, n_sorted);
+    uint32_t cur_cell = 0xffffffffu, cur_map = 0xffffffffu;
+    // per lane: 4 triangles as 2 pairs; a = v2, b = v1 - a, c = v0 - a, n = b x c
+    f2 ax[2], ay[2], az[2], bx[2], by[2], bz[2], cx[2], cy[2], cz[2], nx[2], ny[2], nz[2];
+    for (; i < i_end; ++i) {
+        const uint32_t gid = __builtin_amdgcn_readfirstlane(sorted[i]);
+        const float4* rp = reinterpret_cast<const float4*>(rays + gid);
+        const float4 ra = rp[0], rb = rp[1];
+        const uint32_t cell = __builtin_amdgcn_readfirstlane(__float_as_uint(ra.w));
+        const uint32_t map = __builtin_amdgcn_readfirstlane(__float_as_uint(rb.w)) & 1u;
+        if (cell != cur_cell || map != cur_map) {
+            cur_cell = cell; cur_map = map;
+            const uint32_t kp = map ? kp1 : kp0;
+            const _Float16* base = (map ? tab1 : tab0) + (size_t)cell * 9u * kp + lane * 4u;
+            if (lane * 4u < kp) {
+                half4 v[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = *reinterpret_cast<const half4*>(base + (size_t)q * kp);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int t0 = 2 * p, t1 = 2 * p + 1;
+                    ax[p] = f2{(float)v[6][t0], (float)v[6][t1]};                                    // a = v2, :34
+                    ay[p] = f2{(float)v[7][t0], (float)v[7][t1]};
+                    az[p] = f2{(float)v[8][t0], (float)v[8][t1]};
+                    bx[p] = f2{(float)v[3][t0], (float)v[3][t1]} - ax[p];                            // b = v1 - a, :35
+                    by[p] = f2{(float)v[4][t0], (float)v[4][t1]} - ay[p];
+                    bz[p] = f2{(float)v[5][t0], (float)v[5][t1]} - az[p];
+                    cx[p] = f2{(float)v[0][t0], (float)v[0][t1]} - ax[p];                            // c = v0 - a, :36
+                    cy[p] = f2{(float)v[1][t0], (float)v[1][t1]} - ay[p];
+                    cz[p] = f2{(float)v[2][t0], (float)v[2][t1]} - az[p];
+                    nx[p] = by[p] * cz[p] - bz[p] * cy[p];                                           // b x c, :40
+                    ny[p] = bz[p] * cx[p] - bx[p] * cz[p];
+                    nz[p] = bx[p] * cy[p] - by[p] * cx[p];
+                }
+            } else {
+                const float qnan = __builtin_nanf("");
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    ax[p] = ay[p] = az[p] = f2{qnan, qnan};
+                    bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = f2{0.0f, 0.0f};
+                }
+            }
+        }
+        const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
+        const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
+        float best = __builtin_inff();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f2 gx = sx - ax[p], gy = sy - ay[p], gz = sz - az[p];                                          // :37
+            f2 det = nx[p] * dx + ny[p] * dy + nz[p] * dz;                                                 // :41
+            f2 gcx = gy * cz[p] - gz * cy[p], gcy = gz * cx[p] - gx * cz[p], gcz = gx * cy[p] - gy * cx[p];
+            f2 nn = gcx * dx + gcy * dy + gcz * dz;                                                        // :44-45
+            f2 bgx = by[p] * gz - bz[p] * gy, bgy = bz[p] * gx - bx[p] * gz, bgz = bx[p] * gy - by[p] * gx;
+            f2 mn = bgx * dx + bgy * dy + bgz * dz;                                                        // :49-50
+            f2 kn = nx[p] * gx + ny[p] * gy + nz[p] * gz;                                                  // :54-55
+            Quot3 q = div3_ieee(det, nn, mn, kn);
+            float r0 = accept1(q.n.x, q.m.x, q.k.x, det.x);
+            float r1 = accept1(q.n.y, q.m.y, q.k.y, det.y);
+            best = (r0 < best) ? r0 : best;
+            best = (r1 < best) ? r1 : best;
+        }
+        best = wave_min(best);
+        if (lane == 0u) out[gid] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
@@ -626,6 +837,29 @@ hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* t
                           uint32_t kp1, float* out, hipStream_t s) {
     hipLaunchKernelGGL(raycast_kernel, dim3(blocks_for(n_rays, 8)), dim3(256), 0, s, rays, n_rays,
                        reinterpret_cast<const _Float16*>(tab0), reinterpret_cast<const _Float16*>(tab1), kp0, kp1, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin_rays(const RayRec* rays, uint32_t n_slots, uint32_t* cursor, uint32_t n_bins, uint32_t rocks_bin_offset,
+                           uint32_t* block_sums, uint32_t* sorted, hipStream_t s) {
+    const uint32_t nb = blocks_for(n_bins, SCAN_TILE);
+    if (nb > 1024u * SCAN_ITEMS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, cursor, n_bins, block_sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, cursor, n_bins, block_sums);
+    hipLaunchKernelGGL(scatter_rays_kernel, dim3(blocks_for(n_slots, 256)), dim3(256), 0, s, rays, n_slots, cursor,
+                       rocks_bin_offset, sorted);
+    return hipGetLastError();
+}
+
+hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
+                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, float* out, hipStream_t s) {
+    const uint32_t n_waves = blocks_for(n_sorted, run);
+    const uint32_t n_blocks = blocks_for(n_waves, 4);
+    const uint32_t nb8 = blocks_for(n_blocks, 8);
+    hipLaunchKernelGGL(raycast_binned_kernel, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted,
+                       reinterpret_cast<const _Float16*>(tab0), reinterpret_cast<const _Float16*>(tab1), kp0, kp1, run,
+                       n_blocks, nb8, out);
     return hipGetLastError();
 }
 

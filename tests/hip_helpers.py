@@ -6,9 +6,13 @@ from isaac_rover_amd import _lib
 EXTRA_DT = {k: (torch.int64 if k == "collision_penalty" else torch.float32) for k in _lib.EXTRAS}
 
 
-def make_engine(scene, distribution, num_envs, **kw):
+def make_engine(scene, distribution, num_envs, variant=None, run=None, **kw):
     eng = _lib.Engine(num_envs, device=0, **kw)
     eng.set_scene(scene, distribution)
+    if variant is not None:
+        eng.set_option("raycast_variant", variant)
+    if run is not None:
+        eng.set_option("raycast_run", run)
     return eng
 
 

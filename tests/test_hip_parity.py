@@ -51,6 +51,22 @@ def test_step_matches_oracle(dist_name, num_envs, seed):
     eng.close()
 
 
+@pytest.mark.parametrize("dist_name,num_envs,k", [("37", 4096, 24), ("120", 512, 200), ("9", 300, 7)])
+def test_raycast_variants_bit_identical(dist_name, num_envs, k):
+    """Variant 1 (half-wave per ray, env order) and variant 2 (rays binned by cell, shared-reciprocal IEEE division,
+    any run length) must agree bit for bit, and with the oracle's ray maths given the same rays."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=64, k=k, n_stones=24)
+    distn = synth.ray_distribution(dist_name)
+    st = synth.make_states(num_envs, 6.4, seed=21)
+    ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
+    for run in (1, 5, 16, 64):
+        got = hip_step(make_engine(scene, distn, num_envs, variant=2, run=run), st)
+        for key in ref:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run}")
+
+
 def test_sharded_equals_whole():
     """Two ctxs over env shards (env_offset, num_envs_global) reproduce one ctx over all envs bit for bit."""
     from hip_helpers import hip_step, make_engine
