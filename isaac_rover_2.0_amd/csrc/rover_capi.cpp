@@ -38,6 +38,8 @@ struct rover_ctx {
     float* d_euler = nullptr;       // [E,3]
     float* d_heading = nullptr;     // [E]
     int64_t* d_ids_work = nullptr;  // [E]
+    float* d_env_rec = nullptr;     // [E][48]
+    uint32_t* d_block_cnt = nullptr;// [ceil(E/256)]
     // ray binning (raycast variant 2)
     uint32_t* d_bin_cursor = nullptr;   // [n_bins] histogram -> cursors
     uint32_t* d_block_sums = nullptr;   // [8192]
@@ -119,6 +121,7 @@ static int alloc_bins(rover_ctx* c) {
 
 static int alloc_workspace(rover_ctx* c) {
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work); dfree(c->d_sorted);
+    dfree(c->d_env_rec);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
     c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
     const uint64_t n = E * c->R8;
@@ -129,6 +132,7 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_ids_work, E * sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_env_rec, E * 48 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
     c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + sizeof(uint32_t)) + E * (4 * sizeof(float) + sizeof(int64_t));
@@ -159,7 +163,8 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) c->variant = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) { delete c; return fail(nullptr, ROVER_E_HIP, "hipSetDevice: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_block_cnt, ((size_t)cfg->num_envs / 256 + 2) * sizeof(uint32_t));
+    if (e != hipSuccess) { delete c; return fail(nullptr, ROVER_E_HIP, "rover_create: %s", hipGetErrorString(e)); }
     *out = c;
     return ROVER_OK;
 }
@@ -172,7 +177,7 @@ void rover_destroy(rover_ctx* c) {
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
-    dfree(c->d_bin_cursor); dfree(c->d_block_sums); dfree(c->d_sorted);
+    dfree(c->d_bin_cursor); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec); dfree(c->d_block_cnt);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -297,7 +302,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.E = E; p.P = (uint32_t)c->P; p.R8 = c->R8;
     p.pos = in->pos; p.quat = in->quat; p.joints = in->joints; p.target = in->target;
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
-    p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading;
+    p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading; p.env_rec = c->d_env_rec;
     const int variant = effective_variant(c);
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     if (variant == 2) {
@@ -339,7 +344,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
 }
 
 static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, int inc, int coll, int met, int done,
-                      hipStream_t s) {
+                      hipStream_t s, bool count_done = false) {
     if (!in->pos || !in->target) return fail(c, ROVER_E_INVALID, "metrics/done: null input pointer");
     if ((inc || met || done) && !in->progress) return fail(c, ROVER_E_INVALID, "metrics/done: progress is required");
     if (!out->rock_collision) return fail(c, ROVER_E_INVALID, "metrics/done: rock_collision is required");
@@ -359,6 +364,7 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.progress = in->progress; m.rock_collision = out->rock_collision; m.rew = out->rew; m.reset = out->reset;
     m.ex_pos_reward = out->ex_pos_reward; m.ex_collision = out->ex_collision_penalty; m.ex_upright = out->ex_uprightness_penalty;
     m.ex_heading = out->ex_heading_contraint_penalty; m.ex_motion = out->ex_motion_contraint_penalty;
+    m.block_cnt = count_done ? c->d_block_cnt : nullptr;
     m.ex_goal_angle = out->ex_goal_angle_penalty; m.ex_lin = out->ex_torque_penalty_driving; m.ex_ang = out->ex_torque_penalty_steering;
     HIP_TRY(c, launch_metrics_done(m, s));
     return ROVER_OK;
@@ -397,7 +403,8 @@ int rover_compact_resets(rover_ctx* c, const int64_t* reset, int64_t* ids, int32
     if (!c) return ROVER_E_INVALID;
     if (!reset || !ids || !n_reset) return fail(c, ROVER_E_INVALID, "compact_resets: null pointer");
     if (int r = use_device(c)) return r;
-    HIP_TRY(c, launch_compact(reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, ids, n_reset, (hipStream_t)stream));
+    HIP_TRY(c, launch_compact(reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, c->d_block_cnt, false, ids, n_reset,
+                              (hipStream_t)stream));
     return ROVER_OK;
 }
 
@@ -410,9 +417,11 @@ int rover_step(rover_ctx* c, const rover_step_in* in, const rover_step_out* out,
     if ((flags & ROVER_STEP_COMPACT) && (!out->reset_ids || !out->n_reset))
         return fail(c, ROVER_E_INVALID, "step: ROVER_STEP_COMPACT needs reset_ids and n_reset");
     if (int r = do_observations(c, in, out, s)) return r;
-    if (int r = do_metrics(c, in, out, (flags & ROVER_STEP_INCREMENT_PROGRESS) ? 1 : 0, 1, 1, 1, s)) return r;
-    if (flags & ROVER_STEP_COMPACT)
-        HIP_TRY(c, launch_compact(out->reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, out->reset_ids, out->n_reset, s));
+    const bool compact = (flags & ROVER_STEP_COMPACT) != 0;
+    if (int r = do_metrics(c, in, out, (flags & ROVER_STEP_INCREMENT_PROGRESS) ? 1 : 0, 1, 1, 1, s, compact)) return r;
+    if (compact)
+        HIP_TRY(c, launch_compact(out->reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, c->d_block_cnt, true,
+                                  out->reset_ids, out->n_reset, s));
     return ROVER_OK;
 }
 

@@ -34,6 +34,7 @@ struct PrepArgs {
     KnnDev terrain, rocks;
     RayRec* rays;                // [E*R8]
     float *euler, *heading;      // [E,3], [E]
+    float* env_rec;              // [E][48] per-env euler / heading / sin-cos record (prep_env_kernel)
     uint32_t* bin_count;         // optional [n_bins]: rays per (map, cell) histogram for the binned ray cast
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
 };
@@ -57,6 +58,7 @@ struct MetricsArgs {
     int64_t* rock_collision;
     float* rew;
     int64_t* reset;
+    uint32_t* block_cnt;         // optional [ceil(E/256)]: per-block done count for the compaction
     float* ex_pos_reward; int64_t* ex_collision; float *ex_upright, *ex_heading, *ex_motion, *ex_goal_angle, *ex_lin, *ex_ang;
 };
 
@@ -73,7 +75,8 @@ hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
 hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
                               hipStream_t s);
 hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s);
-hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, int64_t* ids, int32_t* count, hipStream_t s);
+hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint32_t* block_cnt, bool counted, int64_t* ids,
+                          int32_t* count, hipStream_t s);
 hipError_t launch_quat_to_euler(const float* q, float* eul, uint32_t n, hipStream_t s);
 hipError_t launch_clearance(const float* info7, uint32_t S, const float* xy, uint32_t n, float* out, hipStream_t s);
 hipError_t launch_shift_spawns(const float* info7, uint32_t S, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s);

@@ -144,6 +144,40 @@ __constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0,
                                   {0, 0, 0.03}, {0, 0, 0.03}};
 __constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
 
+// per env: quaternion -> euler, heading, and every sin/cos the ray transforms need (46 floats per env)
+//   env_rec[e][0..2]  roll, pitch, yaw          [3] heading_diff
+//   env_rec[e][4..9]  sin/cos of -roll, -pitch, -yaw (Trig6)
+//   env_rec[e][10+6w .. 15+6w]  wheel w: sin/cos(-steer), sin/cos(susX), sin/cos(susY)   (rock_detect.py:248-272)
+#define ENV_REC 48
+__global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.E) return;
+    const float* pos = a.pos + 3ull * e;
+    float roll, pitch, yaw;
+    quat_to_euler(a.quat + 4ull * e, roll, pitch, yaw);
+    a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
+    float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
+    float tx = a.target[3ull * e] - pos[0], ty = a.target[3ull * e + 1] - pos[1];
+    float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
+    a.heading[e] = hd;
+    float* r = a.env_rec + (size_t)ENV_REC * e;
+    r[0] = roll; r[1] = pitch; r[2] = yaw; r[3] = hd;
+    Trig6 t = euler_trig(roll, pitch, yaw);
+    r[4] = t.sx; r[5] = t.cx; r[6] = t.sy; r[7] = t.cy; r[8] = t.sz; r[9] = t.cz;
+    const float* j = a.joints + 13ull * e;
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        float steer = (w == 0) ? j[4] : (w == 1) ? j[6] : (w == 4) ? -j[7] : (w == 5) ? j[8] : 0.0f;    // :248
+        float susY = (w == 0 || w == 2) ? -j[0] : (w == 1 || w == 3) ? j[1] : 0.0f;                      // :263
+        float susX = (w >= 4) ? -j[2] : 0.0f;                                                            // :264
+        float* q = r + 10 + 6 * w;
+        q[0] = sinf(-steer); q[1] = cosf(-steer);
+        q[2] = sinf(susX);   q[3] = cosf(susX);
+        q[4] = sinf(susY);   q[5] = cosf(susY);
+    }
+}
+
+// per (env, slot): ray origin, unit direction, cell id; rank of the ray inside its (map, cell) bin
 __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t e = gid / a.R8, slot = gid % a.R8;
@@ -153,27 +187,15 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
     const uint32_t n_real = 26u + a.P;
     if (slot < n_real) {
         const float* pos = a.pos + 3ull * e;
-        float roll, pitch, yaw;
-        quat_to_euler(a.quat + 4ull * e, roll, pitch, yaw);
-        if (slot == 0) {
-            a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
-            // heading_diff, rover.py:279-283
-            float dx = cosf(yaw), dy = sinf(yaw);
-            float tx = a.target[3ull * e] - pos[0], ty = a.target[3ull * e + 1] - pos[1];
-            a.heading[e] = -atan2f(tx * dy - ty * dx, tx * dx + ty * dy);
-        }
-        Trig6 t = euler_trig(roll, pitch, yaw);
+        const float* er = a.env_rec + (size_t)ENV_REC * e;
+        Trig6 t;
+        t.sx = er[4]; t.cx = er[5]; t.sy = er[6]; t.cy = er[7]; t.sz = er[8]; t.cz = er[9];
         float sx, sy, sz, ux, uy, uz;      // origin, un-normalised direction
         const KnnDev* m;
         if (slot < 24u) {                   // rock_detect.py:160-319
-            const float* j = a.joints + 13ull * e;
             uint32_t w = slot >> 2, r = slot & 3u;
-            float steer = (w == 0) ? j[4] : (w == 1) ? j[6] : (w == 4) ? -j[7] : (w == 5) ? j[8] : 0.0f;
-            float susY = (w == 0 || w == 2) ? -j[0] : (w == 1 || w == 3) ? j[1] : 0.0f;
-            float susX = (w >= 4) ? -j[2] : 0.0f;
-            float sst = sinf(-steer), cst = cosf(-steer);
-            float ssx = sinf(susX), csx = cosf(susX);
-            float ssy = sinf(susY), csy = cosf(susY);
+            const float* q = er + 10 + 6 * w;
+            const float sst = q[0], cst = q[1], ssx = q[2], csx = q[3], ssy = q[4], csy = q[5];
             const float zero3[3] = {0.0f, 0.0f, 0.0f};
             wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[w], c_wp1[w], sst, cst, ssx, csx,
                         ssy, csy, t, pos[0], pos[1], pos[2], sx, sy, sz);
@@ -217,7 +239,11 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->X);
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
         rec.cell = ix * (uint32_t)m->Y + iy;
-        if (a.bin_count) atomicAdd(a.bin_count + ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell, 1u);
+        if (a.bin_count) {
+            // histogram of the counting sort; the returned count is this ray's rank inside its bin (flags bits 2..31)
+            uint32_t rank = atomicAdd(a.bin_count + ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell, 1u);
+            rec.flags |= rank << 2;
+        }
     }
     float4* dst = reinterpret_cast<float4*>(a.rays + gid);
     dst[0] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
@@ -329,9 +355,15 @@ __global__ void __launch_bounds__(256) export_dist_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 // collision mask + reward + extras + done: one thread per env (rover.py:663-668, 460-531, 610-647)
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= a.E) return;
+__device__ __forceinline__ void block_count_flags(bool flag, uint32_t* __restrict__ block_cnt) {
+    __shared__ uint32_t wcnt[4];
+    unsigned long long ballot = __ballot(flag);
+    if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = __popcll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+__device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t e, bool& done_flag) {
     int64_t progress = (a.do_increment | a.do_metrics | a.do_done) ? a.progress[e] : 0;
     if (a.do_increment) { progress += 1; a.progress[e] = progress; }       // rl_task.py:250
     int64_t coll;
@@ -391,37 +423,50 @@ __global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) {
         if (td <= 0.18f) reset = 1;
         if (a.curriculum_level >= 2 && coll == 1) reset = 1;
         a.reset[e] = reset;
+        done_flag = reset != 0;
     }
 }
 
+__global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool done_flag = false;
+    if (e < a.E) metrics_done_env(a, e, done_flag);
+    if (a.block_cnt) block_count_flags(done_flag, a.block_cnt);           // per-block done count for the compaction
+}
+
 // ---------------------------------------------------------------------------------------------------
-// done compaction: nonzero(reset_buf) ascending, no host sync.  One 1024-thread workgroup sweeps the
-// flags; per 64-lane wave a ballot + popcount gives the in-wave rank, a 16-entry LDS scan the wave base.
+// done compaction: nonzero(reset_buf) ascending, no host sync.  Two passes over 256-env blocks:
+//   count  (fused into metrics_done_kernel, or compact_count_kernel for the stand-alone call): per-block popcount
+//   write  each block sums the counts of the blocks before it, ranks its own flags with ballot + popcount
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) compact_kernel(const int64_t* __restrict__ reset, uint32_t n, int64_t offset,
-                                                       int64_t* __restrict__ ids, int32_t* __restrict__ count) {
-    __shared__ uint32_t wave_cnt[16];
-    __shared__ uint32_t base;
+__global__ void __launch_bounds__(256) compact_count_kernel(const int64_t* __restrict__ reset, uint32_t n,
+                                                            uint32_t* __restrict__ block_cnt) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    block_count_flags((i < n) && (reset[i] != 0), block_cnt);
+}
+
+__global__ void __launch_bounds__(256) compact_write_kernel(const int64_t* __restrict__ reset, uint32_t n, int64_t offset,
+                                                            const uint32_t* __restrict__ block_cnt, int64_t* __restrict__ ids,
+                                                            int32_t* __restrict__ count) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wcnt[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (uint32_t start = 0; start < n; start += 1024u) {
-        uint32_t i = start + tid;
-        bool flag = (i < n) && (reset[i] != 0);
-        unsigned long long ballot = __ballot(flag);
-        uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[w] = __popcll(ballot);
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
+    // exclusive prefix of the preceding blocks' counts (<= a few thousand values: one strided pass)
+    uint32_t part = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += 256u) part += block_cnt[b];
 #pragma unroll
-        for (uint32_t v = 0; v < 16u; ++v) { uint32_t c = wave_cnt[v]; woff += (v < w) ? c : 0u; total += c; }
-        uint32_t b = base;
-        if (flag) ids[b + woff + rank] = offset + (int64_t)i;
-        __syncthreads();
-        if (tid == 0) base = b + total;
-        __syncthreads();
-    }
-    if (tid == 0) *count = (int32_t)base;
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    uint32_t i = blockIdx.x * 256u + tid;
+    bool flag = (i < n) && (reset[i] != 0);
+    unsigned long long ballot = __ballot(flag);
+    if (lane == 0u) { wsum[w] = part; wcnt[w] = __popcll(ballot); }
+    __syncthreads();
+    uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint32_t woff = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < 4u; ++v) woff += (v < w) ? wcnt[v] : 0u;
+    if (flag) ids[base + woff + __popcll(ballot & ((1ull << lane) - 1ull))] = offset + (int64_t)i;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = (int32_t)(base + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
 }
 
 __global__ void __launch_bounds__(256) quat_to_euler_kernel(const float* __restrict__ q, float* __restrict__ eul, uint32_t n) {
@@ -672,15 +717,14 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __rest
 }
 
 __global__ void __launch_bounds__(256) scatter_rays_kernel(const RayRec* __restrict__ rays, uint32_t n_slots,
-                                                           uint32_t* __restrict__ cursor, uint32_t rocks_bin_offset,
+                                                           const uint32_t* __restrict__ bin_start, uint32_t rocks_bin_offset,
                                                            uint32_t* __restrict__ sorted) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_slots) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(rays + gid);
     uint32_t cell = w[3], flags = w[7];
     if (!(flags & 2u)) return;
-    uint32_t pos = atomicAdd(cursor + ((flags & 1u) ? rocks_bin_offset : 0u) + cell, 1u);
-    sorted[pos] = gid;
+    sorted[bin_start[((flags & 1u) ? rocks_bin_offset : 0u) + cell] + (flags >> 2)] = gid;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -727,12 +771,24 @@ __device__ __forceinline__ float accept1(float n, float m, float k, float det) {
     return ok ? k : RAY_MISS;
 }
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float o = __shfl_xor(v, off, 64);
-        v = (o < v) ? o : v;
-    }
+// min over the 64 lanes with DPP row operations (no LDS crossbar): result valid in lane 63.
+// One asm block so the DPP read-after-VALU-write wait states (2, "s_nop 1") are under our control.
+__device__ __forceinline__ float wave_min_to_lane63(float v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 
@@ -794,7 +850,7 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
         }
         const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
         const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
-        float best = __builtin_inff();
+        float best = RAY_MISS;            // every cell holds >= 1 real triangle, so the min is <= 11 (ray_casting.py:27)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             f2 gx = sx - ax[p], gy = sy - ay[p], gz = sz - az[p];                                          // :37
@@ -807,11 +863,10 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
             Quot3 q = div3_ieee(det, nn, mn, kn);
             float r0 = accept1(q.n.x, q.m.x, q.k.x, det.x);
             float r1 = accept1(q.n.y, q.m.y, q.k.y, det.y);
-            best = (r0 < best) ? r0 : best;
-            best = (r1 < best) ? r1 : best;
+            best = __builtin_fminf(best, __builtin_fminf(r0, r1));       // no NaN can reach here (accept1 filters)
         }
-        best = wave_min(best);
-        if (lane == 0u) out[gid] = best;
+        best = wave_min_to_lane63(best);
+        if (lane == 63u) out[gid] = best;
     }
 }
 
@@ -829,6 +884,7 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
     uint64_t n = (uint64_t)a.E * a.R8;
+    hipLaunchKernelGGL(prep_env_kernel, dim3(blocks_for(a.E, 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -880,8 +936,11 @@ hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, int64_t* ids, int32_t* count, hipStream_t s) {
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, reset, n, offset, ids, count);
+hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint32_t* block_cnt, bool counted, int64_t* ids,
+                          int32_t* count, hipStream_t s) {
+    const uint32_t nb = blocks_for(n, 256);
+    if (!counted) hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, s, reset, n, block_cnt);
+    hipLaunchKernelGGL(compact_write_kernel, dim3(nb), dim3(256), 0, s, reset, n, offset, block_cnt, ids, count);
     return hipGetLastError();
 }
 
