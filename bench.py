@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--rays", default="37", choices=["9", "37", "120"])
     ap.add_argument("--cells", type=int, default=600)
@@ -167,15 +167,20 @@ def main():
     eng.set_profiling(True)
     t0 = time.perf_counter()
     stamps = []
+    evs = []
     for i in range(args.steps):
         one_step(args.warmup + i)
         if args.debug_timing:
             stamps.append(time.perf_counter())
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            evs.append(ev)
     t_enq = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
     if args.debug_timing and rank == 0:
         d = [1e6 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps)]
+        print("gpu ms/step:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(evs[:-1], evs[1:])), file=sys.stderr)
         print("enqueue us/step:", " ".join(f"{x:.0f}" for x in d), "| enqueue total ms", 1e3 * (t_enq - t0),
               "| fence ms", 1e3 * (elapsed - (t_enq - t0)), file=sys.stderr)
     prof = eng.get_profile()

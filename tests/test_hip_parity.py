@@ -51,7 +51,8 @@ def test_step_matches_oracle(dist_name, num_envs, seed):
     eng.close()
 
 
-@pytest.mark.parametrize("dist_name,num_envs,k", [("37", 4096, 24), ("120", 512, 200), ("9", 300, 7)])
+@pytest.mark.parametrize("dist_name,num_envs,k", [("37", 4096, 24), ("120", 512, 200), ("9", 300, 7), ("37", 700, 100),
+                                                  ("9", 200, 16)])
 def test_raycast_variants_bit_identical(dist_name, num_envs, k):
     """Variant 1 (half-wave per ray, env order) and variant 2 (rays binned by cell, shared-reciprocal IEEE division,
     any run length) must agree bit for bit, and with the oracle's ray maths given the same rays."""
@@ -61,10 +62,11 @@ def test_raycast_variants_bit_identical(dist_name, num_envs, k):
     distn = synth.ray_distribution(dist_name)
     st = synth.make_states(num_envs, 6.4, seed=21)
     ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
-    for run in (1, 5, 16, 64):
-        got = hip_step(make_engine(scene, distn, num_envs, variant=2, run=run), st)
-        for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run}")
+    for variant in (2, 3):
+        for run in (1, 5, 16, 64):
+            got = hip_step(make_engine(scene, distn, num_envs, variant=variant, run=run), st)
+            for key in ref:
+                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} run={run}")
 
 
 def test_sharded_equals_whole():
