@@ -139,17 +139,18 @@ def main():
     if args.validate_goals:
         n_used = torch.zeros(1, dtype=torch.int32, device=device)
         initial = [b["pos"].clone() for b in batches]
+        joint_vel = torch.zeros(E, 13, device=device)
 
     def one_step(i):
         b = i % len(batches)
         eng.step(sins[b], sout, increment_progress=True, compact=True)
         if args.validate_goals:
-            # reset/spawn-goal validation for the envs flagged done (configs[4]); the count is read on the host
-            # exactly like rover.py:356-357 does
-            n = int(n_reset.item())
-            if n:
-                ids = reset_ids[:n] - rank * E
-                eng.generate_goals(ids, initial[b], batches[b]["target"], seed=i, max_draws=256, n_draws_used=n_used)
+            # configs[4]: reset_idx + set_targets (goal re-draw + stone-clearance validation + goal z) for the envs the
+            # step flagged done, consuming the compacted ids on the device — no host sync (rover.py:356-361 has one)
+            st = batches[b]
+            eng.reset_envs(reset_ids, initial[b], st["pos"], st["quat"], reset, st["progress"], n_reset_dev=n_reset,
+                           joint_pos13=st["joints"], joint_vel13=joint_vel, target3=st["target"], radius=8.0, seed=i,
+                           max_draws=256, n_draws_used=n_used)
         gather.gather()
 
     def fence():

@@ -153,8 +153,41 @@ ROVER_API int rover_generate_goals(rover_ctx *ctx, const int64_t *env_ids, int32
                                    float *target3, float radius, const float *draws, int32_t max_draws, uint64_t seed,
                                    int32_t *n_draws_used, void *stream);
 
-/* ---- action side ("next" row f-1): Ackermann tasks/utils/kinematics.py:13-67 --------------------------- */
-/* lin, ang [n] -> steering [n][6], velocities [n][6] in wheel order FL,FR,ML,MR,RL,RR */
+/* ---- device-side reset orchestration ("next" row f-2): reset_idx + set_targets rover.py:416-453,566-584 ----- */
+/* Consumes the compacted reset ids of the last step WITHOUT the host sync of rover.py:357: the count is read from
+ * device memory (n_reset_dev) by the kernels.  For every listed env: pose = initial_pos, orientation = the
+ * reference's (w,x,y,z) <- scipy (x,y,z,w) yaw quirk with d = yaw_deg[i] or a Philox draw in [0,360], joint
+ * positions / velocities zeroed, reset = 0, progress = 0; then (if target3 != NULL) goals are re-drawn and validated
+ * exactly like rover_generate_goals, including the goal z lookup.  All pointers are device pointers. */
+typedef struct {
+    const int64_t *reset_ids;     /* [E] ascending GLOBAL env ids (rover_step's reset_ids)                         */
+    const int32_t *n_reset_dev;   /* [1] device count; NULL = use n_reset_host                                     */
+    int32_t n_reset_host;
+    const float *initial_pos3;    /* [E,3] self.initial_pos                                                        */
+    float *pos3, *quat4;          /* [E,3], [E,4] RoverView poses (in place)                                       */
+    float *joint_pos13, *joint_vel13; /* [E,13] optional                                                           */
+    float *base_pos3;             /* [E,3] optional self.base_pos                                                  */
+    int64_t *reset, *progress;    /* [E] reset_buf, progress_buf                                                   */
+    const int32_t *yaw_deg;       /* [n] optional: replaces random.randint(0, 360) (rover.py:429)                  */
+    float *target3;               /* [E,3] optional self.target_positions: re-draw + validate goals                */
+    float radius;                 /* rover.py:578 (8)                                                              */
+    const float *draws;           /* optional [max_draws][n] uniforms (needs n_reset_host)                         */
+    int32_t max_draws;
+    uint64_t seed;
+    int32_t *n_draws_used;        /* optional [1]                                                                  */
+} rover_reset_io;
+ROVER_API int rover_reset_envs(rover_ctx *ctx, const rover_reset_io *io, void *stream);
+
+/* ---- action side ("next" row f-1) --------------------------------------------------------------------------- */
+/* pre_physics_step rover.py:338-414 minus the reset branch, one kernel: euler_pre = tensor_quat_to_eul(quat) (:343),
+ * Memory.input_state for both histories (:379-380, in place, newest first), Ackermann (:391) and the scatter of
+ * 4 steering angles / 6 wheel speeds into the [E,13] joint-target arrays at the indices of
+ * robots/articulations/views/rover_view.py:45-46.  actions [E,2]; euler_pre / targets optional. */
+ROVER_API int rover_pre_physics_step(rover_ctx *ctx, const float *actions, const float *quat, float *lin_hist,
+                                     float *ang_hist, float *euler_pre, float *joint_pos_targets13,
+                                     float *joint_vel_targets13, void *stream);
+/* Ackermann tasks/utils/kinematics.py:13-67 on its own:
+ * lin, ang [n] -> steering [n][6], velocities [n][6] in wheel order FL,FR,ML,MR,RL,RR */
 ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang, int32_t n, float *steering,
                               float *velocities, void *stream);
 

@@ -57,6 +57,14 @@ class Info(C.Structure):
                 ("table_bytes", C.c_uint64 * 2), ("workspace_bytes", C.c_uint64)]
 
 
+class ResetIO(C.Structure):
+    _fields_ = [("reset_ids", C.c_void_p), ("n_reset_dev", C.c_void_p), ("n_reset_host", C.c_int32),
+                ("initial_pos3", C.c_void_p), ("pos3", C.c_void_p), ("quat4", C.c_void_p), ("joint_pos13", C.c_void_p),
+                ("joint_vel13", C.c_void_p), ("base_pos3", C.c_void_p), ("reset", C.c_void_p), ("progress", C.c_void_p),
+                ("yaw_deg", C.c_void_p), ("target3", C.c_void_p), ("radius", C.c_float), ("draws", C.c_void_p),
+                ("max_draws", C.c_int32), ("seed", C.c_uint64), ("n_draws_used", C.c_void_p)]
+
+
 class Profile(C.Structure):
     _fields_ = [("raycast_ms", C.c_double), ("launches", C.c_int32), ("pairs_per_launch", C.c_uint64)]
 
@@ -84,6 +92,8 @@ SYMBOLS = {
     "rover_shift_spawns": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "rover_sample_height": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rover_generate_goals": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_float, _P, C.c_int32, C.c_uint64, _P, _P]),
+    "rover_reset_envs": (C.c_int, [_P, C.POINTER(ResetIO), _P]),
+    "rover_pre_physics_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rover_ackermann": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "rover_replay_raycast": (C.c_int, [_P, _P]),
@@ -356,6 +366,39 @@ class Engine:
         self._check(self.lib.rover_generate_goals(self._h, _ptr(env_ids), n, _ptr(initial_pos3), _ptr(target3),
                                                   float(radius), _ptr(draws), int(max_draws), int(seed),
                                                   _ptr(n_draws_used), _stream()), "rover_generate_goals")
+
+    def reset_envs(self, reset_ids, initial_pos3, pos3, quat4, reset, progress, n_reset_dev=None, n_reset_host=0,
+                   joint_pos13=None, joint_vel13=None, base_pos3=None, yaw_deg=None, target3=None, radius=8.0, draws=None,
+                   max_draws=256, seed=0, n_draws_used=None):
+        e, f, i64 = self.num_envs, torch.float32, torch.int64
+        self._chk(reset_ids, (e,), i64, "reset_ids")
+        for t, sh, n in ((initial_pos3, (e, 3), "initial_pos3"), (pos3, (e, 3), "pos3"), (quat4, (e, 4), "quat4"),
+                         (joint_pos13, (e, 13), "joint_pos13"), (joint_vel13, (e, 13), "joint_vel13"),
+                         (base_pos3, (e, 3), "base_pos3"), (target3, (e, 3), "target3")):
+            self._chk(t, sh, f, n)
+        self._chk(reset, (e,), i64, "reset")
+        self._chk(progress, (e,), i64, "progress")
+        self._chk(n_reset_dev, (1,), torch.int32, "n_reset_dev")
+        self._chk(n_draws_used, (1,), torch.int32, "n_draws_used")
+        if yaw_deg is not None:
+            self._chk(yaw_deg, (yaw_deg.shape[0],), torch.int32, "yaw_deg")
+        if draws is not None:
+            self._chk(draws, (draws.shape[0], int(n_reset_host)), f, "draws")
+            max_draws = draws.shape[0]
+        io = ResetIO(_ptr(reset_ids), _ptr(n_reset_dev), int(n_reset_host), _ptr(initial_pos3), _ptr(pos3), _ptr(quat4),
+                     _ptr(joint_pos13), _ptr(joint_vel13), _ptr(base_pos3), _ptr(reset), _ptr(progress), _ptr(yaw_deg),
+                     _ptr(target3), float(radius), _ptr(draws), int(max_draws), int(seed), _ptr(n_draws_used))
+        self._check(self.lib.rover_reset_envs(self._h, C.byref(io), _stream()), "rover_reset_envs")
+
+    def pre_physics_step(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None):
+        e, f = self.num_envs, torch.float32
+        for t, sh, n in ((actions, (e, 2), "actions"), (quat, (e, 4), "quat"), (lin_hist, (e, 3), "lin_hist"),
+                         (ang_hist, (e, 3), "ang_hist"), (euler_pre, (e, 3), "euler_pre"),
+                         (pos_targets13, (e, 13), "pos_targets13"), (vel_targets13, (e, 13), "vel_targets13")):
+            self._chk(t, sh, f, n)
+        self._check(self.lib.rover_pre_physics_step(self._h, _ptr(actions), _ptr(quat), _ptr(lin_hist), _ptr(ang_hist),
+                                                    _ptr(euler_pre), _ptr(pos_targets13), _ptr(vel_targets13), _stream()),
+                    "rover_pre_physics_step")
 
     def ackermann(self, lin, ang):
         n = lin.shape[0]

@@ -39,6 +39,7 @@ struct rover_ctx {
     float* d_heading = nullptr;     // [E]
     int64_t* d_ids_work = nullptr;  // [E]
     float* d_env_rec = nullptr;     // [E][48]
+    uint32_t* d_goal_work = nullptr;// [2][E] work lists of generate_goals
     uint32_t* d_block_cnt = nullptr;// [ceil(E/256)]
     // ray binning (raycast variant 2)
     uint32_t* d_bin_cursor = nullptr;   // [n_bins] histogram -> cursors
@@ -140,7 +141,7 @@ static int alloc_bins(rover_ctx* c) {
 }
 
 static int alloc_workspace(rover_ctx* c) {
-    dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work); dfree(c->d_sorted);
+    dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_sorted);
     dfree(c->d_env_rec);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
     c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
@@ -150,7 +151,6 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_dist_out, n * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_euler, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_ids_work, E * sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_env_rec, E * 48 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
@@ -184,6 +184,8 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_block_cnt, ((size_t)cfg->num_envs / 256 + 2) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_goal_work, 2 * (size_t)cfg->num_envs * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ids_work, (size_t)cfg->num_envs * sizeof(int64_t));
     if (e != hipSuccess) { delete c; return fail(nullptr, ROVER_E_HIP, "rover_create: %s", hipGetErrorString(e)); }
     *out = c;
     return ROVER_OK;
@@ -198,6 +200,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_stones);
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
     dfree(c->d_bin_cursor); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec); dfree(c->d_block_cnt);
+    dfree(c->d_goal_work);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -499,10 +502,49 @@ int rover_generate_goals(rover_ctx* c, const int64_t* env_ids, int32_t n, const 
     if (n < 0 || n > c->cfg.num_envs || (n > 0 && (!env_ids || !initial_pos3 || !target3)) || max_draws <= 0)
         return fail(c, ROVER_E_INVALID, "generate_goals: bad arguments (n=%d, max_draws=%d)", n, max_draws);
     if (n == 0) return ROVER_OK;
-    if (!c->d_ids_work) return fail(c, ROVER_E_STATE, "generate_goals: rover_set_distribution first (allocates the workspace)");
     if (int r = use_device(c)) return r;
-    HIP_TRY(c, launch_generate_goals(c->d_stones, (uint32_t)c->S, c->hf, env_ids, c->d_ids_work, (uint32_t)n, initial_pos3, target3,
-                                     radius, draws, max_draws, seed, n_draws_used, (hipStream_t)stream));
+    HIP_TRY(c, launch_generate_goals(c->d_stones, (uint32_t)c->S, c->hf, env_ids, 0, c->d_ids_work, c->d_goal_work,
+                                     (uint32_t)c->cfg.num_envs, (uint32_t)n, nullptr, initial_pos3, target3, radius, draws,
+                                     max_draws, seed, n_draws_used, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_reset_envs(rover_ctx* c, const rover_reset_io* io, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!io) return fail(c, ROVER_E_INVALID, "reset_envs: null struct");
+    if (!io->reset_ids || !io->initial_pos3 || !io->pos3 || !io->quat4 || !io->reset || !io->progress)
+        return fail(c, ROVER_E_INVALID, "reset_envs: reset_ids, initial_pos3, pos3, quat4, reset and progress are required");
+    if (!io->n_reset_dev && (io->n_reset_host < 0 || io->n_reset_host > c->cfg.num_envs))
+        return fail(c, ROVER_E_INVALID, "reset_envs: n_reset_host=%d out of range", io->n_reset_host);
+    if (io->draws && io->n_reset_dev) return fail(c, ROVER_E_INVALID, "reset_envs: caller-supplied draws need n_reset_host");
+    if (io->target3 && (!c->have_stones || !c->have_hf))
+        return fail(c, ROVER_E_STATE, "reset_envs: goal validation needs rover_set_stones and rover_set_heightfield");
+    if (!io->n_reset_dev && io->n_reset_host == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    ResetArgs a{};
+    a.ids = io->reset_ids; a.id_offset = c->cfg.env_offset; a.n_host = (uint32_t)io->n_reset_host; a.n_dev = io->n_reset_dev;
+    a.initial_pos3 = io->initial_pos3; a.pos3 = io->pos3; a.quat4 = io->quat4; a.joint_pos13 = io->joint_pos13;
+    a.joint_vel13 = io->joint_vel13; a.base_pos3 = io->base_pos3; a.reset = io->reset; a.progress = io->progress;
+    a.yaw_deg = io->yaw_deg; a.seed = io->seed;
+    const uint32_t n_max = io->n_reset_dev ? (uint32_t)c->cfg.num_envs : (uint32_t)io->n_reset_host;
+    HIP_TRY(c, launch_reset_envs(a, n_max, s));
+    if (io->target3)
+        HIP_TRY(c, launch_generate_goals(c->d_stones, (uint32_t)c->S, c->hf, io->reset_ids, (int64_t)c->cfg.env_offset,
+                                         c->d_ids_work, c->d_goal_work, (uint32_t)c->cfg.num_envs, (uint32_t)io->n_reset_host,
+                                         io->n_reset_dev, io->initial_pos3, io->target3, io->radius > 0.f ? io->radius : 8.0f,
+                                         io->draws, io->max_draws > 0 ? io->max_draws : 256, io->seed, io->n_draws_used, s));
+    return ROVER_OK;
+}
+
+int rover_pre_physics_step(rover_ctx* c, const float* actions, const float* quat, float* lin_hist, float* ang_hist,
+                           float* euler_pre, float* pos_targets13, float* vel_targets13, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!actions || !lin_hist || !ang_hist) return fail(c, ROVER_E_INVALID, "pre_physics_step: actions and both histories are required");
+    if (euler_pre && !quat) return fail(c, ROVER_E_INVALID, "pre_physics_step: euler_pre needs quat");
+    if (int r = use_device(c)) return r;
+    PrePhysicsArgs a{(uint32_t)c->cfg.num_envs, actions, quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13};
+    HIP_TRY(c, launch_pre_physics(a, (hipStream_t)stream));
     return ROVER_OK;
 }
 

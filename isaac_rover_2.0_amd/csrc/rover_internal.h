@@ -63,6 +63,24 @@ struct MetricsArgs {
     float* ex_pos_reward; int64_t* ex_collision; float *ex_upright, *ex_heading, *ex_motion, *ex_goal_angle, *ex_lin, *ex_ang;
 };
 
+struct ResetArgs {
+    const int64_t* ids;          // compacted reset ids (global)
+    int64_t id_offset;           // env_offset: global -> local
+    uint32_t n_host;
+    const int32_t* n_dev;        // optional: count in device memory
+    const float* initial_pos3;
+    float *pos3, *quat4, *joint_pos13, *joint_vel13, *base_pos3;
+    int64_t *reset, *progress;
+    const int32_t* yaw_deg;      // optional [n]
+    uint64_t seed;
+};
+
+struct PrePhysicsArgs {
+    uint32_t E;
+    const float *actions, *quat;
+    float *lin_hist, *ang_hist, *euler_pre, *pos_targets13, *vel_targets13;
+};
+
 hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                          uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s);
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
@@ -85,9 +103,12 @@ hipError_t launch_quat_to_euler(const float* q, float* eul, uint32_t n, hipStrea
 hipError_t launch_clearance(const float* info7, uint32_t S, const float* xy, uint32_t n, float* out, hipStream_t s);
 hipError_t launch_shift_spawns(const float* info7, uint32_t S, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s);
 hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n, float* out, hipStream_t s);
-hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t* ids_work,
-                                 uint32_t n, const float* initial_pos3, float* target3, float radius, const float* draws,
-                                 int32_t max_draws, uint64_t seed, int32_t* n_draws_used, hipStream_t s);
+hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t id_offset,
+                                 int64_t* ids_work, uint32_t* work2, uint32_t work_stride, uint32_t n, const int32_t* n_dev,
+                                 const float* initial_pos3, float* target3, float radius, const float* draws, int32_t max_draws,
+                                 uint64_t seed, int32_t* n_draws_used, hipStream_t s);
+hipError_t launch_reset_envs(const ResetArgs& a, uint32_t n_max, hipStream_t s);
+hipError_t launch_pre_physics(const PrePhysicsArgs& a, hipStream_t s);
 hipError_t launch_ackermann(const float* lin, const float* ang, uint32_t n, float* steer, float* vel, hipStream_t s);
 
 }  // namespace rover

@@ -561,67 +561,162 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t draw, ui
     return (float)(c0 >> 8) * (1.0f / 16777216.0f);                        // [0,1) with 24 bits, like torch.rand f32
 }
 
-// generate_goals rover.py:544-549 as ONE workgroup (resets per step are few): draw -> write -> check -> mask,
-// with the env_ids = mask*env_ids aliasing (:540).  Duplicate id-0 writers resolve "last entry wins", the
-// order a sequential index_put gives.  ids_work [n] is scratch.
+// generate_goals rover.py:544-549 as ONE workgroup: draw -> write -> check -> mask, with the
+// env_ids = mask*env_ids aliasing (:540): an accepted entry's id becomes 0, so from then on it re-randomises
+// env 0's goal and the loop also waits for env 0's goal to be clear.  Duplicate id-0 writers resolve "last entry
+// wins" (what a sequential index_put gives), so only the highest-index zero entry draws.  Entries that are
+// still colliding live in a compacted work list, so an iteration costs (#colliding + 1) x S distance tests.
+// n may come from device memory (n_dev: the done-compaction count) so no host sync is needed.
 __global__ void __launch_bounds__(1024) generate_goals_kernel(const float* __restrict__ info7, uint32_t S, HeightDev h,
-                                                              const int64_t* __restrict__ env_ids, int64_t* __restrict__ ids_work,
-                                                              uint32_t n, const float* __restrict__ initial_pos3,
-                                                              float* __restrict__ target3, float radius,
-                                                              const float* __restrict__ draws, int32_t max_draws, uint64_t seed,
-                                                              int32_t* __restrict__ n_draws_used) {
+                                                              const int64_t* __restrict__ env_ids, int64_t id_offset,
+                                                              int64_t* __restrict__ ids_work, uint32_t* __restrict__ work_a,
+                                                              uint32_t* __restrict__ work_b, uint32_t n_host,
+                                                              const int32_t* __restrict__ n_dev,
+                                                              const float* __restrict__ initial_pos3, float* __restrict__ target3,
+                                                              float radius, const float* __restrict__ draws, int32_t max_draws,
+                                                              uint64_t seed, int32_t* __restrict__ n_draws_used) {
     __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
-    __shared__ int bad, last_zero;
+    __shared__ int n_work, n_next, last_zero, last_zero_new, env0_bad;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < n; i += blockDim.x) ids_work[i] = env_ids[i];
+    const uint32_t n = n_dev ? (uint32_t)max(*n_dev, 0) : n_host;
+    if (n == 0) { if (tid == 0 && n_draws_used) *n_draws_used = 0; return; }
+    if (tid == 0) { n_work = 0; last_zero = -1; }
     __syncthreads();
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        int64_t id = env_ids[i] - id_offset;
+        ids_work[i] = id;
+        if (id != 0) work_a[atomicAdd(&n_work, 1)] = i;
+        else atomicMax(&last_zero, (int)i);
+    }
+    __syncthreads();
+    uint32_t* work = work_a;
+    uint32_t* work_next = work_b;
     int32_t used = 0;
     bool failed = false;
+    const float two_pi = (float)(2 * 3.14159265358979323846);
     while (true) {
         if (used >= max_draws) { failed = true; break; }
-        if (tid == 0) { bad = 0; last_zero = -1; }
+        const int nw = n_work, lz = last_zero;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += blockDim.x)
-            if (ids_work[i] == 0) atomicMax(&last_zero, (int)i);
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += blockDim.x) {                    // random_goals :554-564
-            int64_t id = ids_work[i];
-            if (id == 0 && (int)i != last_zero) continue;
+        for (uint32_t k = tid; k < (uint32_t)nw + 1u; k += blockDim.x) {        // random_goals :554-564
+            const bool env0_writer = (k == (uint32_t)nw);
+            if (env0_writer && lz < 0) continue;
+            const uint32_t i = env0_writer ? (uint32_t)lz : work[k];
+            const int64_t id = env0_writer ? 0 : ids_work[i];
             float u = draws ? draws[(uint64_t)used * n + i] : philox_uniform(seed, (uint32_t)used, i);
-            float alpha = (float)(2 * 3.14159265358979323846) * u;
+            float alpha = two_pi * u;
             float x = radius * cosf(alpha) + 0.0f, y = radius * sinf(alpha) + 0.0f;
             target3[3ull * id] = x + initial_pos3[3ull * id];
             target3[3ull * id + 1] = y + initial_pos3[3ull * id + 1];
         }
+        if (tid == 0) { n_next = 0; last_zero_new = -1; env0_bad = 0; }
         __threadfence_block();
         __syncthreads();
         ++used;
-        for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {                   // check_goal_collision :533-542
-            uint32_t i = i0 + tid;
-            bool live = i < n;
-            int64_t id = live ? ids_work[i] : 0;
+        for (uint32_t k0 = 0; k0 < (uint32_t)nw + 1u; k0 += blockDim.x) {       // check_goal_collision :533-542
+            const uint32_t k = k0 + tid;
+            const bool env0_check = (k == (uint32_t)nw) && lz >= 0;
+            const bool live = (k < (uint32_t)nw) || env0_check;
+            uint32_t i = 0; int64_t id = 0;
+            if (k < (uint32_t)nw) { i = work[k]; id = ids_work[i]; }
             float x = live ? target3[3ull * id] : 0.0f, y = live ? target3[3ull * id + 1] : 0.0f;
             float c = clearance_tiles(info7, S, x, y, live, sx, sy, sr);
             if (live) {
-                bool m = c <= 1.0f;
-                ids_work[i] = m ? id : 0;
-                if (m) atomicAdd(&bad, 1);
+                const bool m = c <= 1.0f;
+                if (env0_check) { if (m) env0_bad = 1; }
+                else if (m) work_next[atomicAdd(&n_next, 1)] = i;
+                else { ids_work[i] = 0; atomicMax(&last_zero_new, (int)i); }
             }
         }
         __syncthreads();
-        int b = bad;
+        const int bad = n_next + env0_bad;
         __syncthreads();
-        if (b == 0) break;
+        if (tid == 0) { n_work = n_next; last_zero = max(last_zero, last_zero_new); }
+        uint32_t* t = work; work = work_next; work_next = t;
+        __syncthreads();
+        if (bad == 0) break;
     }
     // goal z, set_targets rover.py:581-583 (over the ORIGINAL env ids)
     for (uint32_t i = tid; i < n; i += blockDim.x) {
-        int64_t id = env_ids[i];
+        int64_t id = env_ids[i] - id_offset;
         uint32_t ix = cell_coord(target3[3ull * id], h.shift_x, h.hscale, h.N0);
         uint32_t iy = cell_coord(target3[3ull * id + 1], h.shift_y, h.hscale, h.N0);
         if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
         target3[3ull * id + 2] = h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
     }
     if (tid == 0 && n_draws_used) *n_draws_used = failed ? -1 : used;
+}
+
+// reset_idx rover.py:416-453 for the compacted reset ids, count read from device memory (no host sync).
+// Orientation: the reference feeds scipy's (x,y,z,w) of a rotation about x to Isaac as (w,x,y,z) (:429-431,:449),
+// i.e. w = sin(d/2), z = cos(d/2) with d = randint(0, 360) degrees.  yaw_deg (optional) replaces the draw.
+__global__ void __launch_bounds__(256) reset_envs_kernel(ResetArgs a) {
+    const uint32_t n = a.n_dev ? (uint32_t)max(*a.n_dev, 0) : a.n_host;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = a.ids[i] - a.id_offset;
+    float deg = a.yaw_deg ? (float)a.yaw_deg[i]
+                          : floorf(philox_uniform(a.seed ^ 0x9E3779B97F4A7C15ull, 0u, (uint32_t)id) * 361.0f);
+    float half = (deg * (3.14159265358979323846f / 180.0f)) / 2.0f;
+    a.quat4[4ull * id] = sinf(half); a.quat4[4ull * id + 1] = 0.0f; a.quat4[4ull * id + 2] = 0.0f; a.quat4[4ull * id + 3] = cosf(half);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = a.initial_pos3[3ull * id + c];
+        a.pos3[3ull * id + c] = v;
+        if (a.base_pos3) a.base_pos3[3ull * id + c] = v;
+    }
+    for (int j = 0; j < 13; ++j) {
+        if (a.joint_pos13) a.joint_pos13[13ull * id + j] = 0.0f;
+        if (a.joint_vel13) a.joint_vel13[13ull * id + j] = 0.0f;
+    }
+    a.reset[id] = 0;                                                        // :452-453
+    a.progress[id] = 0;
+}
+
+// pre_physics_step rover.py:338-414 without the reset branch: pre-physics euler (:343), Memory.input_state x2
+// (:379-380), Ackermann (:391) and the scatter into the joint-target layout (:400-414, rover_view.py:45-46).
+__global__ void __launch_bounds__(256) pre_physics_kernel(PrePhysicsArgs a) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.E) return;
+    if (a.euler_pre) {
+        float r, p, y;
+        quat_to_euler(a.quat + 4ull * e, r, p, y);
+        a.euler_pre[3ull * e] = r; a.euler_pre[3ull * e + 1] = p; a.euler_pre[3ull * e + 2] = y;
+    }
+    float lin = a.actions[2ull * e], ang = a.actions[2ull * e + 1];
+    float l0 = a.lin_hist[3ull * e], l1 = a.lin_hist[3ull * e + 1];
+    a.lin_hist[3ull * e] = lin; a.lin_hist[3ull * e + 1] = l0; a.lin_hist[3ull * e + 2] = l1;
+    float g0 = a.ang_hist[3ull * e], g1 = a.ang_hist[3ull * e + 1];
+    a.ang_hist[3ull * e] = ang; a.ang_hist[3ull * e + 1] = g0; a.ang_hist[3ull * e + 2] = g1;
+    if (!a.pos_targets13 && !a.vel_targets13) return;
+    // Ackermann, tasks/utils/kinematics.py:13-67 (same operation order as ackermann_kernel)
+    const float wl[6][2] = {{-0.385, 0.438}, {0.385, 0.438}, {-0.447, 0.0}, {0.447, 0.0}, {-0.385, -0.411}, {0.385, -0.411}};
+    const float side[6] = {-1.0f, 1.0f, -1.0f, 1.0f, -1.0f, 1.0f};
+    float Px = copysignf(lin / ang, -ang);
+    Px = (fabsf(Px) > 0.45f) ? Px : 0.0f;
+    lin = (Px != 0.0f) ? lin : 0.0f;
+    float steer[6], vel[6];
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        float dx = Px - wl[w][0], dy = 0.0f - wl[w][1];
+        float dist = sqrtf(dx * dx + dy * dy);
+        float av = (lin != 0.0f) ? copysignf(ang, lin) : ang * side[w];
+        float mv = dist * av;
+        if (dist > 1000.0f) mv = lin;
+        vel[w] = mv / 0.2f;
+        float sa = atan2f(wl[w][1], wl[w][0] - Px);
+        if (sa < (float)(-3.14 / 2)) sa = sa + 3.14159265358979323846f;
+        if (sa > (float)(3.14 / 2)) sa = sa - 3.14159265358979323846f;
+        steer[w] = sa;
+    }
+    if (a.pos_targets13) {                      // positions [FR, RR, FL, RL] = steer[1,5,0,4] -> joints [6,8,4,7]
+        float* p = a.pos_targets13 + 13ull * e;
+        p[6] = steer[1]; p[8] = steer[5]; p[4] = steer[0]; p[7] = steer[4];
+    }
+    if (a.vel_targets13) {                      // velocities [FR,CR,RR,FL,CL,RL] = vel[1,3,5,0,2,4] -> joints [10,5,12,9,3,11]
+        float* v = a.vel_targets13 + 13ull * e;
+        v[10] = vel[1]; v[5] = vel[3]; v[12] = vel[5]; v[9] = vel[0]; v[3] = vel[2]; v[11] = vel[4];
+    }
 }
 
 // Ackermann, tasks/utils/kinematics.py:13-67
@@ -1088,11 +1183,22 @@ hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n,
     return hipGetLastError();
 }
 
-hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t* ids_work,
-                                 uint32_t n, const float* initial_pos3, float* target3, float radius, const float* draws,
-                                 int32_t max_draws, uint64_t seed, int32_t* n_draws_used, hipStream_t s) {
-    hipLaunchKernelGGL(generate_goals_kernel, dim3(1), dim3(1024), 0, s, info7, S, h, env_ids, ids_work, n, initial_pos3, target3,
-                       radius, draws, max_draws, seed, n_draws_used);
+hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t id_offset,
+                                 int64_t* ids_work, uint32_t* work2, uint32_t work_stride, uint32_t n, const int32_t* n_dev,
+                                 const float* initial_pos3, float* target3, float radius, const float* draws, int32_t max_draws,
+                                 uint64_t seed, int32_t* n_draws_used, hipStream_t s) {
+    hipLaunchKernelGGL(generate_goals_kernel, dim3(1), dim3(1024), 0, s, info7, S, h, env_ids, id_offset, ids_work, work2,
+                       work2 + work_stride, n, n_dev, initial_pos3, target3, radius, draws, max_draws, seed, n_draws_used);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset_envs(const ResetArgs& a, uint32_t n_max, hipStream_t s) {
+    hipLaunchKernelGGL(reset_envs_kernel, dim3(blocks_for(n_max, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pre_physics(const PrePhysicsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(pre_physics_kernel, dim3(blocks_for(a.E, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

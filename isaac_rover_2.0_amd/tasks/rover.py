@@ -16,6 +16,8 @@ Deviations from the reference, all deliberate and tested:
   * the done compaction (``reset_buf.nonzero()``, :356) happens on the device inside the fused step; only
     the count is read on the host (the reference's ``len()`` is the same sync).
   * ``reset_idx`` draws its yaw on the device RNG instead of Python's ``random`` (RNG streams cannot match).
+  * ``pre_physics_step`` defaults to the device-side reset orchestration (``rover_reset_envs``): same state
+    transitions as ``reset_idx`` + ``set_targets``, but the reset count never travels to the host.
 """
 from __future__ import annotations
 
@@ -61,7 +63,7 @@ class _Camera:
 
 class RoverTask(RLTask):
     def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
-                 num_envs_global=None, env_offset=0) -> None:
+                 device_reset=True, num_envs_global=None, env_offset=0) -> None:
         """``scene``: a ``synth.Scene`` (or ``assets.load_reference_assets(root)``) with the terrain / rocks KNN maps,
         stone list and heightfield the reference loads from disk (:92-94,:144,:210).  ``distribution``: optional
         (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set."""
@@ -105,6 +107,7 @@ class RoverTask(RLTask):
         self.vertical_scale = scene.vertical_scale                                        # :213
         self.heightmap = scene.heightmap.to(self._device)                                 # :210
         self._fused = bool(fused)
+        self._device_reset = bool(device_reset)
         RLTask.__init__(self, name, env)                                                  # :184
 
         dev_index = torch.device(self._device).index or 0
@@ -218,9 +221,12 @@ class RoverTask(RLTask):
     # action side + resets (rover.py:338-453)
     # ------------------------------------------------------------------------------------------------
     def pre_physics_step(self, actions, reset_yaw_deg=None) -> None:
+        """rover.py:338-414.  Default (``device_reset=True``): three launches and NO host sync —
+        ``rover_pre_physics_step`` (pre-physics euler :343, history :379-380, Ackermann + joint-target scatter
+        :391-414) and ``rover_reset_envs`` (reset_idx + set_targets for the compacted ids, count read on the device).
+        ``device_reset=False`` keeps the reference's control flow (host ``len()`` of the id list, then the methods)."""
         self.global_step += 1
         self.rover_loc = self._rover.get_world_poses()[0]
-        self._engine.quat_to_euler(self._rover.get_world_poses()[1], out=self.rover_rot)          # :343
         if self.global_step == 10:                                                               # :344-353
             self.curriculum_level = 2
             self._engine.set_curriculum_level(2)
@@ -228,15 +234,28 @@ class RoverTask(RLTask):
         if not self._compaction_fresh:
             self._engine.compact_resets(self.reset_buf, self.reset_env_ids_buf, self._n_reset)
         self._compaction_fresh = False
+        _actions = actions.to(self._device).float().contiguous()
+        self.actions_nn = torch.cat((torch.reshape(_actions, (self.num_envs, self._num_actions, 1)), self.actions_nn), 2)[:, :, 0:3]
+        rv = self._rover
+        if self._device_reset:
+            # euler_pre must see the PRE-reset orientation (:343 runs before :359), so this kernel goes first
+            self._engine.pre_physics_step(_actions, rv._quat, self.linear_velocity.tracker, self.angular_velocity.tracker,
+                                          euler_pre=self.rover_rot, pos_targets13=rv._joint_pos_targets,
+                                          vel_targets13=rv._joint_vel_targets)
+            self._engine.reset_envs(self.reset_env_ids_buf, self.initial_pos, rv._pos, rv._quat, self.reset_buf,
+                                    self.progress_buf, n_reset_dev=self._n_reset, joint_pos13=rv._joint_pos,
+                                    joint_vel13=rv._joint_vel, base_pos3=self.base_pos, yaw_deg=reset_yaw_deg,
+                                    target3=self.target_positions, radius=8.0, seed=self.global_step)
+            self._balls._pos.copy_(self.target_positions)                                        # :584 (visual only)
+            return
+        self._engine.quat_to_euler(rv.get_world_poses()[1], out=self.rover_rot)                  # :343
         n = int(self._n_reset.item())                      # the reference's len(reset_env_ids) is the same host sync
         if n > 0:
             reset_env_ids = self.reset_env_ids_buf[:n] - self._env_offset
-            self.reset_idx(reset_env_ids, yaw_deg=reset_yaw_deg)
+            self.reset_idx(reset_env_ids, yaw_deg=None if reset_yaw_deg is None else reset_yaw_deg[:n])
             self.set_targets(reset_env_ids)
-        _actions = actions.to(self._device)
         self.linear_velocity.input_state(_actions[:, 0])                                         # :379-380
         self.angular_velocity.input_state(_actions[:, 1])
-        self.actions_nn = torch.cat((torch.reshape(_actions, (self.num_envs, self._num_actions, 1)), self.actions_nn), 2)[:, :, 0:3]
         steering_angles, motor_velocities = self._engine.ackermann(_actions[:, 0].contiguous(), _actions[:, 1].contiguous())  # :391
         positions = torch.zeros((self._rover.count, 4), dtype=torch.float32, device=self._device)
         velocities = torch.zeros((self._rover.count, 6), dtype=torch.float32, device=self._device)

@@ -9,7 +9,7 @@ from conftest import assert_step_close, load_golden, scene_for, states_of
 pytestmark = pytest.mark.gpu
 
 
-def _make_task(fx, fused, level=2):
+def _make_task(fx, fused, level=2, device_reset=True):
     from isaac_rover_amd.config import SimConfig
     from isaac_rover_amd.tasks.rover import RoverTask
     from isaac_rover_amd.vec_env import VecEnv
@@ -19,7 +19,7 @@ def _make_task(fx, fused, level=2):
     cfg = SimConfig(num_envs=e, device="cuda:0")
     env = VecEnv(headless=True)
     task = RoverTask("Rover", cfg, env, scene=scene, distribution=(fx["distribution"], fx["sparse_idx"], fx["dense_idx"]),
-                     fused=fused)
+                     fused=fused, device_reset=device_reset)
     env.set_task(task, sim_params={"dt": 0.05}, spawn_positions=st["pos"].clone())
     # feed the captured sim state (the reference harness does the same on its SimpleNamespace)
     dev = task.device
@@ -63,10 +63,11 @@ def test_native_observation_layout():
     env.close()
 
 
-def test_pre_physics_step_reset_branch():
+@pytest.mark.parametrize("device_reset", [True, False])
+def test_pre_physics_step_reset_branch(device_reset):
     """rover.py:356-361,416-453,566-584: compaction order, reset bookkeeping, goal validity."""
     fx = load_golden("step_e64_p37_fp32")
-    task, env = _make_task(fx, True)
+    task, env = _make_task(fx, True, device_reset=device_reset)
     task.post_physics_step()
     reset_before = task.reset_buf.clone()
     ids = reset_before.nonzero(as_tuple=False).squeeze(-1)
@@ -96,6 +97,35 @@ def test_pre_physics_step_reset_branch():
     np.testing.assert_array_equal(task.linear_velocity.tracker[:, 0].cpu().numpy(), actions[:, 0].cpu().numpy())
     np.testing.assert_array_equal(task.linear_velocity.tracker[:, 1:].cpu().numpy(), hist_before[:, :2].cpu().numpy())
     env.close()
+
+
+def test_device_reset_equals_host_reset():
+    """The no-host-sync orchestration (rover_pre_physics_step + rover_reset_envs) and the reference-shaped control flow
+    leave identical state when fed the same yaw draws (goal draws come from the same Philox stream)."""
+    fx = load_golden("step_e64_p37_fp32")
+    states = []
+    for device_reset in (True, False):
+        task, env = _make_task(fx, True, device_reset=device_reset)
+        task.post_physics_step()
+        task.global_step = 20
+        g = torch.Generator().manual_seed(5)
+        actions = (2 * torch.rand(task.num_envs, 2, generator=g) - 1).cuda()
+        yaw = torch.randint(0, 361, (task.num_envs,), generator=g, dtype=torch.int32).cuda()
+        task.pre_physics_step(actions, reset_yaw_deg=yaw)
+        torch.cuda.synchronize()
+        pos, quat = task._rover.get_world_poses()
+        states.append(dict(pos=pos.clone(), quat=quat.clone(), joints=task._rover.get_joint_positions().clone(),
+                           target=task.target_positions.clone(), reset=task.reset_buf.clone(), progress=task.progress_buf.clone(),
+                           lin=task.linear_velocity.tracker.clone(), ang=task.angular_velocity.tracker.clone(),
+                           rot=task.rover_rot.clone(), jpt=task._rover._joint_pos_targets.clone(),
+                           jvt=task._rover._joint_vel_targets.clone(), base=task.base_pos.clone()))
+        env.close()
+    a, b = states
+    for k in a:
+        if k == "quat":
+            np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), atol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=k)
 
 
 def test_vec_env_rollout():
