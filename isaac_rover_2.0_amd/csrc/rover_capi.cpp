@@ -30,6 +30,7 @@ struct rover_ctx {
     bool have_hf = false;
     float* d_stones = nullptr;
     int32_t S = 0;
+    StoneGridDev sgrid{};
     bool have_stones = false;
     // per-step workspace
     uint32_t R8 = 0;
@@ -198,6 +199,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
+    { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); p = const_cast<uint32_t*>(c->sgrid.stone_idx); dfree(p); }
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
     dfree(c->d_bin_cursor); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec); dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
@@ -296,9 +298,50 @@ int rover_set_stones(rover_ctx* c, const float* info7, int32_t S) {
     if (!c) return ROVER_E_INVALID;
     if (S < 0 || (S > 0 && !info7)) return fail(c, ROVER_E_INVALID, "set_stones: bad arguments");
     if (int r = use_device(c)) return r;
+    std::vector<float> h((size_t)S * 7);
+    if (S) HIP_TRY(c, hipMemcpy(h.data(), info7, h.size() * sizeof(float), hipMemcpyDefault));
+    // stone-occupancy grid: 2 m cells over the stones' bounding box padded by r_max + 1.4 m (the largest threshold the
+    // task uses, rover.py:660) + margin; a cell lists the stones whose inflated disc reaches it.
+    const float cell = 2.0f, reach = 1.4f + 0.05f;
+    float x0 = 0.f, y0 = 0.f, x1 = 1.f, y1 = 1.f, rmax = 0.f;
+    bool any = false, poisoned = false;
+    for (int s = 0; s < S; ++s) {
+        float x = h[7 * s], y = h[7 * s + 1], r = h[7 * s + 6];
+        // torch.min propagates NaN (rover.py:538): one NaN stone makes nearest_rock NaN for every query, and
+        // NaN <= thr is False -> nothing ever collides.  Reproduced by leaving every cell list empty.
+        if (!(x == x) || !(y == y) || !(r == r)) { poisoned = true; continue; }
+        if (!any) { x0 = x1 = x; y0 = y1 = y; any = true; }
+        x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        rmax = r > rmax ? r : rmax;
+    }
+    const float pad = rmax + reach;
+    x0 -= pad; y0 -= pad; x1 += pad; y1 += pad;
+    int nx = (int)((x1 - x0) / cell) + 1, ny = (int)((y1 - y0) / cell) + 1;
+    if (nx < 1) nx = 1; if (ny < 1) ny = 1;
+    if ((int64_t)nx * ny > (int64_t)1 << 24) return fail(c, ROVER_E_INVALID, "set_stones: stone extent too large for the 2 m grid");
+    std::vector<std::vector<uint32_t>> lists((size_t)nx * ny);
+    for (int s = 0; s < S && any && !poisoned; ++s) {
+        float x = h[7 * s], y = h[7 * s + 1], r = h[7 * s + 6];
+        if (!(x == x) || !(y == y) || !(r == r)) continue;
+        float rr = r + reach;
+        int cx0 = (int)((x - rr - x0) / cell), cx1 = (int)((x + rr - x0) / cell);
+        int cy0 = (int)((y - rr - y0) / cell), cy1 = (int)((y + rr - y0) / cell);
+        cx0 = cx0 < 0 ? 0 : cx0; cy0 = cy0 < 0 ? 0 : cy0; cx1 = cx1 >= nx ? nx - 1 : cx1; cy1 = cy1 >= ny ? ny - 1 : cy1;
+        for (int cx = cx0; cx <= cx1; ++cx)
+            for (int cy = cy0; cy <= cy1; ++cy) lists[(size_t)cx * ny + cy].push_back((uint32_t)s);   // stone order kept
+    }
+    std::vector<uint32_t> start((size_t)nx * ny + 1, 0), idx;
+    for (size_t k = 0; k < lists.size(); ++k) { start[k + 1] = start[k] + (uint32_t)lists[k].size(); idx.insert(idx.end(), lists[k].begin(), lists[k].end()); }
+    uint32_t *d_start = nullptr, *d_idx = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_start, start.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&d_idx, (idx.size() + 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(d_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!idx.empty()) HIP_TRY(c, hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     dfree(c->d_stones);
+    { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); p = const_cast<uint32_t*>(c->sgrid.stone_idx); dfree(p); }
     HIP_TRY(c, hipMalloc((void**)&c->d_stones, ((uint64_t)S * 7 + 1) * sizeof(float)));
-    if (S) HIP_TRY(c, hipMemcpy(c->d_stones, info7, (uint64_t)S * 7 * sizeof(float), hipMemcpyDefault));
+    if (S) HIP_TRY(c, hipMemcpy(c->d_stones, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->sgrid = StoneGridDev{d_start, d_idx, x0, y0, 1.0f / cell, nx, ny};
     c->S = S;
     c->have_stones = true;
     return ROVER_OK;
@@ -481,7 +524,7 @@ int rover_shift_spawns(rover_ctx* c, float* pos3, int32_t n, int32_t max_iter, v
     if (n < 0 || (n > 0 && !pos3) || max_iter < 0) return fail(c, ROVER_E_INVALID, "shift_spawns: bad arguments");
     if (n == 0) return ROVER_OK;
     if (int r = use_device(c)) return r;
-    HIP_TRY(c, launch_shift_spawns(c->d_stones, (uint32_t)c->S, pos3, (uint32_t)n, max_iter, (hipStream_t)stream));
+    HIP_TRY(c, launch_shift_spawns(c->sgrid, c->d_stones, pos3, (uint32_t)n, max_iter, (hipStream_t)stream));
     return ROVER_OK;
 }
 
@@ -503,9 +546,9 @@ int rover_generate_goals(rover_ctx* c, const int64_t* env_ids, int32_t n, const 
         return fail(c, ROVER_E_INVALID, "generate_goals: bad arguments (n=%d, max_draws=%d)", n, max_draws);
     if (n == 0) return ROVER_OK;
     if (int r = use_device(c)) return r;
-    HIP_TRY(c, launch_generate_goals(c->d_stones, (uint32_t)c->S, c->hf, env_ids, 0, c->d_ids_work, c->d_goal_work,
-                                     (uint32_t)c->cfg.num_envs, (uint32_t)n, nullptr, initial_pos3, target3, radius, draws,
-                                     max_draws, seed, n_draws_used, (hipStream_t)stream));
+    GoalArgs g{c->d_stones, (uint32_t)c->S, c->hf, c->sgrid, env_ids, 0, (uint32_t)n, nullptr, initial_pos3, target3, radius, draws,
+               max_draws, seed, (int32_t*)c->d_goal_work, n_draws_used};
+    HIP_TRY(c, launch_generate_goals(g, (uint32_t)n, (hipStream_t)stream));
     return ROVER_OK;
 }
 
@@ -529,11 +572,12 @@ int rover_reset_envs(rover_ctx* c, const rover_reset_io* io, void* stream) {
     a.yaw_deg = io->yaw_deg; a.seed = io->seed;
     const uint32_t n_max = io->n_reset_dev ? (uint32_t)c->cfg.num_envs : (uint32_t)io->n_reset_host;
     HIP_TRY(c, launch_reset_envs(a, n_max, s));
-    if (io->target3)
-        HIP_TRY(c, launch_generate_goals(c->d_stones, (uint32_t)c->S, c->hf, io->reset_ids, (int64_t)c->cfg.env_offset,
-                                         c->d_ids_work, c->d_goal_work, (uint32_t)c->cfg.num_envs, (uint32_t)io->n_reset_host,
-                                         io->n_reset_dev, io->initial_pos3, io->target3, io->radius > 0.f ? io->radius : 8.0f,
-                                         io->draws, io->max_draws > 0 ? io->max_draws : 256, io->seed, io->n_draws_used, s));
+    if (io->target3) {
+        GoalArgs g{c->d_stones, (uint32_t)c->S, c->hf, c->sgrid, io->reset_ids, (int64_t)c->cfg.env_offset, (uint32_t)io->n_reset_host,
+                   io->n_reset_dev, io->initial_pos3, io->target3, io->radius > 0.f ? io->radius : 8.0f, io->draws,
+                   io->max_draws > 0 ? io->max_draws : 256, io->seed, (int32_t*)c->d_goal_work, io->n_draws_used};
+        HIP_TRY(c, launch_generate_goals(g, n_max, s));
+    }
     return ROVER_OK;
 }
 

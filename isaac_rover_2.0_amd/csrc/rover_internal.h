@@ -28,6 +28,14 @@ struct HeightDev {
     float hscale, vscale, shift_x, shift_y;
 };
 
+// stone-occupancy grid (built on the host at rover_set_stones): CSR lists of the stones that can matter per grid cell
+struct StoneGridDev {
+    const uint32_t* cell_start;  // [nx*ny + 1]
+    const uint32_t* stone_idx;
+    float x0, y0, inv_cell;
+    int32_t nx, ny;
+};
+
 struct PrepArgs {
     uint32_t E, P, R8;
     const float *pos, *quat, *joints, *target;
@@ -75,6 +83,16 @@ struct ResetArgs {
     uint64_t seed;
 };
 
+struct GoalArgs {
+    const float* info7; uint32_t S; HeightDev h; StoneGridDev grid;
+    const int64_t* env_ids; int64_t id_offset;
+    uint32_t n_host; const int32_t* n_dev;
+    const float* initial_pos3; float* target3; float radius;
+    const float* draws; int32_t max_draws; uint64_t seed;
+    int32_t* t_acc;              // [n] scratch: iteration at which entry i was accepted (-1: id 0 from the start)
+    int32_t* n_draws_used;
+};
+
 struct PrePhysicsArgs {
     uint32_t E;
     const float *actions, *quat;
@@ -101,12 +119,9 @@ hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint
                           int32_t* count, hipStream_t s);
 hipError_t launch_quat_to_euler(const float* q, float* eul, uint32_t n, hipStream_t s);
 hipError_t launch_clearance(const float* info7, uint32_t S, const float* xy, uint32_t n, float* out, hipStream_t s);
-hipError_t launch_shift_spawns(const float* info7, uint32_t S, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s);
+hipError_t launch_shift_spawns(const StoneGridDev& g, const float* info7, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s);
 hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n, float* out, hipStream_t s);
-hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t id_offset,
-                                 int64_t* ids_work, uint32_t* work2, uint32_t work_stride, uint32_t n, const int32_t* n_dev,
-                                 const float* initial_pos3, float* target3, float radius, const float* draws, int32_t max_draws,
-                                 uint64_t seed, int32_t* n_draws_used, hipStream_t s);
+hipError_t launch_generate_goals(const GoalArgs& a, uint32_t n_max, hipStream_t s);
 hipError_t launch_reset_envs(const ResetArgs& a, uint32_t n_max, hipStream_t s);
 hipError_t launch_pre_physics(const PrePhysicsArgs& a, hipStream_t s);
 hipError_t launch_ackermann(const float* lin, const float* ang, uint32_t n, float* steer, float* vel, hipStream_t s);

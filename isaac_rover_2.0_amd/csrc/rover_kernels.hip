@@ -504,6 +504,24 @@ __device__ __forceinline__ float clearance_tiles(const float* __restrict__ info7
     return best;
 }
 
+// Decision form of the same test, min_s(|p - stone_s| - r_s) <= thr, through the stone-occupancy grid built at
+// rover_set_stones: a grid cell lists every stone whose disc inflated by the largest threshold used (1.4 m, plus a
+// margin far above f32 rounding) touches the cell, so stones outside the list cannot satisfy the inequality and the
+// per-stone arithmetic on the listed ones is the reference's own (sqrt of the f32 sum of squares, minus r).
+__device__ __forceinline__ bool collides_grid(const StoneGridDev& g, const float* __restrict__ info7, float x, float y, float thr) {
+    float fx = (x - g.x0) * g.inv_cell, fy = (y - g.y0) * g.inv_cell;
+    if (!(fx >= 0.0f) || !(fy >= 0.0f) || !(fx < (float)g.nx) || !(fy < (float)g.ny)) return false;   // also NaN
+    uint32_t c = (uint32_t)fx * (uint32_t)g.ny + (uint32_t)fy;
+    uint32_t k0 = g.cell_start[c], k1 = g.cell_start[c + 1];
+    for (uint32_t k = k0; k < k1; ++k) {
+        const float* r = info7 + 7ull * g.stone_idx[k];
+        float dx = x - r[0], dy = y - r[1];
+        float d = sqrtf(dx * dx + dy * dy) - r[6];                          // rover.py:536-537 / :655-656
+        if (d <= thr) return true;
+    }
+    return false;
+}
+
 __global__ void __launch_bounds__(256) clearance_kernel(const float* __restrict__ info7, uint32_t S, const float* __restrict__ xy,
                                                         uint32_t n, float* __restrict__ out) {
     __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
@@ -514,27 +532,15 @@ __global__ void __launch_bounds__(256) clearance_kernel(const float* __restrict_
     if (live) out[i] = c;
 }
 
-// avoid_pos_rock_collision rover.py:649-661.  Workgroup-uniform loop: iterate while any env of the group moves.
-__global__ void __launch_bounds__(256) shift_spawns_kernel(const float* __restrict__ info7, uint32_t S, float* __restrict__ pos3,
+// avoid_pos_rock_collision rover.py:649-661: per env, x += 0.05 while the stone clearance is <= 1.4.  (The reference
+// iterates over all envs until nothing moves; per env that is this loop.)
+__global__ void __launch_bounds__(256) shift_spawns_kernel(StoneGridDev g, const float* __restrict__ info7, float* __restrict__ pos3,
                                                            uint32_t n, int32_t max_iter) {
-    __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
-    __shared__ int any_moved;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = i < n;
-    float x = live ? pos3[3ull * i] : 0.0f, y = live ? pos3[3ull * i + 1] : 0.0f;
-    bool moving = live;
-    for (int32_t it = 0; it < max_iter; ++it) {
-        if (threadIdx.x == 0) any_moved = 0;
-        float c = clearance_tiles(info7, S, x, y, moving, sx, sy, sr);     // has barriers: all threads call it
-        if (moving) {
-            if (c <= 1.4f) { x = x + 0.05f; any_moved = 1; }               // :660
-            else moving = false;
-        }
-        __syncthreads();
-        if (!any_moved) break;
-        __syncthreads();
-    }
-    if (live) pos3[3ull * i] = x;
+    if (i >= n) return;
+    float x = pos3[3ull * i], y = pos3[3ull * i + 1];
+    for (int32_t it = 0; it < max_iter && collides_grid(g, info7, x, y, 1.4f); ++it) x = x + 0.05f;   // :660
+    pos3[3ull * i] = x;
 }
 
 // get_pos_height rover.py:588-608
@@ -561,90 +567,92 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t draw, ui
     return (float)(c0 >> 8) * (1.0f / 16777216.0f);                        // [0,1) with 24 bits, like torch.rand f32
 }
 
-// generate_goals rover.py:544-549 as ONE workgroup: draw -> write -> check -> mask, with the
-// env_ids = mask*env_ids aliasing (:540): an accepted entry's id becomes 0, so from then on it re-randomises
-// env 0's goal and the loop also waits for env 0's goal to be clear.  Duplicate id-0 writers resolve "last entry
-// wins" (what a sequential index_put gives), so only the highest-index zero entry draws.  Entries that are
-// still colliding live in a compacted work list, so an iteration costs (#colliding + 1) x S distance tests.
-// n may come from device memory (n_dev: the done-compaction count) so no host sync is needed.
-__global__ void __launch_bounds__(1024) generate_goals_kernel(const float* __restrict__ info7, uint32_t S, HeightDev h,
-                                                              const int64_t* __restrict__ env_ids, int64_t id_offset,
-                                                              int64_t* __restrict__ ids_work, uint32_t* __restrict__ work_a,
-                                                              uint32_t* __restrict__ work_b, uint32_t n_host,
-                                                              const int32_t* __restrict__ n_dev,
-                                                              const float* __restrict__ initial_pos3, float* __restrict__ target3,
-                                                              float radius, const float* __restrict__ draws, int32_t max_draws,
-                                                              uint64_t seed, int32_t* __restrict__ n_draws_used) {
-    __shared__ float sx[STONE_TILE], sy[STONE_TILE], sr[STONE_TILE];
-    __shared__ int n_work, n_next, last_zero, last_zero_new, env0_bad;
+// generate_goals rover.py:544-549 (+ random_goals :554-564, check_goal_collision :533-542, goal z :581-583).
+//
+// The reference loops globally: draw goals for every listed env, test them against the stone list, and — the
+// env_ids = mask*env_ids aliasing of :540 — turn the id of every ACCEPTED entry into 0, so accepted entries keep
+// re-randomising env 0's goal and the loop also waits for env 0's goal to be clear.  Unrolled per entry this is:
+//   * entry i keeps its own first clear draw u[t_i][i] (later iterations no longer write its env);
+//   * the loop ends at the first iteration T >= max_i t_i at which env 0's goal — written by the LAST zero-id entry
+//     of that iteration ("last writer wins", what a sequential index_put gives) — is clear, or at max_i t_i when no
+//     zero-id entry exists yet.
+// goals_draw_kernel does the per-entry part in parallel over all workgroups (stones staged through LDS tiles);
+// goals_env0_kernel replays env 0's part on one workgroup.  Same draws, same results as the sequential loop
+// (oracle_generate_goals); n may come from device memory so no host sync is needed.
+__device__ __forceinline__ void goal_from_draw(float u, float radius, const float* __restrict__ initial_pos3, int64_t id,
+                                               float& x, float& y) {
+    float alpha = (float)(2 * 3.14159265358979323846) * u;                  // :556
+    float gx = radius * cosf(alpha) + 0.0f, gy = radius * sinf(alpha) + 0.0f;   // :560-561
+    x = gx + initial_pos3[3ull * id];                                       // :563-564
+    y = gy + initial_pos3[3ull * id + 1];
+}
+
+__device__ __forceinline__ float height_at(const HeightDev& h, float x, float y) {
+    uint32_t ix = cell_coord(x, h.shift_x, h.hscale, h.N0);
+    uint32_t iy = cell_coord(y, h.shift_y, h.hscale, h.N0);
+    if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
+    return h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
+}
+
+__global__ void __launch_bounds__(256) goals_draw_kernel(GoalArgs a) {
+    const uint32_t n = a.n_dev ? (uint32_t)max(*a.n_dev, 0) : a.n_host;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = a.env_ids[i] - a.id_offset;
+    if (id == 0) { a.t_acc[i] = -1; return; }                                // zero-id entry from the start
+    int32_t t = 0, t_acc = a.max_draws;
+    float x = 0.0f, y = 0.0f;
+    for (; t < a.max_draws; ++t) {
+        float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed, (uint32_t)t, i);
+        goal_from_draw(u, a.radius, a.initial_pos3, id, x, y);
+        if (!collides_grid(a.grid, a.info7, x, y, 1.0f)) { t_acc = t; break; }   // :539: redraw while nearest_rock <= 1.0
+    }
+    a.t_acc[i] = t_acc;
+    a.target3[3ull * id] = x; a.target3[3ull * id + 1] = y;
+    a.target3[3ull * id + 2] = height_at(a.h, x, y);                        // set_targets :581-583
+}
+
+__global__ void __launch_bounds__(1024) goals_env0_kernel(GoalArgs a) {
+    __shared__ int s_tmax, s_lz, s_has_zero, s_fail;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = n_dev ? (uint32_t)max(*n_dev, 0) : n_host;
-    if (n == 0) { if (tid == 0 && n_draws_used) *n_draws_used = 0; return; }
-    if (tid == 0) { n_work = 0; last_zero = -1; }
+    const uint32_t n = a.n_dev ? (uint32_t)max(*a.n_dev, 0) : a.n_host;
+    if (n == 0) { if (tid == 0 && a.n_draws_used) *a.n_draws_used = 0; return; }
+    if (tid == 0) { s_tmax = -1; s_lz = -1; s_has_zero = 0; s_fail = 0; }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += blockDim.x) {
-        int64_t id = env_ids[i] - id_offset;
-        ids_work[i] = id;
-        if (id != 0) work_a[atomicAdd(&n_work, 1)] = i;
-        else atomicMax(&last_zero, (int)i);
+        int32_t t = a.t_acc[i];
+        if (t >= a.max_draws) s_fail = 1;
+        else if (t < 0) s_has_zero = 1;
+        else atomicMax(&s_tmax, t);
     }
     __syncthreads();
-    uint32_t* work = work_a;
-    uint32_t* work_next = work_b;
-    int32_t used = 0;
-    bool failed = false;
-    const float two_pi = (float)(2 * 3.14159265358979323846);
-    while (true) {
-        if (used >= max_draws) { failed = true; break; }
-        const int nw = n_work, lz = last_zero;
-        __syncthreads();
-        for (uint32_t k = tid; k < (uint32_t)nw + 1u; k += blockDim.x) {        // random_goals :554-564
-            const bool env0_writer = (k == (uint32_t)nw);
-            if (env0_writer && lz < 0) continue;
-            const uint32_t i = env0_writer ? (uint32_t)lz : work[k];
-            const int64_t id = env0_writer ? 0 : ids_work[i];
-            float u = draws ? draws[(uint64_t)used * n + i] : philox_uniform(seed, (uint32_t)used, i);
-            float alpha = two_pi * u;
-            float x = radius * cosf(alpha) + 0.0f, y = radius * sinf(alpha) + 0.0f;
-            target3[3ull * id] = x + initial_pos3[3ull * id];
-            target3[3ull * id + 1] = y + initial_pos3[3ull * id + 1];
-        }
-        if (tid == 0) { n_next = 0; last_zero_new = -1; env0_bad = 0; }
-        __threadfence_block();
-        __syncthreads();
-        ++used;
-        for (uint32_t k0 = 0; k0 < (uint32_t)nw + 1u; k0 += blockDim.x) {       // check_goal_collision :533-542
-            const uint32_t k = k0 + tid;
-            const bool env0_check = (k == (uint32_t)nw) && lz >= 0;
-            const bool live = (k < (uint32_t)nw) || env0_check;
-            uint32_t i = 0; int64_t id = 0;
-            if (k < (uint32_t)nw) { i = work[k]; id = ids_work[i]; }
-            float x = live ? target3[3ull * id] : 0.0f, y = live ? target3[3ull * id + 1] : 0.0f;
-            float c = clearance_tiles(info7, S, x, y, live, sx, sy, sr);
-            if (live) {
-                const bool m = c <= 1.0f;
-                if (env0_check) { if (m) env0_bad = 1; }
-                else if (m) work_next[atomicAdd(&n_next, 1)] = i;
-                else { ids_work[i] = 0; atomicMax(&last_zero_new, (int)i); }
-            }
-        }
-        __syncthreads();
-        const int bad = n_next + env0_bad;
-        __syncthreads();
-        if (tid == 0) { n_work = n_next; last_zero = max(last_zero, last_zero_new); }
-        uint32_t* t = work; work = work_next; work_next = t;
-        __syncthreads();
-        if (bad == 0) break;
-    }
-    // goal z, set_targets rover.py:581-583 (over the ORIGINAL env ids)
+    if (s_fail) { if (tid == 0 && a.n_draws_used) *a.n_draws_used = -1; return; }
+    const int tmax = s_tmax;                          // -1 when every entry was a zero-id entry
+    // zero-id set before the draw of iteration max(tmax, 0): original zeros and entries accepted earlier
     for (uint32_t i = tid; i < n; i += blockDim.x) {
-        int64_t id = env_ids[i] - id_offset;
-        uint32_t ix = cell_coord(target3[3ull * id], h.shift_x, h.hscale, h.N0);
-        uint32_t iy = cell_coord(target3[3ull * id + 1], h.shift_y, h.hscale, h.N0);
-        if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
-        target3[3ull * id + 2] = h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
+        int32_t t = a.t_acc[i];
+        if (t < 0 || t < tmax) atomicMax(&s_lz, (int)i);
     }
-    if (tid == 0 && n_draws_used) *n_draws_used = failed ? -1 : used;
+    __syncthreads();
+    if (tid != 0) return;
+    int32_t t = max(tmax, 0), used = -1;
+    int lz = s_lz;
+    float x = 0.0f, y = 0.0f;
+    bool wrote = false;
+    while (t < a.max_draws) {
+        if (lz < 0) { used = t + 1; break; }          // nobody writes env 0 in this iteration: bad == 0
+        float u = a.draws ? a.draws[(uint64_t)t * n + (uint32_t)lz] : philox_uniform(a.seed, (uint32_t)t, (uint32_t)lz);
+        goal_from_draw(u, a.radius, a.initial_pos3, 0, x, y);
+        wrote = true;
+        if (!collides_grid(a.grid, a.info7, x, y, 1.0f)) { used = t + 1; break; }
+        ++t;
+        lz = (int)n - 1;                              // from iteration tmax+1 on every entry has id 0
+    }
+    if (wrote) {
+        a.target3[0] = x; a.target3[1] = y;
+        if (s_has_zero) a.target3[2] = height_at(a.h, x, y);               // env 0 was listed: set_targets :581-583
+    }
+    if (a.n_draws_used) *a.n_draws_used = used;
 }
 
 // reset_idx rover.py:416-453 for the compacted reset ids, count read from device memory (no host sync).
@@ -1173,8 +1181,8 @@ hipError_t launch_clearance(const float* info7, uint32_t S, const float* xy, uin
     return hipGetLastError();
 }
 
-hipError_t launch_shift_spawns(const float* info7, uint32_t S, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s) {
-    hipLaunchKernelGGL(shift_spawns_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, info7, S, pos3, n, max_iter);
+hipError_t launch_shift_spawns(const StoneGridDev& g, const float* info7, float* pos3, uint32_t n, int32_t max_iter, hipStream_t s) {
+    hipLaunchKernelGGL(shift_spawns_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, g, info7, pos3, n, max_iter);
     return hipGetLastError();
 }
 
@@ -1183,12 +1191,9 @@ hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n,
     return hipGetLastError();
 }
 
-hipError_t launch_generate_goals(const float* info7, uint32_t S, const HeightDev& h, const int64_t* env_ids, int64_t id_offset,
-                                 int64_t* ids_work, uint32_t* work2, uint32_t work_stride, uint32_t n, const int32_t* n_dev,
-                                 const float* initial_pos3, float* target3, float radius, const float* draws, int32_t max_draws,
-                                 uint64_t seed, int32_t* n_draws_used, hipStream_t s) {
-    hipLaunchKernelGGL(generate_goals_kernel, dim3(1), dim3(1024), 0, s, info7, S, h, env_ids, id_offset, ids_work, work2,
-                       work2 + work_stride, n, n_dev, initial_pos3, target3, radius, draws, max_draws, seed, n_draws_used);
+hipError_t launch_generate_goals(const GoalArgs& a, uint32_t n_max, hipStream_t s) {
+    hipLaunchKernelGGL(goals_draw_kernel, dim3(blocks_for(n_max, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(goals_env0_kernel, dim3(1), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 

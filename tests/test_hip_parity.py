@@ -121,6 +121,38 @@ def test_reset_path_matches_reference_golden():
     np.testing.assert_array_equal(ids_out[: int(n.item())].cpu().numpy(), fx["reset_ids"] + 5000)
 
 
+def test_generate_goals_matches_sequential_oracle_random_cases():
+    """The parallel decomposition (per-entry first clear draw + env-0 replay) against the sequential loop of
+    rover.py:544-549 as restated by the oracle, over random stone sets / id lists (with and without env 0)."""
+    from isaac_rover_amd import _lib, synth
+    from oracle import oracle as orc
+    fx = load_golden("reset_path")
+    scene = scene_for(fx)
+    e = 48
+    eng = _lib.Engine(e, device=0)
+    eng.set_scene(scene, synth.ray_distribution("9"))
+    dev = eng.device
+    rng = np.random.default_rng(123)
+    for case in range(40):
+        s_cnt = int(rng.integers(1, 40))
+        info = np.zeros((s_cnt, 7), np.float32)
+        info[:, 0:2] = rng.uniform(0, 12.8, (s_cnt, 2))
+        info[:, 6] = rng.uniform(0.05, 0.45, s_cnt)
+        eng.set_stones(info)
+        n = int(rng.integers(1, e + 1))
+        ids = np.sort(rng.choice(np.arange(0 if case % 2 else 1, e), size=min(n, e - 1), replace=False)).astype(np.int64)
+        initial = np.zeros((e, 3), np.float32)
+        initial[:, 0:2] = rng.uniform(1.0, 11.8, (e, 2))
+        draws = rng.random((64, len(ids))).astype(np.float32)
+        want, used = orc.generate_goals(info, ids, initial, draws, radius=3.0)
+        target = torch.zeros(e, 3, device=dev)
+        used_d = torch.zeros(1, dtype=torch.int32, device=dev)
+        eng.generate_goals(torch.from_numpy(ids).to(dev), torch.from_numpy(initial).to(dev), target, radius=3.0,
+                           draws=torch.from_numpy(draws).to(dev), n_draws_used=used_d)
+        assert int(used_d.item()) == used, f"case {case}: draws used {int(used_d.item())} != {used}"
+        np.testing.assert_allclose(target[:, 0:2].cpu().numpy(), want[:, 0:2], rtol=1e-6, atol=1e-5, err_msg=f"case {case}")
+
+
 def test_philox_goals_have_clearance():
     """Library RNG path: every accepted goal has clearance > 1.0 and sits `radius` from its spawn."""
     from isaac_rover_amd import _lib, synth
