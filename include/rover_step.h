@@ -192,10 +192,10 @@ ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang
                               float *velocities, void *stream);
 
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
-/* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order; 2 = rays counting-sorted by (map, cell),
- *        one wave per run of sorted rays, the cell's triangles held in registers (needs K8 <= 256); 3 = same with
- *        lane groups (several rays per wave; default when both maps share one layout).  All give bit-identical results.
- * name = "raycast_run": sorted rays per wave (variant 2) / per lane group (variant 3); default 16. */
+/* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
+ *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers
+ *        (needs K <= 256 on both maps; the default when it applies).  Both give bit-identical results.
+ * name = "raycast_run": sorted rays per wave for variant 2 (default 16). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
 
 /* ---- introspection (bench / roofline) ---------------------------------------------------------------- */

@@ -49,6 +49,7 @@ struct rover_ctx {
     uint32_t n_bins = 0;
     int variant = 0;                    // 0 = auto
     int last_variant = 1;
+    bool sorted_valid = false;
     uint32_t run = 16;
     uint64_t workspace_bytes = 0;
     bool rays_valid = false;
@@ -102,32 +103,10 @@ static void dfree(T*& p) {
     if (p) { (void)hipFree((void*)p); p = nullptr; }
 }
 
-// lane-group layout for K triangles per cell: T in {4, 8, 10} triangles per lane, L = ceil(K/T) lanes per ray,
-// G = 64/L rays per wave; pick the T with the most useful lane-slots per wave iteration.
-static void choose_layout(int32_t K, int32_t* T_out, int32_t* L_out) {
-    const int cand[3] = {4, 8, 10};
-    double best = 0.0;
-    *T_out = 0; *L_out = 0;
-    for (int t : cand) {
-        int L = (K + t - 1) / t;
-        if (L > 64) continue;
-        int G = 64 / L;
-        double eff = (double)K * G / (64.0 * t);
-        if (eff > best + 1e-9) { best = eff; *T_out = t; *L_out = L; }
-    }
-}
-
-static bool groups_ok(const rover_ctx* c) {
-    return c->map[0].T > 0 && c->map[0].T == c->map[1].T && c->map[0].L == c->map[1].L;
-}
-
 static int effective_variant(const rover_ctx* c) {
-    const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;
-    int v = c->variant;
-    if (v == 3 && !groups_ok(c)) v = 2;
-    if (v == 2 && !v2_ok) v = 1;
-    if (v == 0) v = v2_ok ? 2 : (groups_ok(c) ? 3 : 1);       // measured: 2 beats 3 at K = 200
-    return v;
+    const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
+    if (c->variant == 1 || !v2_ok) return 1;
+    return 2;
 }
 
 static int alloc_bins(rover_ctx* c) {
@@ -181,7 +160,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
-    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 3) ? x : 0; }
+    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 2) ? x : 0; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_block_cnt, ((size_t)cfg->num_envs / 256 + 2) * sizeof(uint32_t));
@@ -218,10 +197,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     if ((uint64_t)X * (uint64_t)Y > 0xffffffffull) return fail(c, ROVER_E_INVALID, "set_knn_map: X*Y exceeds 2^32 cells");
     if (int r = use_device(c)) return r;
     const uint64_t n_cells = (uint64_t)X * Y;
-    int32_t lay_T = 0, lay_L = 0;
-    choose_layout(K, &lay_T, &lay_L);
-    const int32_t slots = lay_T ? lay_T * lay_L : K;
-    const uint32_t K8 = (uint32_t)(((slots > K ? slots : K) + 7) / 8 * 8);
+    const uint32_t K8 = (uint32_t)((K + 7) / 8 * 8);
     const uint64_t bytes = n_cells * 9ull * K8 * sizeof(uint16_t);
     int32_t *d_idx = nullptr, *d_tris = nullptr;
     uint16_t *d_verts = nullptr, *d_table = nullptr;
@@ -245,7 +221,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     cleanup();
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
-    c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, lay_T, lay_L};
+    c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y};
     c->table_bytes[which] = bytes;
     c->have_map[which] = true;
     c->rays_valid = false;
@@ -374,24 +350,20 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading; p.env_rec = c->d_env_rec;
     const int variant = effective_variant(c);
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
-    if (variant >= 2) {
+    if (variant == 2) {
         p.bin_count = c->d_bin_cursor;
         p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
         HIP_TRY(c, hipMemsetAsync(c->d_bin_cursor, 0, (uint64_t)c->n_bins * sizeof(uint32_t), s));
     }
     HIP_TRY(c, launch_prep(p, s));
-    if (variant >= 2)
+    if (variant == 2)
         HIP_TRY(c, launch_bin_rays(c->d_rays, E * c->R8, c->d_bin_cursor, c->n_bins, p.rocks_bin_offset, c->d_block_sums,
                                    c->d_sorted, s));
     if (c->profiling) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
     }
-    if (variant == 3)
-        HIP_TRY(c, launch_raycast_groups(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
-                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, (uint32_t)c->map[0].T,
-                                         (uint32_t)c->map[0].L, c->run, c->d_dist_out, s));
-    else if (variant == 2)
+    if (variant == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
                                          (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->run, c->d_dist_out, s));
     else
@@ -403,6 +375,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
         ++c->prof_launches;
     }
     c->last_variant = variant;
+    c->sorted_valid = variant == 2;
     c->rays_valid = true;
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
@@ -616,9 +589,8 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
 int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
     if (!strcmp(name, "raycast_variant")) {
-        if (value < 0 || value > 3) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1, 2 or 3");
+        if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 or 2");
         c->variant = (int)value;
-        c->rays_valid = false;
         return ROVER_OK;
     }
     if (!strcmp(name, "raycast_run")) {
@@ -657,17 +629,16 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (int r = check_ready(c)) return r;
     if (!c->rays_valid) return fail(c, ROVER_E_STATE, "replay_raycast: no ray records yet (run a step first)");
     if (int r = use_device(c)) return r;
-    if (c->last_variant == 3)
-        HIP_TRY(c, launch_raycast_groups(c->d_rays, c->d_sorted, (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P),
-                                         c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8,
-                                         (uint32_t)c->map[0].T, (uint32_t)c->map[0].L, c->run, c->d_dist_out, (hipStream_t)stream));
-    else if (c->last_variant == 2)
-        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P),
-                                         c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8,
-                                         c->run, c->d_dist_out, (hipStream_t)stream));
+    int v = effective_variant(c);
+    if (v == 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
+    const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
+    hipStream_t s = (hipStream_t)stream;
+    if (v == 2)
+        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
+                                         (uint32_t)c->map[1].K8, c->run, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
-                                  (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, (hipStream_t)stream));
+                                  (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, s));
     return ROVER_OK;
 }
 

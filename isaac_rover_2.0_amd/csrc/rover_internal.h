@@ -17,9 +17,8 @@ static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
 // One re-packed KNN map: per-cell contiguous fp16 block [X*Y][9][K8]
 struct KnnDev {
     const uint16_t* table;
-    int32_t X, Y, K, K8;         // K8: row pitch of one component inside a cell block (multiple of 8, >= L*T)
+    int32_t X, Y, K, K8;         // K8: row pitch of one component inside a cell block (K rounded up to a multiple of 8)
     float cell, shift_x, shift_y;
-    int32_t T, L;                // lane-group layout of ray-cast variant 3: T triangles per lane, L lanes per ray (0 = none)
 };
 
 struct HeightDev {
@@ -108,9 +107,6 @@ hipError_t launch_bin_rays(const RayRec* rays, uint32_t n_slots, uint32_t* curso
                            uint32_t* block_sums, uint32_t* sorted, hipStream_t s);
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
                                  const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, float* out, hipStream_t s);
-hipError_t launch_raycast_groups(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
-                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t T, uint32_t L, uint32_t run, float* out,
-                                 hipStream_t s);
 hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
 hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
                               hipStream_t s);

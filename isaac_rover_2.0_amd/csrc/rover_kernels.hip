@@ -868,9 +868,11 @@ __device__ __forceinline__ Quot3 div3_ieee(f2 det, f2 nn, f2 mn, f2 kn) {
     return q;
 }
 
+// ray_casting.py:59 with the :46,:51,:56 substitutions folded in: det == fp16(-0.1) forces n = 11 and det == fp16(1.1)
+// forces m = k = 11, either of which fails n + m <= 1.1.
 __device__ __forceinline__ float accept1(float n, float m, float k, float det) {
     bool ok = (n >= RAY_NEG_EPS) && (m >= RAY_NEG_EPS) && (n + m <= RAY_ONE_EPS)
-              && (det != RAY_NEG_EPS) && (det != RAY_ONE_EPS);       // ray_casting.py:46,51,56,59
+              && (det != RAY_NEG_EPS) && (det != RAY_ONE_EPS);
     return ok ? k : RAY_MISS;
 }
 
@@ -895,6 +897,41 @@ __device__ __forceinline__ float wave_min_to_lane63(float v) {
     return v;
 }
 
+// per-lane triangle pairs of one cell: a = v2, b = v1 - a, c = v0 - a, n = b x c (ray_casting.py:34-36,40)
+template <int NP>
+struct CellRegs {
+    f2 ax[NP], ay[NP], az[NP], bx[NP], by[NP], bz[NP], cx[NP], cy[NP], cz[NP], nx[NP], ny[NP], nz[NP];
+    __device__ __forceinline__ void poison() {       // lanes past K: NaN vertex -> every test fails
+        const float qnan = __builtin_nanf("");
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            ax[p] = ay[p] = az[p] = f2{qnan, qnan};
+            bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = f2{0.0f, 0.0f};
+        }
+    }
+};
+
+// the ray-dependent part of ray_casting.py:37-59 for the lane's NP pairs; returns the lane's min distance
+template <int NP>
+__device__ __forceinline__ float cast_pairs(const CellRegs<NP>& t, f2 sx, f2 sy, f2 sz, f2 dx, f2 dy, f2 dz) {
+    float best = RAY_MISS;            // every cell holds >= 1 real triangle, so the min is <= 11 (ray_casting.py:27)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        f2 gx = sx - t.ax[p], gy = sy - t.ay[p], gz = sz - t.az[p];                                          // :37
+        f2 det = t.nx[p] * dx + t.ny[p] * dy + t.nz[p] * dz;                                                 // :41
+        f2 gcx = gy * t.cz[p] - gz * t.cy[p], gcy = gz * t.cx[p] - gx * t.cz[p], gcz = gx * t.cy[p] - gy * t.cx[p];
+        f2 nn = gcx * dx + gcy * dy + gcz * dz;                                                              // :44-45
+        f2 bgx = t.by[p] * gz - t.bz[p] * gy, bgy = t.bz[p] * gx - t.bx[p] * gz, bgz = t.bx[p] * gy - t.by[p] * gx;
+        f2 mn = bgx * dx + bgy * dy + bgz * dz;                                                              // :49-50
+        f2 kn = t.nx[p] * gx + t.ny[p] * gy + t.nz[p] * gz;                                                  // :54-55
+        Quot3 q = div3_ieee(det, nn, mn, kn);
+        float r0 = accept1(q.n.x, q.m.x, q.k.x, det.x);
+        float r1 = accept1(q.n.y, q.m.y, q.k.y, det.y);
+        best = __builtin_fminf(best, __builtin_fminf(r0, r1));       // no NaN can reach here (accept1 filters)
+    }
+    return best;
+}
+
 __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
                                                              uint32_t n_sorted, const _Float16* __restrict__ tab0,
                                                              const _Float16* __restrict__ tab1, uint32_t kp0, uint32_t kp1,
@@ -910,8 +947,8 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
     if (i >= n_sorted) return;
     const uint32_t i_end = min(i + run, n_sorted);
     uint32_t cur_cell = 0xffffffffu, cur_map = 0xffffffffu;
-    // per lane: 4 triangles as 2 pairs; a = v2, b = v1 - a, c = v0 - a, n = b x c
-    f2 ax[2], ay[2], az[2], bx[2], by[2], bz[2], cx[2], cy[2], cz[2], nx[2], ny[2], nz[2];
+    CellRegs<2> t;                    // per lane: 4 triangles as 2 packed pairs
+    t.poison();
     for (; i < i_end; ++i) {
         const uint32_t gid = __builtin_amdgcn_readfirstlane(sorted[i]);
         const float4* rp = reinterpret_cast<const float4*>(rays + gid);
@@ -919,6 +956,7 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
         const uint32_t cell = __builtin_amdgcn_readfirstlane(__float_as_uint(ra.w));
         const uint32_t map = __builtin_amdgcn_readfirstlane(__float_as_uint(rb.w)) & 1u;
         if (cell != cur_cell || map != cur_map) {
+            if (map != cur_map && cur_map != 0xffffffffu && kp0 != kp1) t.poison();   // lanes past the new map's K
             cur_cell = cell; cur_map = map;
             const uint32_t kp = map ? kp1 : kp0;
             const _Float16* base = (map ? tab1 : tab0) + (size_t)cell * 9u * kp + lane * 4u;
@@ -929,151 +967,26 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int t0 = 2 * p, t1 = 2 * p + 1;
-                    ax[p] = f2{(float)v[6][t0], (float)v[6][t1]};                                    // a = v2, :34
-                    ay[p] = f2{(float)v[7][t0], (float)v[7][t1]};
-                    az[p] = f2{(float)v[8][t0], (float)v[8][t1]};
-                    bx[p] = f2{(float)v[3][t0], (float)v[3][t1]} - ax[p];                            // b = v1 - a, :35
-                    by[p] = f2{(float)v[4][t0], (float)v[4][t1]} - ay[p];
-                    bz[p] = f2{(float)v[5][t0], (float)v[5][t1]} - az[p];
-                    cx[p] = f2{(float)v[0][t0], (float)v[0][t1]} - ax[p];                            // c = v0 - a, :36
-                    cy[p] = f2{(float)v[1][t0], (float)v[1][t1]} - ay[p];
-                    cz[p] = f2{(float)v[2][t0], (float)v[2][t1]} - az[p];
-                    nx[p] = by[p] * cz[p] - bz[p] * cy[p];                                           // b x c, :40
-                    ny[p] = bz[p] * cx[p] - bx[p] * cz[p];
-                    nz[p] = bx[p] * cy[p] - by[p] * cx[p];
-                }
-            } else {
-                const float qnan = __builtin_nanf("");
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    ax[p] = ay[p] = az[p] = f2{qnan, qnan};
-                    bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = f2{0.0f, 0.0f};
+                    t.ax[p] = f2{(float)v[6][t0], (float)v[6][t1]};
+                    t.ay[p] = f2{(float)v[7][t0], (float)v[7][t1]};
+                    t.az[p] = f2{(float)v[8][t0], (float)v[8][t1]};
+                    t.bx[p] = f2{(float)v[3][t0], (float)v[3][t1]} - t.ax[p];
+                    t.by[p] = f2{(float)v[4][t0], (float)v[4][t1]} - t.ay[p];
+                    t.bz[p] = f2{(float)v[5][t0], (float)v[5][t1]} - t.az[p];
+                    t.cx[p] = f2{(float)v[0][t0], (float)v[0][t1]} - t.ax[p];
+                    t.cy[p] = f2{(float)v[1][t0], (float)v[1][t1]} - t.ay[p];
+                    t.cz[p] = f2{(float)v[2][t0], (float)v[2][t1]} - t.az[p];
+                    t.nx[p] = t.by[p] * t.cz[p] - t.bz[p] * t.cy[p];
+                    t.ny[p] = t.bz[p] * t.cx[p] - t.bx[p] * t.cz[p];
+                    t.nz[p] = t.bx[p] * t.cy[p] - t.by[p] * t.cx[p];
                 }
             }
         }
         const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
         const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
-        float best = RAY_MISS;            // every cell holds >= 1 real triangle, so the min is <= 11 (ray_casting.py:27)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            f2 gx = sx - ax[p], gy = sy - ay[p], gz = sz - az[p];                                          // :37
-            f2 det = nx[p] * dx + ny[p] * dy + nz[p] * dz;                                                 // :41
-            f2 gcx = gy * cz[p] - gz * cy[p], gcy = gz * cx[p] - gx * cz[p], gcz = gx * cy[p] - gy * cx[p];
-            f2 nn = gcx * dx + gcy * dy + gcz * dz;                                                        // :44-45
-            f2 bgx = by[p] * gz - bz[p] * gy, bgy = bz[p] * gx - bx[p] * gz, bgz = bx[p] * gy - by[p] * gx;
-            f2 mn = bgx * dx + bgy * dy + bgz * dz;                                                        // :49-50
-            f2 kn = nx[p] * gx + ny[p] * gy + nz[p] * gz;                                                  // :54-55
-            Quot3 q = div3_ieee(det, nn, mn, kn);
-            float r0 = accept1(q.n.x, q.m.x, q.k.x, det.x);
-            float r1 = accept1(q.n.y, q.m.y, q.k.y, det.y);
-            best = __builtin_fminf(best, __builtin_fminf(r0, r1));       // no NaN can reach here (accept1 filters)
-        }
+        float best = cast_pairs<2>(t, sx, sy, sz, dx, dy, dz);
         best = wave_min_to_lane63(best);
         if (lane == 63u) out[gid] = best;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// ray cast, variant 3: lane GROUPS.  A group of L = ceil(K/T) lanes holds one cell (T triangles per lane, T even
-// -> T/2 packed pairs); G = 64 / L groups share a wave and walk G adjacent sub-runs of the sorted rays, so
-// 60 of 64 lanes work at K = 200 (T = 10, L = 20, G = 3) instead of 50.  Ray parameters are per-lane VGPRs
-// (group-uniform), the group min is a bounded tree over ds_bpermute.  Same arithmetic as variant 2.
-// ---------------------------------------------------------------------------------------------------
-template <int T>
-struct __attribute__((packed, aligned(4))) HalfT { _Float16 v[T]; };
-
-template <int T>
-__global__ void __launch_bounds__(256) raycast_groups_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
-                                                             uint32_t n_sorted, const _Float16* __restrict__ tab0,
-                                                             const _Float16* __restrict__ tab1, uint32_t kp0, uint32_t kp1,
-                                                             uint32_t L, uint32_t G, uint32_t run, uint32_t n_blocks,
-                                                             uint32_t nb8, float* __restrict__ out) {
-    constexpr int NP = T / 2;
-    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);        // XCD-aware order (speed only)
-    if (lb >= n_blocks) return;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t g = lane / L, li = lane - g * L;
-    const bool member = g < G;
-    uint32_t i = (wave * G + g) * run;
-    const uint32_t i_end = min(i + run, n_sorted);
-    // bounded-tree partners for the group min: lane li takes li+off while that stays inside the group
-    int src16 = (int)((li + 16u < L ? lane + 16u : lane) << 2), src8 = (int)((li + 8u < L ? lane + 8u : lane) << 2),
-        src4 = (int)((li + 4u < L ? lane + 4u : lane) << 2), src2 = (int)((li + 2u < L ? lane + 2u : lane) << 2),
-        src1 = (int)((li + 1u < L ? lane + 1u : lane) << 2);
-    uint32_t cur_cell = 0xffffffffu, cur_map = 0xffffffffu;
-    f2 ax[NP], ay[NP], az[NP], bx[NP], by[NP], bz[NP], cx[NP], cy[NP], cz[NP], nx[NP], ny[NP], nz[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        ax[p] = ay[p] = az[p] = f2{__builtin_nanf(""), __builtin_nanf("")};
-        bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = f2{0.0f, 0.0f};
-    }
-    // software pipeline over the group's run: slot ids two rays ahead, ray records one ray ahead
-    const float4 idle_a = make_float4(0.f, 0.f, 0.f, 0.f), idle_b = make_float4(0.f, 0.f, 1.f, 0.f);
-    uint32_t gid = (member && i < i_end) ? sorted[i] : 0u;
-    uint32_t gid_n = (member && i + 1u < i_end) ? sorted[i + 1u] : 0u;
-    float4 ra = idle_a, rb = idle_b;
-    if (member && i < i_end) { const float4* rp = reinterpret_cast<const float4*>(rays + gid); ra = rp[0]; rb = rp[1]; }
-    for (uint32_t it = 0; it < run; ++it, ++i) {
-        const bool valid = member && (i < i_end);
-        if (!__any(valid)) break;
-        // issue the next ray's loads now; they are consumed at the bottom of this iteration
-        float4 ra_n = idle_a, rb_n = idle_b;
-        if (member && i + 1u < i_end) { const float4* rp = reinterpret_cast<const float4*>(rays + gid_n); ra_n = rp[0]; rb_n = rp[1]; }
-        const uint32_t gid_nn = (member && i + 2u < i_end) ? sorted[i + 2u] : 0u;
-        const uint32_t cell = __float_as_uint(ra.w), map = __float_as_uint(rb.w) & 1u;
-        const bool need = valid && (cell != cur_cell || map != cur_map);
-        if (__any(need)) {
-            if (need) {
-                cur_cell = cell; cur_map = map;
-                const uint32_t kp = map ? kp1 : kp0;
-                const _Float16* base = (map ? tab1 : tab0) + (size_t)cell * 9u * kp + li * (uint32_t)T;
-                HalfT<T> v[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) v[q] = *reinterpret_cast<const HalfT<T>*>(base + (size_t)q * kp);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int t0 = 2 * p, t1 = 2 * p + 1;
-                    ax[p] = f2{(float)v[6].v[t0], (float)v[6].v[t1]};
-                    ay[p] = f2{(float)v[7].v[t0], (float)v[7].v[t1]};
-                    az[p] = f2{(float)v[8].v[t0], (float)v[8].v[t1]};
-                    bx[p] = f2{(float)v[3].v[t0], (float)v[3].v[t1]} - ax[p];
-                    by[p] = f2{(float)v[4].v[t0], (float)v[4].v[t1]} - ay[p];
-                    bz[p] = f2{(float)v[5].v[t0], (float)v[5].v[t1]} - az[p];
-                    cx[p] = f2{(float)v[0].v[t0], (float)v[0].v[t1]} - ax[p];
-                    cy[p] = f2{(float)v[1].v[t0], (float)v[1].v[t1]} - ay[p];
-                    cz[p] = f2{(float)v[2].v[t0], (float)v[2].v[t1]} - az[p];
-                    nx[p] = by[p] * cz[p] - bz[p] * cy[p];
-                    ny[p] = bz[p] * cx[p] - bx[p] * cz[p];
-                    nz[p] = bx[p] * cy[p] - by[p] * cx[p];
-                }
-            }
-        }
-        const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
-        const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
-        float best = RAY_MISS;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            f2 gx = sx - ax[p], gy = sy - ay[p], gz = sz - az[p];
-            f2 det = nx[p] * dx + ny[p] * dy + nz[p] * dz;
-            f2 gcx = gy * cz[p] - gz * cy[p], gcy = gz * cx[p] - gx * cz[p], gcz = gx * cy[p] - gy * cx[p];
-            f2 nn = gcx * dx + gcy * dy + gcz * dz;
-            f2 bgx = by[p] * gz - bz[p] * gy, bgy = bz[p] * gx - bx[p] * gz, bgz = bx[p] * gy - by[p] * gx;
-            f2 mn = bgx * dx + bgy * dy + bgz * dz;
-            f2 kn = nx[p] * gx + ny[p] * gy + nz[p] * gz;
-            Quot3 q = div3_ieee(det, nn, mn, kn);
-            float r0 = accept1(q.n.x, q.m.x, q.k.x, det.x);
-            float r1 = accept1(q.n.y, q.m.y, q.k.y, det.y);
-            best = __builtin_fminf(best, __builtin_fminf(r0, r1));
-        }
-        // group min -> lane li == 0 (bounded tree; partners precomputed)
-        if (L > 16u) best = __builtin_fminf(best, __int_as_float(__builtin_amdgcn_ds_bpermute(src16, __float_as_int(best))));
-        if (L > 8u) best = __builtin_fminf(best, __int_as_float(__builtin_amdgcn_ds_bpermute(src8, __float_as_int(best))));
-        if (L > 4u) best = __builtin_fminf(best, __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(best))));
-        if (L > 2u) best = __builtin_fminf(best, __int_as_float(__builtin_amdgcn_ds_bpermute(src2, __float_as_int(best))));
-        if (L > 1u) best = __builtin_fminf(best, __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(best))));
-        if (valid && li == 0u) out[gid] = best;
-        gid = gid_n; gid_n = gid_nn; ra = ra_n; rb = rb_n;
     }
 }
 
@@ -1123,26 +1036,6 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
     hipLaunchKernelGGL(raycast_binned_kernel, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted,
                        reinterpret_cast<const _Float16*>(tab0), reinterpret_cast<const _Float16*>(tab1), kp0, kp1, run,
                        n_blocks, nb8, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_raycast_groups(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
-                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t T, uint32_t L, uint32_t run, float* out,
-                                 hipStream_t s) {
-    const uint32_t G = 64u / L;
-    const uint32_t n_waves = blocks_for(n_sorted, G * run);
-    const uint32_t n_blocks = blocks_for(n_waves, 4);
-    const uint32_t nb8 = blocks_for(n_blocks, 8);
-    const _Float16* t0 = reinterpret_cast<const _Float16*>(tab0);
-    const _Float16* t1 = reinterpret_cast<const _Float16*>(tab1);
-#define ROVER_LAUNCH_T(TT)                                                                                                   \
-    hipLaunchKernelGGL(raycast_groups_kernel<TT>, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted, t0, t1, kp0, kp1, L, G, \
-                       run, n_blocks, nb8, out)
-    if (T == 4) ROVER_LAUNCH_T(4);
-    else if (T == 8) ROVER_LAUNCH_T(8);
-    else if (T == 10) ROVER_LAUNCH_T(10);
-    else return hipErrorInvalidValue;
-#undef ROVER_LAUNCH_T
     return hipGetLastError();
 }
 

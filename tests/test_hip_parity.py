@@ -62,11 +62,69 @@ def test_raycast_variants_bit_identical(dist_name, num_envs, k):
     distn = synth.ray_distribution(dist_name)
     st = synth.make_states(num_envs, 6.4, seed=21)
     ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
-    for variant in (2, 3):
+    for variant in (2,):
         for run in (1, 5, 16, 64):
             got = hip_step(make_engine(scene, distn, num_envs, variant=variant, run=run), st)
             for key in ref:
                 np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} run={run}")
+
+
+def _custom_scene(n_x, n_y, k_t, k_r, shift=(0.0, 0.0, 0.0), seed=0):
+    """Non-square maps with different K per map, cut out of a square synthetic scene."""
+    from isaac_rover_amd import synth
+    n = max(n_x, n_y)
+    base_t = synth.make_scene(n_cells=n, k=k_t, n_stones=12, seed=seed)
+    base_r = base_t if k_r == k_t else synth.make_scene(n_cells=n, k=k_r, n_stones=12, seed=seed)
+    t = synth.KnnMap(base_t.terrain.map_indices[:n_x, :n_y].contiguous(), base_t.terrain.triangles, base_t.terrain.vertices)
+    r = synth.KnnMap(base_r.rocks.map_indices[:n_x, :n_y].contiguous(), base_r.rocks.triangles, base_r.rocks.vertices)
+    return synth.Scene(terrain=t, rocks=r, stone_info_raw=base_t.stone_info_raw, heightmap=base_t.heightmap, shift=shift)
+
+
+@pytest.mark.parametrize("num_envs,n_x,n_y,k_t,k_r,dist_name,shift", [
+    (1, 40, 40, 16, 16, "9", (0.0, 0.0, 0.0)),          # a single env
+    (257, 48, 32, 16, 16, "37", (0.0, 0.0, 0.0)),       # E not a multiple of the block size, X > Y
+    (100, 32, 48, 1, 1, "9", (0.0, 0.0, 0.0)),          # K = 1, X < Y
+    (64, 40, 40, 255, 255, "9", (0.0, 0.0, 0.0)),       # K8 = 256: the widest the register-resident variants take
+    (64, 40, 40, 300, 300, "9", (0.0, 0.0, 0.0)),       # K8 > 256: falls back to the streaming variant
+    (200, 40, 40, 24, 40, "37", (0.0, 0.0, 0.0)),       # different K for terrain and rocks
+    (128, 40, 40, 16, 16, "120", (-1.3, 0.7, 0.0)),     # shifted map origin (camera.py:239-241)
+])
+def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift):
+    from hip_helpers import hip_step
+    from isaac_rover_amd import _lib, synth
+    from oracle import oracle as orc
+    scene = _custom_scene(n_x, n_y, k_t, k_r, shift)
+    distn = synth.ray_distribution(dist_name)
+    st = synth.make_states(num_envs, min(n_x, n_y) * 0.1, seed=31)
+    t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices, shift=shift[0:2])
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices, shift=shift[0:2])
+    want = orc.step(t, r, st, *distn)
+    results = []
+    for variant in (0, 1):
+        eng = _lib.Engine(num_envs, device=0)
+        eng.set_scene(scene, distn)
+        eng.set_option("raycast_variant", variant)
+        got = hip_step(eng, st)
+        assert_step_close(got, {"out_" + k: v for k, v in want.items()}, f"odd:{variant}")
+        np.testing.assert_array_equal(got["reset_ids"], np.nonzero(got["reset_buf"])[0])
+        results.append(got)
+        eng.close()
+    for k in results[0]:
+        np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+
+
+def test_nan_pose_does_not_fault():
+    """A NaN quaternion / position (the reference would raise at the cell lookup): cell 0, every ray misses."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=32, k=8, n_stones=4)
+    distn = synth.ray_distribution("9")
+    st = synth.make_states(16, 3.2, seed=1)
+    st["quat"][3] = float("nan")
+    st["pos"][5, 0] = float("nan")
+    got = hip_step(make_engine(scene, distn, 16), st)
+    assert (got["ray_dist"][[3, 5]] == 11.0).all()
+    assert np.isfinite(got["obs_buf"][[0, 1, 2, 4]]).all()
 
 
 def test_sharded_equals_whole():
