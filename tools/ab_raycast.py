@@ -9,7 +9,8 @@ from isaac_rover_amd import _lib, synth
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-ARMS = [dict(raycast_variant=2, raycast_run=r) for r in (8, 16, 32, 64)] + [dict(raycast_variant=1, raycast_run=16)]
+ARMS = [dict(raycast_variant=2, raycast_run=16), dict(raycast_variant=2, raycast_run=32), dict(raycast_variant=1, raycast_run=16)]
+FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
 distn = synth.ray_distribution("37")
 eng = _lib.Engine(E, device=0)
@@ -20,18 +21,20 @@ obs = torch.zeros(E, eng.num_observations, device="cuda")
 z64 = lambda: torch.zeros(E, dtype=torch.int64, device="cuda")
 sout = eng.make_out(obs, rew=torch.zeros(E, device="cuda"), reset=z64(), rock_collision=z64(), reset_ids=z64(),
                     n_reset=torch.zeros(1, dtype=torch.int32, device="cuda"))
-eng.set_option("raycast_variant", 2)
-eng.step(sin, sout, compact=True)          # leaves ray records + the sorted list every arm replays
 torch.cuda.synchronize()
 times = {i: [] for i in range(len(ARMS))}
 for r in range(ROUNDS + 2):
     for i, arm in enumerate(ARMS):
         for k, v in arm.items():
             eng.set_option(k, v)
+        eng.step(sin, sout, compact=True)      # (re)build this arm's ray records / bins
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
-            eng.replay_raycast()
+            if FULL_STEP:
+                eng.step(sin, sout, compact=True)
+            else:
+                eng.replay_raycast()
         b.record()
         torch.cuda.synchronize()
         if r >= 2:
