@@ -204,6 +204,7 @@ typedef struct {
     int32_t K[2], K8[2], X[2], Y[2];
     uint64_t table_bytes[2];       /* re-packed per-cell fp16 tables */
     uint64_t workspace_bytes;
+    int32_t raycast_variant;       /* the variant the next step will run (1 or 2) */
 } rover_info;
 ROVER_API int rover_get_info(const rover_ctx *ctx, rover_info *info);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -583,6 +583,7 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
         info->table_bytes[w] = c->table_bytes[w];
     }
     info->workspace_bytes = c->workspace_bytes;
+    info->raycast_variant = (c->have_map[0] && c->have_map[1]) ? effective_variant(c) : 0;
     return ROVER_OK;
 }
 
