@@ -1,0 +1,96 @@
+"""GPU (-m gpu): error behaviour of the C ABI — every misuse is refused with a negative code and a message,
+nothing faults, and contexts can be created / destroyed repeatedly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n=16):
+    from isaac_rover_amd import _lib, synth
+    scene = synth.make_scene(n_cells=32, k=8, n_stones=4)
+    eng = _lib.Engine(n, device=0)
+    eng.set_scene(scene, synth.ray_distribution("9"))
+    return eng, scene
+
+
+def test_missing_tables_are_reported():
+    from isaac_rover_amd import _lib, synth
+    eng = _lib.Engine(8, device=0)
+    dev = eng.device
+    with pytest.raises(_lib.RoverError, match="rover_set_stones"):
+        eng.clearance(torch.zeros(4, 2, device=dev))
+    with pytest.raises(_lib.RoverError, match="rover_set_heightfield"):
+        eng.sample_height(torch.zeros(4, 2, device=dev))
+    with pytest.raises(_lib.RoverError, match="set_distribution|index"):
+        eng.set_distribution(np.zeros((3, 3)), [0, 5], [])
+    with pytest.raises(_lib.RoverError, match="bad shape"):
+        eng.set_knn_map(0, np.zeros((4, 4, 2), np.int32), np.zeros((1, 3), np.int32), np.zeros((3, 3), np.float16), cell_size=0.0)
+    eng.close()
+
+
+def test_wrong_tensor_shapes_are_refused_on_the_host():
+    from isaac_rover_amd import _lib
+    eng, _ = _engine(16)
+    dev = eng.device
+    z3 = torch.zeros(16, 3, device=dev)
+    with pytest.raises(_lib.RoverError, match="quat"):
+        eng.make_in(z3, torch.zeros(16, 3, device=dev), torch.zeros(16, 13, device=dev), z3, z3, z3, z3,
+                    torch.zeros(16, dtype=torch.int64, device=dev))
+    with pytest.raises(_lib.RoverError, match="progress"):
+        eng.make_in(z3, torch.zeros(16, 4, device=dev), torch.zeros(16, 13, device=dev), z3, z3, z3, z3,
+                    torch.zeros(16, dtype=torch.int32, device=dev))
+    with pytest.raises(_lib.RoverError, match="obs"):
+        eng.make_out(torch.zeros(16, 5, device=dev))
+    with pytest.raises(_lib.RoverError, match="expected a tensor on"):
+        eng.make_in(torch.zeros(16, 3), torch.zeros(16, 4, device=dev), torch.zeros(16, 13, device=dev), z3, z3, z3, z3,
+                    torch.zeros(16, dtype=torch.int64, device=dev))
+    eng.close()
+
+
+def test_c_level_argument_checks():
+    from isaac_rover_amd import _lib
+    eng, _ = _engine(16)
+    lib = eng.lib
+    assert lib.rover_step(eng._h, None, None, 0, None) == -1
+    assert b"null struct" in lib.rover_last_error(eng._h)
+    sin, sout = _lib.StepIn(), _lib.StepOut()
+    assert lib.rover_step(eng._h, C.byref(sin), C.byref(sout), 0, None) == -1          # null pointers inside
+    assert lib.rover_set_option(eng._h, b"no_such_option", 1) == -1
+    assert lib.rover_set_option(eng._h, b"raycast_variant", 9) == -1
+    assert lib.rover_replay_raycast(eng._h, None) == -2                                   # no step yet
+    assert lib.rover_calculate_metrics(eng._h, C.byref(sin), C.byref(sout), None) == -2   # get_observations first
+    assert lib.rover_create(None, None) == -1
+    cfg = _lib.Cfg(num_envs=4, device=99)
+    h = C.c_void_p()
+    assert lib.rover_create(C.byref(cfg), C.byref(h)) == -1 and b"out of range" in lib.rover_last_error(None)
+    eng.close()
+
+
+def test_obs_row_stride_and_create_destroy_loop():
+    """obs may be a strided view (e.g. the front columns of a wider learner buffer); contexts do not leak."""
+    from hip_helpers import hip_step
+    from isaac_rover_amd import _lib, synth
+    eng, scene = _engine(16)
+    st = synth.make_states(16, 3.2, seed=3)
+    want = hip_step(eng, st)["obs_buf"]
+    dev = eng.device
+    wide = torch.full((16, eng.num_observations + 7), -7.0, device=dev)
+    d = {k: v.to(dev) for k, v in st.items()}
+    sin = eng.make_in(d["pos"], d["quat"], d["joints"], d["target"], d["lin_hist"], d["ang_hist"], d["euler_pre"], d["progress"].clone())
+    sout = eng.make_out(wide[:, : eng.num_observations], rew=torch.zeros(16, device=dev),
+                        reset=torch.zeros(16, dtype=torch.int64, device=dev),
+                        rock_collision=torch.zeros(16, dtype=torch.int64, device=dev))
+    eng.step(sin, sout)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(wide[:, : eng.num_observations].cpu().numpy(), want)
+    assert bool((wide[:, eng.num_observations:] == -7.0).all())
+    eng.close()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        e2, _ = _engine(64)
+        e2.close()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
