@@ -191,6 +191,16 @@ ROVER_API int rover_pre_physics_step(rover_ctx *ctx, const float *actions, const
 ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang, int32_t n, float *steering,
                               float *velocities, void *stream);
 
+/* ---- KNN map builder ("next" row f-3): tasks/utils/rover_utils.py:48-123 ------------------------------------ */
+/* For every cell (x, y) of an X x Y map at `res` metres per cell (cell position = (x res, y res), rover_utils.py:75-81)
+ * the K triangles whose centroid ((v0+v1+v2)/3, :68-70) is nearest in xy, ascending.  vertices [V,3] float32,
+ * triangles [T,3] int32 (host or device pointers); map_idx_out [X,Y,K] int32 is a DEVICE pointer.  Ranking is exact f32
+ * squared distance with ties broken by triangle id; the reference ranks fp16-rounded distances with torch.topk (ties
+ * unspecified), so its maps agree with this one only up to that rounding.  Synchronous (init-time tool); needs no
+ * prior set_* call.  Fails with ROVER_E_INVALID when T < K or a search ring holds more than 8192 candidates. */
+ROVER_API int rover_build_knn_map(rover_ctx *ctx, const float *vertices, int32_t V, const int32_t *triangles, int32_t T,
+                                  int32_t X, int32_t Y, float res, int32_t K, int32_t *map_idx_out);
+
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers

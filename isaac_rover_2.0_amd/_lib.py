@@ -97,6 +97,7 @@ SYMBOLS = {
     "rover_ackermann": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "rover_replay_raycast": (C.c_int, [_P, _P]),
+    "rover_build_knn_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "rover_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
     "rover_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
@@ -315,6 +316,17 @@ class Engine:
         out = torch.empty(n, 3, device=self.device) if out is None else out
         self._chk(out, (n, 3), torch.float32, "euler")
         self._check(self.lib.rover_quat_to_euler(self._h, _ptr(quat), _ptr(out), n, _stream()), "rover_quat_to_euler")
+        return out
+
+    def build_knn_map(self, vertices, triangles, n_x, n_y, res=0.1, k=200):
+        """rover_utils.py:48-123 on the GPU: -> map_indices [X, Y, K] int32 (device tensor), nearest first."""
+        v = _host(vertices, np.float32)
+        t = _host(triangles, np.int32)
+        if v.ndim != 2 or v.shape[1] != 3 or t.ndim != 2 or t.shape[1] != 3:
+            raise RoverError("build_knn_map: expected vertices [V,3] and triangles [T,3]")
+        out = torch.empty(int(n_x), int(n_y), int(k), dtype=torch.int32, device=self.device)
+        self._check(self.lib.rover_build_knn_map(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], int(n_x), int(n_y),
+                                                 float(res), int(k), _ptr(out)), "rover_build_knn_map")
         return out
 
     def set_option(self, name, value):

@@ -54,3 +54,75 @@ def read_stone_info(path: str, device="cpu") -> torch.Tensor:
     """utils/terrain_utils/terrain_utils.py:416-424: append radius = max(extent_x, extent_y) / 4 -> [S,7] f32."""
     from .synth import read_stone_info_array
     return torch.from_numpy(read_stone_info_array(np.load(path))).to(device)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mesh ingestion + KNN map building ("next" row f-3): what rover_utils.py does with open3d / pymeshlab
+# ---------------------------------------------------------------------------------------------------------
+_PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4",
+              "double": "f8", "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4",
+              "float32": "f4", "float64": "f8"}
+
+
+def load_ply(path: str):
+    """Minimal PLY reader (ascii / binary_little_endian, triangle faces): -> (vertices [V,3] float32, faces [T,3] int32).
+    Stands in for ``o3d.io.read_triangle_mesh`` (rover_utils.py:63-66) and ``pymeshlab`` (:187-195)."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] == "comment":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append([tok[1], int(tok[2]), []])
+            elif tok[0] == "property":
+                elements[-1][2].append(tok[1:])
+            elif tok[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian"):
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+        verts = faces = None
+        for name, count, props in elements:
+            is_list = any(p[0] == "list" for p in props)
+            if fmt == "ascii":
+                rows = [f.readline().split() for _ in range(count)]
+                if name == "vertex":
+                    cols = [p[-1] for p in props]
+                    ix = [cols.index(c) for c in ("x", "y", "z")]
+                    verts = np.asarray([[float(r[i]) for i in ix] for r in rows], dtype=np.float32)
+                elif name == "face":
+                    if any(int(r[0]) != 3 for r in rows):
+                        raise ValueError(f"{path}: only triangle faces are supported")
+                    faces = np.asarray([[int(v) for v in r[1:4]] for r in rows], dtype=np.int32)
+            else:
+                if not is_list:
+                    dt = np.dtype([(p[-1], "<" + _PLY_TYPES[p[0]]) for p in props])
+                    data = np.frombuffer(f.read(dt.itemsize * count), dtype=dt, count=count)
+                    if name == "vertex":
+                        verts = np.stack([data["x"], data["y"], data["z"]], axis=1).astype(np.float32)
+                else:
+                    p = props[0]
+                    dt = np.dtype([("n", "<" + _PLY_TYPES[p[1]]), ("v", "<" + _PLY_TYPES[p[2]], (3,))])
+                    data = np.frombuffer(f.read(dt.itemsize * count), dtype=dt, count=count)
+                    if (data["n"] != 3).any():
+                        raise ValueError(f"{path}: only triangle faces are supported")
+                    if name == "face":
+                        faces = data["v"].astype(np.int32)
+        if verts is None or faces is None:
+            raise ValueError(f"{path}: needs a vertex and a face element")
+        return verts, faces
+
+
+def build_knn_map(engine, vertices, triangles, n_cells: int = 600, res: float = 0.1, k: int = 200) -> KnnMap:
+    """``_get_knn_triangles`` (rover_utils.py:52-123) on the GPU: K nearest triangle centroids per map cell, returned in
+    the in-memory form of one ``knn_*`` directory (vertices rounded to fp16 like :113)."""
+    idx = engine.build_knn_map(vertices, triangles, n_cells, n_cells, res, k)
+    return KnnMap(idx.cpu(), torch.as_tensor(np.asarray(triangles), dtype=torch.int32),
+                  torch.as_tensor(np.asarray(vertices), dtype=torch.float32).to(torch.float16), res)

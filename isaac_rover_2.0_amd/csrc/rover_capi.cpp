@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -584,6 +585,71 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
     }
     info->workspace_bytes = c->workspace_bytes;
     info->raycast_variant = (c->have_map[0] && c->have_map[1]) ? effective_variant(c) : 0;
+    return ROVER_OK;
+}
+
+int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const int32_t* triangles, int32_t T, int32_t X, int32_t Y,
+                        float res, int32_t K, int32_t* map_idx_out) {
+    if (!c) return ROVER_E_INVALID;
+    if (!vertices || !triangles || !map_idx_out || V <= 0 || T <= 0 || X <= 0 || Y <= 0 || K <= 0 || !(res > 0.0f))
+        return fail(c, ROVER_E_INVALID, "build_knn_map: bad arguments");
+    if (T < K) return fail(c, ROVER_E_INVALID, "build_knn_map: the mesh has %d triangles, fewer than K=%d", T, K);
+    if (K > 4096) return fail(c, ROVER_E_INVALID, "build_knn_map: K=%d exceeds the builder's limit of 4096", K);
+    if (int r = use_device(c)) return r;
+    float *d_v = nullptr, *d_cx = nullptr, *d_cy = nullptr;
+    int32_t *d_t = nullptr, *d_over = nullptr;
+    uint32_t *d_cur = nullptr, *d_items = nullptr, *d_bs = nullptr;
+    auto cleanup = [&]() { dfree(d_v); dfree(d_cx); dfree(d_cy); dfree(d_t); dfree(d_over); dfree(d_cur); dfree(d_items); dfree(d_bs); };
+#define KNN_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) { cleanup(); return fail(c, ROVER_E_HIP, "build_knn_map: %s: %s", #expr, hipGetErrorString(e__)); } \
+    } while (0)
+    KNN_TRY(hipMalloc((void**)&d_v, (size_t)V * 3 * sizeof(float)));
+    KNN_TRY(hipMalloc((void**)&d_t, (size_t)T * 3 * sizeof(int32_t)));
+    KNN_TRY(hipMalloc((void**)&d_cx, (size_t)T * sizeof(float)));
+    KNN_TRY(hipMalloc((void**)&d_cy, (size_t)T * sizeof(float)));
+    KNN_TRY(hipMalloc((void**)&d_items, (size_t)T * sizeof(uint32_t)));
+    KNN_TRY(hipMalloc((void**)&d_over, sizeof(int32_t)));
+    KNN_TRY(hipMalloc((void**)&d_bs, 8192 * sizeof(uint32_t)));
+    KNN_TRY(hipMemcpy(d_v, vertices, (size_t)V * 3 * sizeof(float), hipMemcpyDefault));
+    KNN_TRY(hipMemcpy(d_t, triangles, (size_t)T * 3 * sizeof(int32_t), hipMemcpyDefault));
+    KNN_TRY(hipMemset(d_over, 0, sizeof(int32_t)));
+    KNN_TRY(launch_knn_centroids(d_v, d_t, (uint32_t)T, (uint32_t)V, d_cx, d_cy, nullptr));
+    // bucket grid over the centroids' bounding box; bucket edge ~ the radius that holds K/4 centroids at mean density
+    std::vector<float> hx((size_t)T), hy((size_t)T);
+    KNN_TRY(hipMemcpy(hx.data(), d_cx, (size_t)T * sizeof(float), hipMemcpyDeviceToHost));
+    KNN_TRY(hipMemcpy(hy.data(), d_cy, (size_t)T * sizeof(float), hipMemcpyDeviceToHost));
+    float x0 = hx[0], x1 = hx[0], y0 = hy[0], y1 = hy[0];
+    for (int32_t t = 0; t < T; ++t) {
+        if (hx[t] == hx[t]) { x0 = hx[t] < x0 ? hx[t] : x0; x1 = hx[t] > x1 ? hx[t] : x1; }
+        if (hy[t] == hy[t]) { y0 = hy[t] < y0 ? hy[t] : y0; y1 = hy[t] > y1 ? hy[t] : y1; }
+    }
+    const double area = ((double)x1 - x0 + 1e-6) * ((double)y1 - y0 + 1e-6);
+    double gsz = std::sqrt(area * (double)K / (4.0 * (double)T));
+    if (gsz < (double)res) gsz = (double)res;
+    uint32_t nbx = (uint32_t)(((double)x1 - x0) / gsz) + 1, nby = (uint32_t)(((double)y1 - y0) / gsz) + 1;
+    while ((uint64_t)nbx * nby > (1u << 22)) { gsz *= 2.0; nbx = (uint32_t)(((double)x1 - x0) / gsz) + 1; nby = (uint32_t)(((double)y1 - y0) / gsz) + 1; }
+    const float g = (float)gsz, inv_g = 1.0f / g;
+    const uint32_t nb = nbx * nby;
+    KNN_TRY(hipMalloc((void**)&d_cur, ((size_t)nb + 1) * sizeof(uint32_t)));
+    KNN_TRY(hipMemset(d_cur, 0, ((size_t)nb + 1) * sizeof(uint32_t)));
+    KNN_TRY(launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 1, nullptr));
+    KNN_TRY(launch_scan_exclusive(d_cur, nb + 1, d_bs, nullptr));
+    uint32_t* d_start = nullptr;
+    KNN_TRY(hipMalloc((void**)&d_start, ((size_t)nb + 1) * sizeof(uint32_t)));
+    hipError_t e2 = hipMemcpy(d_start, d_cur, ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+    if (e2 == hipSuccess) e2 = launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 0, nullptr);
+    if (e2 == hipSuccess) e2 = launch_knn_select(d_cx, d_cy, d_start, d_items, x0, y0, g, nbx, nby, (uint32_t)X, (uint32_t)Y, res,
+                                                 (uint32_t)K, map_idx_out, d_over, nullptr);
+    if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+    int32_t over = 0;
+    if (e2 == hipSuccess) e2 = hipMemcpy(&over, d_over, sizeof over, hipMemcpyDeviceToHost);
+    dfree(d_start);
+    cleanup();
+#undef KNN_TRY
+    if (e2 != hipSuccess) return fail(c, ROVER_E_HIP, "build_knn_map: %s", hipGetErrorString(e2));
+    if (over) return fail(c, ROVER_E_INVALID, "build_knn_map: a search ring held more than 8192 candidate triangles (mesh too dense for K=%d)", K);
     return ROVER_OK;
 }
 

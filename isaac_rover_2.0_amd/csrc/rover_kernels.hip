@@ -991,6 +991,111 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// KNN map builder ("next" row f-3): for every map cell the K triangles whose centroid is nearest in xy
+// (tasks/utils/rover_utils.py:52-118, which ranks ALL centroids per cell with a python double loop of topk).
+// Here: centroids are bucketed on a uniform grid; one workgroup per map cell gathers buckets ring by ring into
+// LDS as 64-bit keys (f32 squared distance bits << 32 | triangle id), bitonic-sorts them and stops as soon as the
+// K-th distance is inside the searched radius.  Ranking: exact f32 squared distance, ties by triangle id (the
+// reference ranks fp16-rounded distances with an unspecified tie order, so it cannot be matched bit for bit).
+// ---------------------------------------------------------------------------------------------------
+#define KNN_CAP 8192
+
+__global__ void __launch_bounds__(256) knn_centroid_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tris,
+                                                           uint32_t T, uint32_t V, float* __restrict__ cx, float* __restrict__ cy) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t a = (uint32_t)tris[3ull * t], b = (uint32_t)tris[3ull * t + 1], c = (uint32_t)tris[3ull * t + 2];
+    a = a < V ? a : 0u; b = b < V ? b : 0u; c = c < V ? c : 0u;
+    cx[t] = (verts[3ull * a] + verts[3ull * b] + verts[3ull * c]) / 3.0f;             // rover_utils.py:68-70
+    cy[t] = (verts[3ull * a + 1] + verts[3ull * b + 1] + verts[3ull * c + 1]) / 3.0f;
+}
+
+__device__ __forceinline__ uint32_t knn_bucket(float v, float origin, float inv_g, uint32_t n) {
+    float f = (v - origin) * inv_g;
+    if (!(f > 0.0f)) return 0u;
+    uint32_t b = (uint32_t)f;
+    return b < n ? b : n - 1u;
+}
+
+// pass 1 (count = 1): histogram of bucket ids; pass 2 (count = 0): fill ids at cursor positions
+__global__ void __launch_bounds__(256) knn_bucket_kernel(const float* __restrict__ cx, const float* __restrict__ cy, uint32_t T,
+                                                         float ox, float oy, float inv_g, uint32_t nbx, uint32_t nby,
+                                                         uint32_t* __restrict__ cursor, uint32_t* __restrict__ items, int count) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t b = knn_bucket(cx[t], ox, inv_g, nbx) * nby + knn_bucket(cy[t], oy, inv_g, nby);
+    uint32_t pos = atomicAdd(cursor + b, 1u);
+    if (!count) items[pos] = t;
+}
+
+__global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict__ cx, const float* __restrict__ cy,
+                                                         const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ items,
+                                                         float ox, float oy, float g, uint32_t nbx, uint32_t nby, uint32_t X,
+                                                         uint32_t Y, float res, uint32_t K, int32_t* __restrict__ out,
+                                                         int32_t* __restrict__ overflow) {
+    __shared__ unsigned long long keys[KNN_CAP];
+    __shared__ uint32_t count;
+    const uint32_t cell = blockIdx.x, x = cell / Y, y = cell % Y, tid = threadIdx.x;
+    const float px = (float)x * res, py = (float)y * res;                   // rover_utils.py:75-81: cell (x, y) sits at (x res, y res)
+    const float inv_g = 1.0f / g;
+    const int bx = (int)knn_bucket(px, ox, inv_g, nbx), by = (int)knn_bucket(py, oy, inv_g, nby);
+    const int rmax = (int)max(nbx, nby);
+    if (tid == 0) count = 0;
+    __syncthreads();
+    for (int r = 0; r <= rmax; ++r) {
+        // append the buckets at Chebyshev distance r (the square ring), one bucket per thread at a time
+        const int side = 2 * r + 1, nring = r == 0 ? 1 : 8 * r;
+        for (int q = (int)tid; q < nring; q += 256) {
+            int i, j;
+            if (r == 0) { i = bx; j = by; }
+            else if (q < side) { i = bx - r; j = by - r + q; }                         // left column
+            else if (q < 2 * side) { i = bx + r; j = by - r + (q - side); }            // right column
+            else if (q < 2 * side + (side - 2)) { i = bx - r + 1 + (q - 2 * side); j = by - r; }     // bottom row
+            else { i = bx - r + 1 + (q - 2 * side - (side - 2)); j = by + r; }                     // top row
+            if (i < 0 || j < 0 || i >= (int)nbx || j >= (int)nby) continue;
+            const uint32_t b = (uint32_t)i * nby + (uint32_t)j, s0 = bucket_start[b], s1 = bucket_start[b + 1];
+            if (s1 == s0) continue;
+            uint32_t base = atomicAdd(&count, s1 - s0);
+            for (uint32_t k = s0; k < s1; ++k, ++base) {
+                if (base >= KNN_CAP) break;
+                const uint32_t t = items[k];
+                const float dx = cx[t] - px, dy = cy[t] - py;
+                const float d2 = dx * dx + dy * dy;
+                keys[base] = ((unsigned long long)__float_as_uint(d2) << 32) | t;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = count;
+        if (n > KNN_CAP) { if (tid == 0) *overflow = 1; return; }
+        const bool covers_all = (bx - r <= 0) && (by - r <= 0) && (bx + r >= (int)nbx - 1) && (by + r >= (int)nby - 1);
+        if (n >= K || covers_all) {
+            uint32_t m = 1; while (m < n) m <<= 1;                       // bitonic sort of keys[0..m), padded with +inf keys
+            for (uint32_t k = n + tid; k < m; k += 256) keys[k] = ~0ull;
+            __syncthreads();
+            for (uint32_t len = 2; len <= m; len <<= 1) {
+                for (uint32_t stride = len >> 1; stride > 0; stride >>= 1) {
+                    for (uint32_t k = tid; k < (m >> 1); k += 256) {
+                        const uint32_t lo = ((k / stride) * stride << 1) + (k % stride), hi = lo + stride;
+                        const bool up = ((lo & len) == 0);
+                        const unsigned long long a = keys[lo], b = keys[hi];
+                        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            }
+            // every triangle not gathered yet is at least r*g away (its bucket is > r rings out)
+            const float reach = (float)r * g;
+            const float kth = n >= K ? __uint_as_float((uint32_t)(keys[K - 1] >> 32)) : __builtin_inff();
+            if (covers_all || kth <= reach * reach) {
+                for (uint32_t k = tid; k < K; k += 256) out[(uint64_t)cell * K + k] = k < n ? (int32_t)(uint32_t)keys[k] : 0;
+                return;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
@@ -1036,6 +1141,35 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
     hipLaunchKernelGGL(raycast_binned_kernel, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted,
                        reinterpret_cast<const _Float16*>(tab0), reinterpret_cast<const _Float16*>(tab1), kp0, kp1, run,
                        n_blocks, nb8, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, float* cx, float* cy, hipStream_t s) {
+    hipLaunchKernelGGL(knn_centroid_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, verts, tris, T, V, cx, cy);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_bucket(const float* cx, const float* cy, uint32_t T, float ox, float oy, float inv_g, uint32_t nbx, uint32_t nby,
+                             uint32_t* cursor, uint32_t* items, int count, hipStream_t s) {
+    hipLaunchKernelGGL(knn_bucket_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, cx, cy, T, ox, oy, inv_g, nbx, nby, cursor, items,
+                       count);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_exclusive(uint32_t* data, uint32_t n, uint32_t* block_sums, hipStream_t s) {
+    const uint32_t nb = blocks_for(n, SCAN_TILE);
+    if (nb > 1024u * SCAN_ITEMS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, data, n, block_sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, data, n, block_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_select(const float* cx, const float* cy, const uint32_t* bucket_start, const uint32_t* items, float ox, float oy,
+                             float g, uint32_t nbx, uint32_t nby, uint32_t X, uint32_t Y, float res, uint32_t K, int32_t* out,
+                             int32_t* overflow, hipStream_t s) {
+    hipLaunchKernelGGL(knn_select_kernel, dim3(X * Y), dim3(256), 0, s, cx, cy, bucket_start, items, ox, oy, g, nbx, nby, X, Y, res, K,
+                       out, overflow);
     return hipGetLastError();
 }
 

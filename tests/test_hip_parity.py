@@ -256,3 +256,62 @@ def test_errors_are_loud():
         eng.step(sin, sout)
     with pytest.raises(_lib.RoverError):
         _lib.Engine(0, device=0)
+
+
+def _knn_brute_force(verts, tris, n_x, n_y, res, k):
+    """numpy restatement of rover_utils.py:68-108 with the builder's stated ranking (f32 squared distance, ties by id)."""
+    v = verts.astype(np.float32)
+    cx = (v[tris[:, 0], 0] + v[tris[:, 1], 0] + v[tris[:, 2], 0]) / np.float32(3)
+    cy = (v[tris[:, 0], 1] + v[tris[:, 1], 1] + v[tris[:, 2], 1]) / np.float32(3)
+    out = np.zeros((n_x, n_y, k), np.int32)
+    ids = np.arange(len(tris), dtype=np.uint64)
+    for x in range(n_x):
+        px = np.float32(x) * np.float32(res)
+        dx = cx - px
+        for y in range(n_y):
+            dy = cy - np.float32(y) * np.float32(res)
+            d2 = (dx * dx + dy * dy).astype(np.float32)
+            key = (d2.view(np.uint32).astype(np.uint64) << np.uint64(32)) | ids
+            out[x, y] = np.sort(key)[:k].astype(np.uint64) & np.uint64(0xffffffff)
+    return out
+
+
+@pytest.mark.parametrize("n_tri,n_x,n_y,k,res,extent", [(3000, 24, 20, 16, 0.1, 2.4), (900, 16, 16, 200, 0.1, 1.5),
+                                                       (5000, 30, 30, 7, 0.05, 3.0), (64, 8, 8, 64, 0.1, 0.8)])
+def test_knn_builder_matches_brute_force(n_tri, n_x, n_y, k, res, extent):
+    """rover_build_knn_map (bucketed ring search + LDS bitonic sort) against brute force over every centroid, on an
+    irregular random triangle soup whose bounding box is larger AND smaller than the map in different cases."""
+    from isaac_rover_amd import _lib
+    rng = np.random.default_rng(n_tri)
+    centers = rng.uniform(-0.3, extent, (n_tri, 1, 2))
+    verts = np.concatenate([centers + rng.normal(0, 0.05, (n_tri, 3, 2)), rng.normal(0, 0.1, (n_tri, 3, 1))], axis=2)
+    verts = verts.reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * n_tri, dtype=np.int32).reshape(n_tri, 3)
+    eng = _lib.Engine(8, device=0)
+    got = eng.build_knn_map(verts, tris, n_x, n_y, res, k).cpu().numpy()
+    want = _knn_brute_force(verts, tris, n_x, n_y, res, k)
+    np.testing.assert_array_equal(got, want)
+    with pytest.raises(_lib.RoverError, match="fewer than K"):
+        eng.build_knn_map(verts[:30], tris[:10], 4, 4, res, 11)
+    eng.close()
+
+
+def test_built_map_drives_the_step():
+    """Mesh -> rover_build_knn_map -> set_knn_map -> step: same result as the oracle fed the same built map."""
+    from hip_helpers import hip_step
+    from isaac_rover_amd import _lib, assets, synth
+    from oracle import oracle as orc
+    verts, tris, _ = synth.grid_mesh(41, seed=3)
+    eng = _lib.Engine(64, device=0)
+    terrain = assets.build_knn_map(eng, verts, tris, n_cells=40, res=0.1, k=20)
+    scene = synth.make_scene(n_cells=40, k=20, n_stones=6, seed=3)
+    scene.terrain = terrain
+    distn = synth.ray_distribution("37")
+    eng.set_scene(scene, distn)
+    st = synth.make_states(64, 4.0, seed=2)
+    got = hip_step(eng, st)
+    t = orc.KnnMap(terrain.map_indices, terrain.triangles, terrain.vertices)
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
+    want = orc.step(t, r, st, *distn)
+    assert_step_close(got, {"out_" + k: v for k, v in want.items()}, "built-map")
+    assert (got["ray_dist"] < 11.0).mean() > 0.5

@@ -46,6 +46,28 @@ def test_asset_round_trip(tmp_path):
     np.testing.assert_allclose(info[:, 6].numpy(), np.maximum(scene.stone_info_raw[:, 3], scene.stone_info_raw[:, 4]) / 4, rtol=1e-6)
 
 
+def test_ply_reader_ascii_and_binary(tmp_path):
+    from isaac_rover_amd import assets
+    v = np.array([[0, 0, 0], [1, 0, 0.5], [0, 1, 0.25], [1, 1, -0.5]], np.float32)
+    f = np.array([[0, 1, 2], [1, 3, 2]], np.int32)
+    a = tmp_path / "a.ply"
+    a.write_text("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 4\nproperty float x\nproperty float y\n"
+                 "property float z\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n"
+                 + "".join(f"{x} {y} {z}\n" for x, y, z in v) + "".join(f"3 {i} {j} {k}\n" for i, j, k in f))
+    b = tmp_path / "b.ply"
+    with open(b, "wb") as fh:
+        fh.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty double x\nproperty double y\nproperty double z\n"
+                 b"element face 2\nproperty list uchar uint vertex_indices\nend_header\n")
+        fh.write(v.astype("<f8").tobytes())
+        for tri in f:
+            fh.write(np.uint8(3).tobytes() + tri.astype("<u4").tobytes())
+    for path in (a, b):
+        vv, ff = assets.load_ply(str(path))
+        np.testing.assert_array_equal(vv, v)
+        np.testing.assert_array_equal(ff, f)
+        assert vv.dtype == np.float32 and ff.dtype == np.int32
+
+
 def test_knn_map_is_exact_nearest():
     """synth's windowed integer KNN equals brute force over all triangle centroids (rover_utils.py:68-108)."""
     from isaac_rover_amd import synth
