@@ -30,7 +30,8 @@ def scene_for(fixture):
     import torch
     from isaac_rover_amd import synth
 
-    kw = eval(str(fixture["scene_kw"]))  # repr of a plain dict of ints written by oracle/gen_golden.py
+    import ast
+    kw = ast.literal_eval(str(fixture["scene_kw"]))  # repr of a plain dict of ints written by oracle/gen_golden.py
     key = tuple(sorted(kw.items()))
     if key not in _scene_cache:
         scene = synth.make_scene(**kw)
