@@ -211,6 +211,29 @@ def test_generate_goals_matches_sequential_oracle_random_cases():
         np.testing.assert_allclose(target[:, 0:2].cpu().numpy(), want[:, 0:2], rtol=1e-6, atol=1e-5, err_msg=f"case {case}")
 
 
+def test_reset_envs_with_zero_resets_is_a_no_op():
+    """Empty input: no env flagged done -> nothing moves, no goal is redrawn (count read from device memory)."""
+    from isaac_rover_amd import _lib, synth
+    fx = load_golden("reset_path")
+    scene = scene_for(fx)
+    e = 32
+    eng = _lib.Engine(e, device=0)
+    eng.set_scene(scene, synth.ray_distribution("9"))
+    dev = eng.device
+    pos = torch.rand(e, 3, device=dev); quat = torch.rand(e, 4, device=dev); tgt = torch.rand(e, 3, device=dev)
+    before = (pos.clone(), quat.clone(), tgt.clone())
+    reset = torch.zeros(e, dtype=torch.int64, device=dev); progress = torch.full((e,), 7, dtype=torch.int64, device=dev)
+    ids = torch.zeros(e, dtype=torch.int64, device=dev); n = torch.zeros(1, dtype=torch.int32, device=dev)
+    used = torch.full((1,), -5, dtype=torch.int32, device=dev)
+    eng.compact_resets(reset, ids, n)
+    eng.reset_envs(ids, torch.zeros(e, 3, device=dev), pos, quat, reset, progress, n_reset_dev=n, target3=tgt, n_draws_used=used)
+    torch.cuda.synchronize()
+    assert int(n.item()) == 0 and int(used.item()) == 0
+    for a, b in zip(before, (pos, quat, tgt)):
+        assert torch.equal(a, b)
+    assert bool((progress == 7).all())
+
+
 def test_philox_goals_have_clearance():
     """Library RNG path: every accepted goal has clearance > 1.0 and sits `radius` from its spawn."""
     from isaac_rover_amd import _lib, synth
