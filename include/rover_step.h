@@ -201,6 +201,19 @@ ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang
 ROVER_API int rover_build_knn_map(rover_ctx *ctx, const float *vertices, int32_t V, const int32_t *triangles, int32_t T,
                                   int32_t X, int32_t Y, float res, int32_t K, int32_t *map_idx_out);
 
+/* ---- policy-side consumer of the obs layout ("next" row f-4): learning/model.py:105-121 Layer = Linear + activation --- */
+#define ROVER_ACT_NONE      0
+#define ROVER_ACT_LEAKYRELU 1   /* nn.LeakyReLU(), slope 0.01 (cfg/trainSKRL/RoverPPOSKRL.yaml:5,9) */
+#define ROVER_ACT_TANH      2   /* the actor head, model.py:182 */
+#define ROVER_ACT_RELU      3
+#define ROVER_ACT_ELU       4
+/* y[:, 0:N] = act(x[:, 0:K] @ weight^T + bias); weight [N][K] (torch nn.Linear layout), bias [N] or NULL, N <= 256.
+ * x / y are addressed as (pointer, row stride in floats), so a layer can read an obs slice (model.py:186-187) and write
+ * into a column block of the concat buffer (:191-192) without copies.  f32-input MFMA, fp32 accumulate. */
+ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_stride, int32_t M, int32_t K,
+                                   const float *weight, const float *bias, int32_t N, int32_t activation, float *y,
+                                   int64_t y_stride, void *stream);
+
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers

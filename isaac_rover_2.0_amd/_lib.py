@@ -98,6 +98,7 @@ SYMBOLS = {
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "rover_replay_raycast": (C.c_int, [_P, _P]),
     "rover_build_knn_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
+    "rover_linear_forward": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "rover_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
     "rover_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
@@ -108,7 +109,7 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_internal.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_mlp.hip", "rover_internal.h", "build.sh")]
     srcs.append(os.path.join(os.path.dirname(_CSRC), "..", "include", "rover_step.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -327,6 +328,24 @@ class Engine:
         out = torch.empty(int(n_x), int(n_y), int(k), dtype=torch.int32, device=self.device)
         self._check(self.lib.rover_build_knn_map(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], int(n_x), int(n_y),
                                                  float(res), int(k), _ptr(out)), "rover_build_knn_map")
+        return out
+
+    ACTIVATIONS = {"none": 0, None: 0, "leakyrelu": 1, "tanh": 2, "relu": 3, "elu": 4}
+
+    def linear_forward(self, x, weight, bias, activation, out):
+        """out[:, :N] = act(x[:, :K] @ weight.T + bias); x / out may be column slices of wider row-major tensors."""
+        m, k = x.shape
+        n = weight.shape[0]
+        for t, name in ((x, "x"), (out, "out")):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+                raise RoverError(f"linear_forward: {name} must be a float32 GPU matrix with unit column stride")
+        self._chk(weight, (n, k), torch.float32, "weight")
+        self._chk(bias, (n,), torch.float32, "bias")
+        if out.shape[0] != m or out.shape[1] != n:
+            raise RoverError(f"linear_forward: out must be [{m},{n}]")
+        self._check(self.lib.rover_linear_forward(self._h, _ptr(x), x.stride(0), m, k, _ptr(weight), _ptr(bias), n,
+                                                  self.ACTIVATIONS[activation], _ptr(out), out.stride(0), _stream()),
+                    "rover_linear_forward")
         return out
 
     def set_option(self, name, value):

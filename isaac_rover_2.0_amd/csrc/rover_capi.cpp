@@ -653,6 +653,18 @@ int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const in
     return ROVER_OK;
 }
 
+int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t M, int32_t K, const float* weight, const float* bias,
+                         int32_t N, int32_t activation, float* y, int64_t y_stride, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!x || !weight || !y || M < 0 || K <= 0 || N <= 0 || N > 256 || x_stride < K || y_stride < N || activation < 0 || activation > 4)
+        return fail(c, ROVER_E_INVALID, "linear_forward: bad arguments (M=%d K=%d N=%d act=%d)", M, K, N, activation);
+    if (M == 0) return ROVER_OK;
+    if (int r = use_device(c)) return r;
+    LinearArgs a{x, x_stride, weight, bias, y, y_stride, M, K, N, activation};
+    HIP_TRY(c, launch_linear_act(a, (hipStream_t)stream));
+    return ROVER_OK;
+}
+
 int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
     if (!strcmp(name, "raycast_variant")) {

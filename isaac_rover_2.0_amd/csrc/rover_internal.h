@@ -98,6 +98,14 @@ struct PrePhysicsArgs {
     float *lin_hist, *ang_hist, *euler_pre, *pos_targets13, *vel_targets13;
 };
 
+struct LinearArgs {
+    const float* x; int64_t x_stride;      // [M, K] rows at x_stride floats
+    const float* w; const float* b;        // nn.Linear: weight [N][K], bias [N] (optional)
+    float* y; int64_t y_stride;            // [M, N] rows at y_stride floats
+    int32_t M, K, N, act;                  // act: 0 none, 1 leakyrelu(0.01), 2 tanh, 3 relu, 4 elu
+};
+hipError_t launch_linear_act(const LinearArgs& a, hipStream_t s);
+
 hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                          uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s);
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);

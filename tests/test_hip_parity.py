@@ -338,3 +338,64 @@ def test_built_map_drives_the_step():
     want = orc.step(t, r, st, *distn)
     assert_step_close(got, {"out_" + k: v for k, v in want.items()}, "built-map")
     assert (got["ray_dist"] < 11.0).mean() > 0.5
+
+
+def _torch_net_reference(net, states):
+    """fp32 PyTorch restatement of model.py:185-195 on the same weights."""
+    import torch.nn.functional as F
+    act = {"leakyrelu": lambda v: F.leaky_relu(v, 0.01), "tanh": torch.tanh, None: lambda v: v, "relu": F.relu, "elu": F.elu}
+    p, ns, nd = net.num_proprioception, net.num_sparse, net.num_dense
+    def run(layers, x):
+        for l in layers:
+            x = act[l.activation](F.linear(x, l.weight, l.bias))
+        return x
+    x0 = run(net.encoder0, states[:, p:p + ns])
+    x1 = run(net.encoder1, states[:, p + ns:p + ns + nd])
+    return run(net.network, torch.cat((states[:, 0:p], x0, x1), dim=1))
+
+
+@pytest.mark.parametrize("num_envs,ns,nd", [(300, 634, 1112), (4096, 37, 0 + 5), (1, 9, 3)])
+def test_policy_forward_matches_torch_fp32(num_envs, ns, nd):
+    """f-4: actor and critic forward (f32 MFMA linear layers reading obs slices in place) vs a PyTorch fp32 reference."""
+    from isaac_rover_amd import _lib
+    from isaac_rover_amd.learning.model import HeightmapNet
+    eng = _lib.Engine(max(num_envs, 1), device=0)
+    w = 4 + ns + nd
+    g = torch.Generator().manual_seed(1)
+    states = (torch.rand(num_envs, w, generator=g) * 4 - 1).cuda()
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        for outputs, head in ((2, "tanh"), (1, None)):
+            net = HeightmapNet(eng, w, ns, nd, outputs, head, device="cuda:0", seed=outputs)
+            got = net.compute(states)
+            want = _torch_net_reference(net, states)
+            torch.cuda.synchronize()
+            assert got.shape == (num_envs, outputs)
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    sd = net.state_dict()
+    assert "encoder0.encoder.0.layer.0.weight" in sd and "network.3.bias" in sd        # the reference's parameter names
+    eng.close()
+
+
+@pytest.mark.parametrize("act", ["none", "leakyrelu", "tanh", "relu", "elu"])
+def test_linear_forward_shapes_and_activations(act):
+    from isaac_rover_amd import _lib
+    import torch.nn.functional as F
+    eng = _lib.Engine(8, device=0)
+    g = torch.Generator().manual_seed(3)
+    for m, k, n in ((257, 33, 1), (64, 634, 80), (130, 5, 256), (31, 1112, 80)):
+        wide = torch.randn(m, k + 9, generator=g).cuda()
+        x = wide[:, 4:4 + k]
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
+        b = torch.randn(n, generator=g).cuda()
+        out_wide = torch.full((m, n + 3), 7.0).cuda()
+        eng.linear_forward(x, w, b, act, out_wide[:, 1:1 + n])
+        want = F.linear(x.double(), w.double(), b.double())
+        want = {"none": want, "leakyrelu": F.leaky_relu(want, 0.01), "tanh": torch.tanh(want), "relu": F.relu(want), "elu": F.elu(want)}[act]
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out_wide[:, 1:1 + n].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        assert bool((out_wide[:, 0] == 7.0).all()) and bool((out_wide[:, 1 + n:] == 7.0).all())
+    eng.close()
