@@ -44,7 +44,10 @@ struct rover_ctx {
     uint32_t* d_goal_work = nullptr;// [2][E] work lists of generate_goals
     uint32_t* d_block_cnt = nullptr;// [ceil(E/256)]
     // ray binning (raycast variant 2)
-    uint32_t* d_bin_cursor = nullptr;   // [n_bins] histogram -> cursors
+    uint32_t* d_bins = nullptr;         // [E*R8] bin key per slot
+    uint32_t* d_bkt_table = nullptr;    // [n_buckets * n_blocks] counts -> offsets
+    uint2* d_pairs = nullptr;           // [E*R8] (bin, slot) after the coarse partition
+    uint32_t low_bits = 10;             // option "bin_low_bits"
     uint32_t* d_block_sums = nullptr;   // [8192]
     uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
     uint32_t n_bins = 0;
@@ -110,20 +113,26 @@ static int effective_variant(const rover_ctx* c) {
     return 2;
 }
 
+static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
+
 static int alloc_bins(rover_ctx* c) {
     if (!c->have_map[0] || !c->have_map[1]) return ROVER_OK;
     const uint64_t nb = (uint64_t)c->map[0].X * c->map[0].Y + (uint64_t)c->map[1].X * c->map[1].Y;
-    if (nb > 0xffffffffull) return fail(c, ROVER_E_INVALID, "too many map cells for ray binning");
-    dfree(c->d_bin_cursor); dfree(c->d_block_sums);
-    HIP_TRY(c, hipMalloc((void**)&c->d_bin_cursor, nb * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_block_sums, 8192 * sizeof(uint32_t)));
+    if (nb > 0xfffffffeull) return fail(c, ROVER_E_INVALID, "too many map cells for ray binning");
     c->n_bins = (uint32_t)nb;
+    while (c->low_bits < 12u && bucket_count(c) > 4096u) ++c->low_bits;
+    if (!c->d_block_sums) HIP_TRY(c, hipMalloc((void**)&c->d_block_sums, 8192 * sizeof(uint32_t)));
+    if (c->have_dist) {                                   // table size depends on E*R8 too
+        dfree(c->d_bkt_table);
+        const uint64_t n_blocks = ((uint64_t)c->cfg.num_envs * c->R8 + 4095) / 4096;
+        HIP_TRY(c, hipMalloc((void**)&c->d_bkt_table, ((uint64_t)bucket_count(c) * n_blocks + 1) * sizeof(uint32_t)));
+    }
     return ROVER_OK;
 }
 
 static int alloc_workspace(rover_ctx* c) {
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_sorted);
-    dfree(c->d_env_rec);
+    dfree(c->d_env_rec); dfree(c->d_bins); dfree(c->d_pairs);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
     c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
     const uint64_t n = E * c->R8;
@@ -134,11 +143,13 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_env_rec, E * 48 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_bins, n * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_pairs, n * sizeof(uint2)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
-    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + sizeof(uint32_t)) + E * (4 * sizeof(float) + sizeof(int64_t));
+    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (52 * sizeof(float) + sizeof(int64_t));
     c->rays_valid = false;
-    return ROVER_OK;
+    return alloc_bins(c);
 }
 
 extern "C" {
@@ -181,7 +192,8 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_stones);
     { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); p = const_cast<uint32_t*>(c->sgrid.stone_idx); dfree(p); }
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
-    dfree(c->d_bin_cursor); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec); dfree(c->d_block_cnt);
+    dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
+    dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
@@ -351,15 +363,12 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading; p.env_rec = c->d_env_rec;
     const int variant = effective_variant(c);
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
-    if (variant == 2) {
-        p.bin_count = c->d_bin_cursor;
-        p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
-        HIP_TRY(c, hipMemsetAsync(c->d_bin_cursor, 0, (uint64_t)c->n_bins * sizeof(uint32_t), s));
-    }
+    p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
+    if (variant == 2) p.bin_out = c->d_bins;
     HIP_TRY(c, launch_prep(p, s));
     if (variant == 2)
-        HIP_TRY(c, launch_bin_rays(c->d_rays, E * c->R8, c->d_bin_cursor, c->n_bins, p.rocks_bin_offset, c->d_block_sums,
-                                   c->d_sorted, s));
+        HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
+                                   c->d_block_sums, c->d_sorted, s));
     if (c->profiling) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
@@ -671,6 +680,11 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 or 2");
         c->variant = (int)value;
         return ROVER_OK;
+    }
+    if (!strcmp(name, "bin_low_bits")) {
+        if (value < 8 || value > 12) return fail(c, ROVER_E_INVALID, "bin_low_bits must be in [8, 12]");
+        c->low_bits = (uint32_t)value;
+        return alloc_bins(c);
     }
     if (!strcmp(name, "raycast_run")) {
         if (value < 1 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be in [1, 4096]");

@@ -43,7 +43,7 @@ struct PrepArgs {
     RayRec* rays;                // [E*R8]
     float *euler, *heading;      // [E,3], [E]
     float* env_rec;              // [E][48] per-env euler / heading / sin-cos record (prep_env_kernel)
-    uint32_t* bin_count;         // optional [n_bins]: rays per (map, cell) histogram for the binned ray cast
+    uint32_t* bin_out;           // optional [E*R8]: bin = (map, cell) key of every slot for the bucket sort (binned ray cast)
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
 };
 
@@ -111,8 +111,8 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* tab0, const uint16_t* tab1, uint32_t kp0,
                           uint32_t kp1, float* out, hipStream_t s);
-hipError_t launch_bin_rays(const RayRec* rays, uint32_t n_slots, uint32_t* cursor, uint32_t n_bins, uint32_t rocks_bin_offset,
-                           uint32_t* block_sums, uint32_t* sorted, hipStream_t s);
+hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_valid, uint32_t n_bins, uint32_t low_bits,
+                           uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, hipStream_t s);
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
                                  const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, float* out, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, float* cx, float* cy, hipStream_t s);

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
     if (e >= a.E) return;
     RayRec rec;
     rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
+    uint32_t bin = 0xffffffffu;
     const uint32_t n_real = 26u + a.P;
     if (slot < n_real) {
         const float* pos = a.pos + 3ull * e;
@@ -239,12 +240,9 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->X);
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
         rec.cell = ix * (uint32_t)m->Y + iy;
-        if (a.bin_count) {
-            // histogram of the counting sort; the returned count is this ray's rank inside its bin (flags bits 2..31)
-            uint32_t rank = atomicAdd(a.bin_count + ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell, 1u);
-            rec.flags |= rank << 2;
-        }
+        bin = ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell;
     }
+    if (a.bin_out) a.bin_out[gid] = bin;                      // key of the bucket sort; 0xffffffff for padding slots
     float4* dst = reinterpret_cast<float4*>(a.rays + gid);
     dst[0] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
     dst[1] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
@@ -819,15 +817,71 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __rest
     for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) cnt[base + i] = run; run += v[i]; }
 }
 
-__global__ void __launch_bounds__(256) scatter_rays_kernel(const RayRec* __restrict__ rays, uint32_t n_slots,
-                                                           const uint32_t* __restrict__ bin_start, uint32_t rocks_bin_offset,
-                                                           uint32_t* __restrict__ sorted) {
-    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_slots) return;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(rays + gid);
-    uint32_t cell = w[3], flags = w[7];
-    if (!(flags & 2u)) return;
-    sorted[bin_start[((flags & 1u) ? rocks_bin_offset : 0u) + cell] + (flags >> 2)] = gid;
+// ---- bucket sort of the ray slots by bin = (map, cell), without global atomics ------------------------------------
+//   bucket_hist_kernel     per 4096-slot block: LDS histogram over the coarse buckets (bin >> low_bits) -> counts[bucket][block]
+//   (exclusive scan of counts, bucket-major: every bucket becomes one contiguous range)
+//   bucket_scatter_kernel  same blocks: (bin, slot) pairs to their bucket range, position from an LDS cursor per bucket
+//   bucket_sort_kernel     one workgroup per bucket: LDS counting sort on the low bits -> sorted slot ids
+// The order of equal bins is whatever the LDS atomics produce; the ray cast does not depend on it.
+#define BKT_ITEMS 16
+#define BKT_TILE (256 * BKT_ITEMS)
+#define BKT_MAX 4096            // max coarse buckets, and max 2^low_bits
+
+__global__ void __launch_bounds__(256) bucket_hist_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
+                                                          uint32_t n_buckets, uint32_t n_blocks, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t h[BKT_MAX];
+    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * BKT_TILE;
+#pragma unroll 4
+    for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
+        const uint32_t i = base + it * 256u + threadIdx.x;
+        if (i < n_slots) { const uint32_t b = bins[i]; if (b != 0xffffffffu) atomicAdd(&h[b >> low_bits], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) counts[(size_t)i * n_blocks + blockIdx.x] = h[i];
+}
+
+__global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
+                                                             uint32_t n_buckets, uint32_t n_blocks, const uint32_t* __restrict__ offsets,
+                                                             uint2* __restrict__ pairs) {
+    __shared__ uint32_t cur[BKT_MAX];
+    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) cur[i] = offsets[(size_t)i * n_blocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * BKT_TILE;
+#pragma unroll 4
+    for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
+        const uint32_t i = base + it * 256u + threadIdx.x;
+        if (i < n_slots) {
+            const uint32_t b = bins[i];
+            if (b != 0xffffffffu) pairs[atomicAdd(&cur[b >> low_bits], 1u)] = make_uint2(b, i);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ offsets,
+                                                          uint32_t n_blocks, uint32_t n_buckets, uint32_t n_total, uint32_t low_bits,
+                                                          uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t h[BKT_MAX];
+    __shared__ uint32_t wl[4];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, nl = 1u << low_bits, mask = nl - 1u;
+    const uint32_t s0 = offsets[(size_t)b * n_blocks], s1 = (b + 1u < n_buckets) ? offsets[(size_t)(b + 1u) * n_blocks] : n_total;
+    if (s1 <= s0) return;
+    for (uint32_t i = tid; i < nl; i += 256) h[i] = 0;
+    __syncthreads();
+    for (uint32_t k = s0 + tid; k < s1; k += 256) atomicAdd(&h[pairs[k].x & mask], 1u);
+    __syncthreads();
+    // exclusive scan of h[0..nl): each thread owns nl/256 consecutive entries (nl >= 256)
+    const uint32_t per = nl >> 8, first = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; ++j) sum += h[first + j];
+    uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
+    for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
+    __syncthreads();
+    for (uint32_t k = s0 + tid; k < s1; k += 256) {
+        const uint2 p = pairs[k];
+        sorted[s0 + atomicAdd(&h[p.x & mask], 1u)] = p.y;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1121,15 +1175,19 @@ hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* t
     return hipGetLastError();
 }
 
-hipError_t launch_bin_rays(const RayRec* rays, uint32_t n_slots, uint32_t* cursor, uint32_t n_bins, uint32_t rocks_bin_offset,
-                           uint32_t* block_sums, uint32_t* sorted, hipStream_t s) {
-    const uint32_t nb = blocks_for(n_bins, SCAN_TILE);
-    if (nb > 1024u * SCAN_ITEMS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, cursor, n_bins, block_sums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s, cursor, n_bins, block_sums);
-    hipLaunchKernelGGL(scatter_rays_kernel, dim3(blocks_for(n_slots, 256)), dim3(256), 0, s, rays, n_slots, cursor,
-                       rocks_bin_offset, sorted);
+hipError_t launch_scan_exclusive(uint32_t* data, uint32_t n, uint32_t* block_sums, hipStream_t s);
+
+// sort the valid ray slots by bin; work = [counts/offsets table | pairs]; returns hipErrorInvalidValue when the bin space is too large
+hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_valid, uint32_t n_bins, uint32_t low_bits,
+                           uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, hipStream_t s) {
+    const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
+    if (low_bits < 8u || low_bits > 12u || n_buckets > BKT_MAX) return hipErrorInvalidValue;
+    const uint32_t n_blocks = blocks_for(n_slots, BKT_TILE);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table);
+    hipError_t e = launch_scan_exclusive(table, n_buckets * n_blocks, block_sums, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table, pairs);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(256), 0, s, pairs, table, n_blocks, n_buckets, n_valid, low_bits, sorted);
     return hipGetLastError();
 }
 
