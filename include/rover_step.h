@@ -218,6 +218,10 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers
  *        (needs K <= 256 on both maps; the default when it applies).  Both give bit-identical results.
+ * name = "ray_source_fp16": 1 = round every ray origin and direction to fp16 before the cell lookup and the ray maths, like
+ *        the reference AS SHIPPED does (Camera.dtype = float16, camera.py:55,212; rock_detect.py:319,371); the arithmetic
+ *        itself stays f32.  Default 0 = the reference's fp32 mode, which the parity tests pin.
+ * name = "bin_low_bits": width of the low digit of the ray bucket sort, 8..12 (default 10).
  * name = "raycast_run": sorted rays per wave for variant 2 (default 16). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
 

@@ -48,6 +48,7 @@ struct rover_ctx {
     uint32_t* d_bkt_table = nullptr;    // [n_buckets * n_blocks] counts -> offsets
     uint2* d_pairs = nullptr;           // [E*R8] (bin, slot) after the coarse partition
     uint32_t low_bits = 10;             // option "bin_low_bits"
+    bool source_fp16 = false;           // option "ray_source_fp16"
     uint32_t* d_block_sums = nullptr;   // [8192]
     uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
     uint32_t n_bins = 0;
@@ -365,6 +366,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
     if (variant == 2) p.bin_out = c->d_bins;
+    p.source_fp16 = c->source_fp16 ? 1 : 0;
     HIP_TRY(c, launch_prep(p, s));
     if (variant == 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
@@ -681,6 +683,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->variant = (int)value;
         return ROVER_OK;
     }
+    if (!strcmp(name, "ray_source_fp16")) { c->source_fp16 = value != 0; return ROVER_OK; }
     if (!strcmp(name, "bin_low_bits")) {
         if (value < 8 || value > 12) return fail(c, ROVER_E_INVALID, "bin_low_bits must be in [8, 12]");
         c->low_bits = (uint32_t)value;

@@ -45,6 +45,7 @@ struct PrepArgs {
     float* env_rec;              // [E][48] per-env euler / heading / sin-cos record (prep_env_kernel)
     uint32_t* bin_out;           // optional [E*R8]: bin = (map, cell) key of every slot for the bucket sort (binned ray cast)
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
+    int32_t source_fp16;         // round ray origins / directions to fp16 like the reference as shipped (option)
 };
 
 struct ObsArgs {

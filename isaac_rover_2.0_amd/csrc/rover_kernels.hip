@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
             m = &a.terrain;
             rec.flags = 2u;
         }
+        if (a.source_fp16) {            // sources.type(float16), rover_dir.type(float16): camera.py:212, rock_detect.py:319,371
+            sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz;
+            ux = (float)(_Float16)ux; uy = (float)(_Float16)uy; uz = (float)(_Float16)uz;
+        }
         rec.sx = sx; rec.sy = sy; rec.sz = sz;
         neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
         uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->X);

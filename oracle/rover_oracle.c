@@ -31,6 +31,23 @@ static inline float h2f(uint16_t h) {
     float f; memcpy(&f, &u, 4); return f;
 }
 
+/* f32 -> fp16 -> f32, round to nearest even (what Tensor.type(torch.float16) does, camera.py:212) */
+static inline float round_h(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = x & 0x80000000u, ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return f;                                   /* inf / nan */
+    if (ax >= 0x477ff000u) { uint32_t inf = sign | 0x7f800000u; float r; memcpy(&r, &inf, 4); return r; }   /* >= 65520 -> inf */
+    if (ax < 0x38800000u) {                                            /* < 2^-14: fp16 subnormal, spacing 2^-24 */
+        float a = fabsf(f), q = rintf(a * 16777216.0f) / 16777216.0f;
+        return sign ? -q : q;
+    }
+    uint32_t lsb = (ax >> 13) & 1u;
+    ax += 0x0fffu + lsb;                                               /* round the 13 dropped bits, ties to even */
+    ax &= ~0x1fffu;
+    x = sign | ax;
+    float r; memcpy(&r, &x, 4); return r;
+}
+
 /* constants of ray_casting.py:24-27 after fp16 rounding */
 #define RAY_NEG_EPS  (-0.0999755859375f)
 #define RAY_ONE_EPS  (1.099609375f)
@@ -208,6 +225,8 @@ typedef struct {
     int32_t P, Ns, Nd;          /* rays, sparse count, dense count */
     int32_t curriculum_level;   /* rover.py:292,514,645 */
     int32_t max_episode_length; /* rover.py:119 */
+    int32_t source_fp16;        /* 1: ray origins / directions rounded to fp16 like the reference as shipped
+                                   (camera.py:55,212; rock_detect.py:319,371); the ray maths stays f32 */
     float pos_reward, heading_contraint_reward, motion_contraint_reward, goal_angle_reward,
           boogie_contraint_reward;                      /* cfg/task/Rover.yaml:37-46 */
 } oracle_cfg;
@@ -246,11 +265,18 @@ ORACLE_API void oracle_step(const oracle_cfg *cfg, const oracle_knn_map *terrain
         out->heading[e] = hd;
         float *src = out->ray_src + (size_t)3*P*e, dir[3];
         depth_transform(pos, eul, P, in->distribution, src, dir);
+        if (cfg->source_fp16) { for (int q = 0; q < 3*P; ++q) src[q] = round_h(src[q]); for (int q = 0; q < 3; ++q) dir[q] = round_h(dir[q]); }
         float *rd = out->ray_dist + (size_t)P*e;
         for (int p = 0; p < P; ++p) rd[p] = ray_min_distance(terrain, src + 3*p, dir);
         float wsrc[24*3], wdir[6*3], bsrc[2*3], bdir[3];
         wheel_rays(pos, eul, jn, wsrc, wdir);
         body_rays(pos, eul, bsrc, bdir);
+        if (cfg->source_fp16) {
+            for (int q = 0; q < 72; ++q) wsrc[q] = round_h(wsrc[q]);
+            for (int q = 0; q < 18; ++q) wdir[q] = round_h(wdir[q]);
+            for (int q = 0; q < 6; ++q) bsrc[q] = round_h(bsrc[q]);
+            for (int q = 0; q < 3; ++q) bdir[q] = round_h(bdir[q]);
+        }
         float *wd = out->wheel_dist + 24*e, *bd = out->body_dist + 2*e;
         for (int r = 0; r < 24; ++r) wd[r] = ray_min_distance(rocks, wsrc + 3*r, wdir + 3*(r/4));
         for (int r = 0; r < 2; ++r) bd[r] = ray_min_distance(rocks, bsrc + 3*r, bdir);

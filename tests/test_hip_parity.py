@@ -69,6 +69,27 @@ def test_raycast_variants_bit_identical(dist_name, num_envs, k):
                 np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} run={run}")
 
 
+def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
+    """Option ray_source_fp16: origins / directions rounded to fp16 like the reference as shipped, f32 maths after."""
+    from hip_helpers import hip_step, make_engine
+    from oracle import oracle as orc
+    fx16 = load_golden("step_e64_p37_fp16_as_shipped")
+    scene = scene_for(fx16)
+    st = states_of(fx16)
+    distn = (fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"])
+    eng = make_engine(scene, distn, 64)
+    eng.set_option("ray_source_fp16", 1)
+    got = hip_step(eng, st)
+    t, r = _oracle_maps(scene)
+    want = orc.step(t, r, st, *distn, source_fp16=True)
+    assert_step_close(got, {"out_" + k: v for k, v in want.items()}, "fp16-sources vs oracle")
+    d = np.abs(got["ray_dist"].astype(np.float64) - fx16["out_ray_dist"])
+    assert d.mean() < 1e-3 and (d > 0.05).mean() == 0.0                     # vs the reference AS SHIPPED
+    np.testing.assert_array_equal(got["reset_buf"], fx16["out_reset_buf"])
+    np.testing.assert_array_equal(got["rock_collision"], fx16["out_rock_collision"])
+    eng.close()
+
+
 def _custom_scene(n_x, n_y, k_t, k_r, shift=(0.0, 0.0, 0.0), seed=0):
     """Non-square maps with different K per map, cut out of a square synthetic scene."""
     from isaac_rover_amd import synth

@@ -49,6 +49,28 @@ def test_fp16_as_shipped_is_close_informational():
     assert (d > 0.05).mean() < 0.05
 
 
+def test_fp16_source_mode_tracks_the_reference_as_shipped():
+    """With ray origins / directions rounded to fp16 (what `.type(torch.float16)` does at camera.py:212,
+    rock_detect.py:319,371) and f32 arithmetic after that, the restatement follows the reference AS SHIPPED: identical
+    ray origins (hence identical cells), mean |d| 1.7e-4 on the distances (vs 3.6e-2 in fp32 mode on this fixture), every
+    integer output equal.  What remains is the fp16 rounding of the reference's own intermediate products."""
+    fx16 = load_golden("step_e64_p37_fp16_as_shipped")
+    scene = scene_for(fx16)
+    t, r = _maps(scene)
+    args = (fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"])
+    o = orc.step(t, r, states_of(fx16), *args, source_fp16=True)
+    np.testing.assert_array_equal(o["ray_sources"], fx16["out_ray_sources"])
+    d = np.abs(o["ray_dist"].astype(np.float64) - fx16["out_ray_dist"])
+    assert d.mean() < 1e-3 and (d > 0.05).mean() == 0.0 and d.max() < 2e-2
+    dw = np.abs(o["wheel_dist"].astype(np.float64) - fx16["out_wheel_dist"])
+    assert dw.mean() < 1e-3
+    np.testing.assert_array_equal(o["reset_buf"], fx16["out_reset_buf"])
+    np.testing.assert_array_equal(o["rock_collision"], fx16["out_rock_collision"])
+    np.testing.assert_allclose(o["rew_buf"], fx16["out_rew_buf"], rtol=1e-5, atol=1e-5)
+    d32 = np.abs(orc.step(t, r, states_of(fx16), *args)["ray_dist"].astype(np.float64) - fx16["out_ray_dist"])
+    assert d.mean() < 0.05 * d32.mean()
+
+
 def test_shards_equal_whole():
     """Envs are independent: two shards with num_envs_global = E reproduce the unsharded step."""
     fx = load_golden("step_e64_p37_fp32")
