@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--stones", type=int, default=1024)
     ap.add_argument("--validate-goals", action="store_true",
                     help="configs[4]: also run the reset/spawn-goal validation kernel on the envs flagged done each step")
+    ap.add_argument("--ray-precision", default="fp32", choices=["fp32", "fp16_sources", "fp16_as_shipped"],
+                    help="fp32 = the reference's fp32 mode (default, the north star's parity mode); fp16_as_shipped = bit-identical to the "
+                         "reference as shipped (Camera.dtype = float16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-timing", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
@@ -77,11 +80,12 @@ def cpu_baseline(args, scene, distn, states):
     st = {k: v[:n].cpu() for k, v in states.items()}
     t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
     r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
-    orc.step(t, r, st, *distn)                      # warm-up (page-in, thread pool)
+    prec = {"precision": args.ray_precision}
+    orc.step(t, r, st, *distn, **prec)              # warm-up (page-in, thread pool)
     best, reps, t_all = float("inf"), 0, time.perf_counter()
     while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 20):
         t0 = time.perf_counter()
-        orc.step(t, r, st, *distn)
+        orc.step(t, r, st, *distn, **prec)
         best = min(best, time.perf_counter() - t0)
         reps += 1
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
@@ -118,6 +122,7 @@ def main():
     distn = synth.ray_distribution(args.rays)
     eng = _lib.Engine(E, device=local_rank, num_envs_global=E_global, env_offset=rank * E)
     eng.set_scene(scene, distn)
+    eng.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[args.ray_precision])
     info = eng.info()
     W = eng.num_observations
 
@@ -209,11 +214,13 @@ def main():
         line = {
             "metric": "env-steps/sec (obs+reward+done)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.ray_precision == "fp16_as_shipped" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{4 if args.validate_goals else 2}]: {E} envs/GPU x {world} GPU, "
                                    f"{args.rays}-point heightmap + 26 rock rays, K={args.k}, {args.cells}x{args.cells} "
                                    f"cells @0.1 m, stones={args.stones}"
                                    + (", + goal validation" if args.validate_goals else "")
+                                   + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
                                    + (", RCCL gather(obs,rew,done)->rank0" if world > 1 else ""),
                        "envs_total": E_global, "rays_per_env": int(args.rays) + 26, "obs_dim": W,
                        "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(int(args.rays), args.k, eng.Ns, eng.Nd),

@@ -218,9 +218,12 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers
  *        (needs K <= 256 on both maps; the default when it applies).  Both give bit-identical results.
- * name = "ray_source_fp16": 1 = round every ray origin and direction to fp16 before the cell lookup and the ray maths, like
- *        the reference AS SHIPPED does (Camera.dtype = float16, camera.py:55,212; rock_detect.py:319,371); the arithmetic
- *        itself stays f32.  Default 0 = the reference's fp32 mode, which the parity tests pin.
+ * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
+ *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
+ *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.
+ *        2 = AS SHIPPED: (1) plus every operation of ray_casting.py:31-59 rounded to fp16 the way ATen's Half kernels do,
+ *        and fp16 collision thresholds (rover.py:667-668).  Bit-identical to the as-shipped reference on ray origins,
+ *        distances, collision mask and done flags (needs ray-cast variant 2).
  * name = "bin_low_bits": width of the low digit of the ray bucket sort, 8..12 (default 10).
  * name = "raycast_run": sorted rays per wave for variant 2 (default 16). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);

@@ -48,7 +48,7 @@ struct rover_ctx {
     uint32_t* d_bkt_table = nullptr;    // [n_buckets * n_blocks] counts -> offsets
     uint2* d_pairs = nullptr;           // [E*R8] (bin, slot) after the coarse partition
     uint32_t low_bits = 10;             // option "bin_low_bits"
-    bool source_fp16 = false;           // option "ray_source_fp16"
+    int precision = 0;                  // option "ray_precision": 0 fp32 mode, 1 fp16 sources, 2 as shipped (fp16 maths)
     uint32_t* d_block_sums = nullptr;   // [8192]
     uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
     uint32_t n_bins = 0;
@@ -344,10 +344,18 @@ int rover_set_curriculum_level(rover_ctx* c, int32_t level) {
 }
 
 // ---- step ------------------------------------------------------------------------------------------
+static int check_ready(rover_ctx* c);
+static int effective_variant(const rover_ctx* c);
+static int check_precision(rover_ctx* c) {
+    if (c->precision == 2 && effective_variant(c) != 2)
+        return fail(c, ROVER_E_STATE, "ray_precision 2 (as shipped, fp16 maths) needs ray-cast variant 2 (K <= 256 on both maps)");
+    return ROVER_OK;
+}
+
 static int check_ready(rover_ctx* c) {
     if (!c->have_map[0] || !c->have_map[1]) return fail(c, ROVER_E_STATE, "terrain and rocks maps must be set (rover_set_knn_map)");
     if (!c->have_dist) return fail(c, ROVER_E_STATE, "ray distribution must be set (rover_set_distribution)");
-    return ROVER_OK;
+    return check_precision(c);
 }
 
 static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, hipStream_t s) {
@@ -366,7 +374,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
     if (variant == 2) p.bin_out = c->d_bins;
-    p.source_fp16 = c->source_fp16 ? 1 : 0;
+    p.precision = c->precision;
     HIP_TRY(c, launch_prep(p, s));
     if (variant == 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
@@ -377,7 +385,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     }
     if (variant == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
-                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->run, c->d_dist_out, s));
+                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->run, c->precision == 2, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
                                   (uint32_t)c->map[1].K8, c->d_dist_out, s));
@@ -392,7 +400,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
-    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs;
+    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2;
     HIP_TRY(c, launch_assemble_obs(o, s));
     if (out->ray_dist || out->wheel_dist || out->body_dist)
         HIP_TRY(c, launch_export_dist(c->d_dist_out, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
@@ -417,6 +425,8 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.pos_reward = c->cfg.pos_reward; m.heading_contraint_reward = c->cfg.heading_contraint_reward;
     m.motion_contraint_reward = c->cfg.motion_contraint_reward; m.goal_angle_reward = c->cfg.goal_angle_reward;
     m.boogie_contraint_reward = c->cfg.boogie_contraint_reward;
+    m.wheel_thr = c->precision == 2 ? 0.7998046875f : 0.8f;                // fp16(0.8), fp16(0.45): Python scalars compared
+    m.body_thr = c->precision == 2 ? 0.449951171875f : 0.45f;              // against fp16 tensors (rover.py:667-668)
     m.pos = in->pos; m.target = in->target; m.joints = in->joints; m.lin_hist = in->lin_hist; m.ang_hist = in->ang_hist;
     m.euler_pre = in->euler_pre; m.heading = c->d_heading; m.dist = c->d_dist_out;
     m.progress = in->progress; m.rock_collision = out->rock_collision; m.rew = out->rew; m.reset = out->reset;
@@ -683,7 +693,12 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->variant = (int)value;
         return ROVER_OK;
     }
-    if (!strcmp(name, "ray_source_fp16")) { c->source_fp16 = value != 0; return ROVER_OK; }
+    if (!strcmp(name, "ray_precision")) {
+        if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "ray_precision must be 0 (fp32), 1 (fp16 sources) or 2 (as shipped)");
+        c->precision = (int)value;
+        c->rays_valid = false;
+        return ROVER_OK;
+    }
     if (!strcmp(name, "bin_low_bits")) {
         if (value < 8 || value > 12) return fail(c, ROVER_E_INVALID, "bin_low_bits must be in [8, 12]");
         c->low_bits = (uint32_t)value;
@@ -731,7 +746,7 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (v == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
-                                         (uint32_t)c->map[1].K8, c->run, c->d_dist_out, s));
+                                         (uint32_t)c->map[1].K8, c->run, c->precision == 2, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
                                   (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, s));

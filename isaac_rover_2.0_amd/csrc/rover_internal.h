@@ -45,13 +45,14 @@ struct PrepArgs {
     float* env_rec;              // [E][48] per-env euler / heading / sin-cos record (prep_env_kernel)
     uint32_t* bin_out;           // optional [E*R8]: bin = (map, cell) key of every slot for the bucket sort (binned ray cast)
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
-    int32_t source_fp16;         // round ray origins / directions to fp16 like the reference as shipped (option)
+    int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
 };
 
 struct ObsArgs {
     uint32_t E, W, R8;
     int64_t obs_stride;
     const float *pos, *target, *heading, *lin_hist, *ang_hist, *dist;
+    int32_t fp16_div;            // as-shipped mode: round dist / 2 to fp16
     const int32_t* obs_idx;      // [Ns+Nd] ray index per heightmap column
     float* obs;
 };
@@ -62,6 +63,7 @@ struct MetricsArgs {
     int64_t num_envs_global;
     int do_increment, do_collision, do_metrics, do_done;
     float pos_reward, heading_contraint_reward, motion_contraint_reward, goal_angle_reward, boogie_contraint_reward;
+    float wheel_thr, body_thr;   // rover.py:667-668 thresholds (0.8 / 0.45; their fp16 roundings in the as-shipped mode)
     const float *pos, *target, *joints, *lin_hist, *ang_hist, *euler_pre, *heading, *dist;
     int64_t* progress;
     int64_t* rock_collision;
@@ -115,7 +117,8 @@ hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* t
 hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_valid, uint32_t n_bins, uint32_t low_bits,
                            uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, hipStream_t s);
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
-                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, float* out, hipStream_t s);
+                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, float* out,
+                                 hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, float* cx, float* cy, hipStream_t s);
 hipError_t launch_knn_bucket(const float* cx, const float* cy, uint32_t T, float ox, float oy, float inv_g, uint32_t nbx, uint32_t nby,
                              uint32_t* cursor, uint32_t* items, int count, hipStream_t s);

@@ -234,12 +234,17 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
             m = &a.terrain;
             rec.flags = 2u;
         }
-        if (a.source_fp16) {            // sources.type(float16), rover_dir.type(float16): camera.py:212, rock_detect.py:319,371
+        if (a.precision >= 1) {         // sources.type(float16), rover_dir.type(float16): camera.py:212, rock_detect.py:319,371
             sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz;
             ux = (float)(_Float16)ux; uy = (float)(_Float16)uy; uz = (float)(_Float16)uz;
         }
         rec.sx = sx; rec.sy = sy; rec.sz = sz;
-        neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
+        if (a.precision == 2) {         // F.normalize on a float16 tensor: f32-accumulated norm rounded to fp16, fp16 division
+            float nrm = (float)(_Float16)sqrtf(ux * ux + uy * uy + uz * uz);     // (eps 1e-12 is 0 in fp16)
+            rec.dx = -(float)(_Float16)(ux / nrm); rec.dy = -(float)(_Float16)(uy / nrm); rec.dz = -(float)(_Float16)(uz / nrm);
+        } else {
+            neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
+        }
         uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->X);
         uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->X);
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
@@ -327,6 +332,7 @@ __global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
     if (col >= 4u) {
         int32_t p = a.obs_idx[col - 4u];                       // sparse then dense, heightmap_distribution.py:126-133
         v = a.dist[(uint64_t)e * a.R8 + 26u + (uint32_t)p] / 2.0f;
+        if (a.fp16_div) v = (float)(_Float16)v;                // as shipped: `sparse / 2` is an fp16 division (rover.py:324-325)
     } else if (col == 0u) {
         float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
         v = sqrtf(tx * tx + ty * ty) / 9.0f;                   // :320
@@ -377,8 +383,8 @@ __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t 
 #pragma unroll
             for (int r = 1; r < 24; ++r) mw = (d[r] < mw) ? d[r] : mw;
             float mb = (d[25] < d[24]) ? d[25] : d[24];
-            coll = (fabsf(mw) < 0.8f) ? 1 : 0;
-            if (fabsf(mb) < 0.45f) coll = 1;
+            coll = (fabsf(mw) < a.wheel_thr) ? 1 : 0;            // 0.8 / 0.45, as fp16 values in the as-shipped mode
+            if (fabsf(mb) < a.body_thr) coll = 1;
         }
         a.rock_collision[e] = coll;
     } else {
@@ -928,11 +934,12 @@ __device__ __forceinline__ Quot3 div3_ieee(f2 det, f2 nn, f2 mn, f2 kn) {
 
 // ray_casting.py:59 with the :46,:51,:56 substitutions folded in: det == fp16(-0.1) forces n = 11 and det == fp16(1.1)
 // forces m = k = 11, either of which fails n + m <= 1.1.
-__device__ __forceinline__ float accept1(float n, float m, float k, float det) {
-    bool ok = (n >= RAY_NEG_EPS) && (m >= RAY_NEG_EPS) && (n + m <= RAY_ONE_EPS)
+__device__ __forceinline__ float accept1(float n, float m, float k, float det, float n_plus_m) {
+    bool ok = (n >= RAY_NEG_EPS) && (m >= RAY_NEG_EPS) && (n_plus_m <= RAY_ONE_EPS)
               && (det != RAY_NEG_EPS) && (det != RAY_ONE_EPS);
     return ok ? k : RAY_MISS;
 }
+__device__ __forceinline__ float accept1(float n, float m, float k, float det) { return accept1(n, m, k, det, n + m); }
 
 // min over the 64 lanes with DPP row operations (no LDS crossbar): result valid in lane 63.
 // One asm block so the DPP read-after-VALU-write wait states (2, "s_nop 1") are under our control.
@@ -1154,6 +1161,103 @@ __global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ray cast in the reference's AS-SHIPPED arithmetic (option ray_precision = 2): Camera.dtype = float16, so every
+// elementwise ATen op of ray_casting.py:31-59 rounds to fp16.  Same structure as raycast_binned_kernel, the per-pair
+// maths in packed fp16 (v_pk_mul_f16 / v_pk_add_f16, one rounding per op, no contraction); the three quotients are
+// taken in f32 (IEEE, shared reciprocal) and rounded to fp16, which equals the fp16 quotient (24 >= 2*11 + 2 bits).
+// Bit-identical to the oracle's fp16 mode, which the as-shipped golden fixture pins bit for bit.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+struct CellRegsH {
+    h2 ax[2], ay[2], az[2], bx[2], by[2], bz[2], cx[2], cy[2], cz[2], nx[2], ny[2], nz[2];
+    __device__ __forceinline__ void poison() {
+        const _Float16 qnan = (_Float16)__builtin_nanf("");
+        const _Float16 zero = (_Float16)0.0f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ax[p] = ay[p] = az[p] = h2{qnan, qnan};
+            bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = h2{zero, zero};
+        }
+    }
+};
+
+__device__ __forceinline__ f2 h2_to_f2(h2 v) { return f2{(float)v.x, (float)v.y}; }
+
+__device__ __forceinline__ float cast_pairs_h(const CellRegsH& t, h2 sx, h2 sy, h2 sz, h2 dx, h2 dy, h2 dz) {
+    float best = RAY_MISS;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        h2 gx = sx - t.ax[p], gy = sy - t.ay[p], gz = sz - t.az[p];
+        h2 det = t.nx[p] * dx + t.ny[p] * dy + t.nz[p] * dz;
+        h2 gcx = gy * t.cz[p] - gz * t.cy[p], gcy = gz * t.cx[p] - gx * t.cz[p], gcz = gx * t.cy[p] - gy * t.cx[p];
+        h2 nn = gcx * dx + gcy * dy + gcz * dz;
+        h2 bgx = t.by[p] * gz - t.bz[p] * gy, bgy = t.bz[p] * gx - t.bx[p] * gz, bgz = t.bx[p] * gy - t.by[p] * gx;
+        h2 mn = bgx * dx + bgy * dy + bgz * dz;
+        h2 kn = t.nx[p] * gx + t.ny[p] * gy + t.nz[p] * gz;
+        const f2 detf = h2_to_f2(det);
+        Quot3 q = div3_ieee(detf, h2_to_f2(nn), h2_to_f2(mn), h2_to_f2(kn));
+        h2 n = h2{(_Float16)q.n.x, (_Float16)q.n.y}, m = h2{(_Float16)q.m.x, (_Float16)q.m.y}, k = h2{(_Float16)q.k.x, (_Float16)q.k.y};
+        h2 nm = n + m;                                                            // fp16 sum, then compared (ray_casting.py:59)
+        float r0 = accept1((float)n.x, (float)m.x, (float)k.x, detf.x, (float)nm.x);
+        float r1 = accept1((float)n.y, (float)m.y, (float)k.y, detf.y, (float)nm.y);
+        best = __builtin_fminf(best, __builtin_fminf(r0, r1));
+    }
+    return best;
+}
+
+__global__ void __launch_bounds__(256) raycast_binned_h_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
+                                                               uint32_t n_sorted, const _Float16* __restrict__ tab0,
+                                                               const _Float16* __restrict__ tab1, uint32_t kp0, uint32_t kp1,
+                                                               uint32_t run, uint32_t n_blocks, uint32_t nb8,
+                                                               float* __restrict__ out) {
+    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    if (lb >= n_blocks) return;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t i = wave * run;
+    if (i >= n_sorted) return;
+    const uint32_t i_end = min(i + run, n_sorted);
+    uint32_t cur_cell = 0xffffffffu, cur_map = 0xffffffffu;
+    CellRegsH t;
+    t.poison();
+    for (; i < i_end; ++i) {
+        const uint32_t gid = __builtin_amdgcn_readfirstlane(sorted[i]);
+        const float4* rp = reinterpret_cast<const float4*>(rays + gid);
+        const float4 ra = rp[0], rb = rp[1];
+        const uint32_t cell = __builtin_amdgcn_readfirstlane(__float_as_uint(ra.w));
+        const uint32_t map = __builtin_amdgcn_readfirstlane(__float_as_uint(rb.w)) & 1u;
+        if (cell != cur_cell || map != cur_map) {
+            if (map != cur_map && cur_map != 0xffffffffu && kp0 != kp1) t.poison();
+            cur_cell = cell; cur_map = map;
+            const uint32_t kp = map ? kp1 : kp0;
+            const _Float16* base = (map ? tab1 : tab0) + (size_t)cell * 9u * kp + lane * 4u;
+            if (lane * 4u < kp) {
+                half4 v[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = *reinterpret_cast<const half4*>(base + (size_t)q * kp);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int t0 = 2 * p, t1 = 2 * p + 1;
+                    t.ax[p] = h2{v[6][t0], v[6][t1]}; t.ay[p] = h2{v[7][t0], v[7][t1]}; t.az[p] = h2{v[8][t0], v[8][t1]};
+                    t.bx[p] = h2{v[3][t0], v[3][t1]} - t.ax[p]; t.by[p] = h2{v[4][t0], v[4][t1]} - t.ay[p]; t.bz[p] = h2{v[5][t0], v[5][t1]} - t.az[p];
+                    t.cx[p] = h2{v[0][t0], v[0][t1]} - t.ax[p]; t.cy[p] = h2{v[1][t0], v[1][t1]} - t.ay[p]; t.cz[p] = h2{v[2][t0], v[2][t1]} - t.az[p];
+                    t.nx[p] = t.by[p] * t.cz[p] - t.bz[p] * t.cy[p];
+                    t.ny[p] = t.bz[p] * t.cx[p] - t.bx[p] * t.cz[p];
+                    t.nz[p] = t.bx[p] * t.cy[p] - t.by[p] * t.cx[p];
+                }
+            }
+        }
+        // the record holds fp16 values widened to f32 (prep_rays_kernel, precision 2): the casts are exact
+        const _Float16 hsx = (_Float16)ra.x, hsy = (_Float16)ra.y, hsz = (_Float16)ra.z;
+        const _Float16 hdx = (_Float16)rb.x, hdy = (_Float16)rb.y, hdz = (_Float16)rb.z;
+        float best = cast_pairs_h(t, h2{hsx, hsx}, h2{hsy, hsy}, h2{hsz, hsz}, h2{hdx, hdx}, h2{hdy, hdy}, h2{hdz, hdz});
+        best = wave_min_to_lane63(best);
+        if (lane == 63u) out[gid] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
@@ -1196,13 +1300,19 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
 }
 
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
-                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, float* out, hipStream_t s) {
+                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, float* out,
+                                 hipStream_t s) {
     const uint32_t n_waves = blocks_for(n_sorted, run);
     const uint32_t n_blocks = blocks_for(n_waves, 4);
     const uint32_t nb8 = blocks_for(n_blocks, 8);
-    hipLaunchKernelGGL(raycast_binned_kernel, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted,
-                       reinterpret_cast<const _Float16*>(tab0), reinterpret_cast<const _Float16*>(tab1), kp0, kp1, run,
-                       n_blocks, nb8, out);
+    const _Float16* t0 = reinterpret_cast<const _Float16*>(tab0);
+    const _Float16* t1 = reinterpret_cast<const _Float16*>(tab1);
+    if (fp16_math)
+        hipLaunchKernelGGL(raycast_binned_h_kernel, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted, t0, t1, kp0, kp1, run,
+                           n_blocks, nb8, out);
+    else
+        hipLaunchKernelGGL(raycast_binned_kernel, dim3(nb8 * 8u), dim3(256), 0, s, rays, sorted, n_sorted, t0, t1, kp0, kp1, run,
+                           n_blocks, nb8, out);
     return hipGetLastError();
 }
 

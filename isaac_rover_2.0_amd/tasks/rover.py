@@ -63,7 +63,7 @@ class _Camera:
 
 class RoverTask(RLTask):
     def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
-                 device_reset=True, as_shipped_fp16_sources=False, num_envs_global=None, env_offset=0) -> None:
+                 device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0) -> None:
         """``scene``: a ``synth.Scene`` (or ``assets.load_reference_assets(root)``) with the terrain / rocks KNN maps,
         stone list and heightfield the reference loads from disk (:92-94,:144,:210).  ``distribution``: optional
         (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set."""
@@ -115,8 +115,9 @@ class RoverTask(RLTask):
                                    env_offset=env_offset, curriculum_level=self.curriculum_level,
                                    max_episode_length=self.max_episode_length, rewards=self.rew_scales)
         self._engine.set_scene(scene, (hm.distribution, hm.coarse_idx, hm.fine_idx))
-        if as_shipped_fp16_sources:       # Camera.dtype = float16 as shipped (camera.py:55): fp16 ray origins / directions
-            self._engine.set_option("ray_source_fp16", 1)
+        # "fp32" = the reference with Camera.dtype = float32 (parity target); "fp16_as_shipped" = Camera.dtype = float16
+        # exactly as the reference ships (camera.py:55); "fp16_sources" = fp16 ray origins, f32 arithmetic
+        self._engine.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[ray_precision])
         self._env_offset = int(env_offset)
 
         # persistent side-state the three methods hand to each other (:274-283, :343, :667)

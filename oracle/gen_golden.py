@@ -115,8 +115,11 @@ def main():
     step_fixture("step_e8_native_fp32", scene, digest, None, 8, seed=3, native=True)
     # curriculum level 1: collision term off (rover.py:292,514,645)
     step_fixture("step_e64_p37_fp32_level1", scene, digest, "37", 64, seed=1, edges=True, curriculum_level=1)
-    # as shipped (fp16 ray maths): informational tolerance only
+    # the reference AS SHIPPED (Camera.dtype = float16, nothing patched): pins the fp16 modes bit for bit
     step_fixture("step_e64_p37_fp16_as_shipped", scene, digest, "37", 64, seed=1, fp32=False, edges=True)
+    step_fixture("step_e256_p9_fp16_as_shipped", scene, digest, "9", 256, seed=0, fp32=False)
+    step_fixture("step_e64_p120_fp16_as_shipped", scene, digest, "120", 64, seed=2, fp32=False, edges=True)
+    step_fixture("step_e8_native_fp16_as_shipped", scene, digest, None, 8, seed=3, fp32=False, native=True)
 
     # ---- native distribution table (heightmap_distribution.py:36-115) -----------------------
     ref = rh.Reference(scene, fp32=True)

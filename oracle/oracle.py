@@ -34,7 +34,7 @@ class _KnnMap(C.Structure):
 class _Cfg(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_envs_global", C.c_int32), ("P", C.c_int32), ("Ns", C.c_int32),
                 ("Nd", C.c_int32), ("curriculum_level", C.c_int32), ("max_episode_length", C.c_int32),
-                ("source_fp16", C.c_int32), ("pos_reward", C.c_float), ("heading_contraint_reward", C.c_float),
+                ("precision", C.c_int32), ("pos_reward", C.c_float), ("heading_contraint_reward", C.c_float),
                 ("motion_contraint_reward", C.c_float), ("goal_angle_reward", C.c_float),
                 ("boogie_contraint_reward", C.c_float)]
 
@@ -95,7 +95,7 @@ EXTRAS = ("pos_reward", "collision_penalty", "uprightness_penalty", "heading_con
 
 
 def step(terrain: KnnMap, rocks: KnnMap, st: dict, distribution, sparse_idx, dense_idx, num_envs_global=None,
-         curriculum_level=2, max_episode_length=3000, rewards=None, source_fp16=False):
+         curriculum_level=2, max_episode_length=3000, rewards=None, source_fp16=False, precision=None):
     """One post_physics_step on sim state ``st`` (keys as synth.make_states). Returns a dict of numpy arrays."""
     rw = dict(DEFAULT_REWARDS)
     rw.update(rewards or {})
@@ -117,7 +117,8 @@ def step(terrain: KnnMap, rocks: KnnMap, st: dict, distribution, sparse_idx, den
                 reset=np.zeros(e, i64), ex_pos_reward=np.zeros(e, f32), ex_collision=np.zeros(e, i64),
                 ex_upright=np.zeros(e, f32), ex_heading=np.zeros(e, f32), ex_motion=np.zeros(e, f32),
                 ex_goal_angle=np.zeros(e, f32), ex_lin=np.zeros(e, f32), ex_ang=np.zeros(e, f32))
-    cfg = _Cfg(e, num_envs_global or e, p, len(sp), len(de), curriculum_level, max_episode_length, 1 if source_fp16 else 0,
+    prec = {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[precision] if precision is not None else (1 if source_fp16 else 0)
+    cfg = _Cfg(e, num_envs_global or e, p, len(sp), len(de), curriculum_level, max_episode_length, prec,
                rw["pos_reward"], rw["heading_contraint_reward"], rw["motion_contraint_reward"],
                rw["goal_angle_reward"], rw["boogie_contraint_reward"])
     cin = _In(*[_p(ins[n]) for n, _ in _In._fields_])

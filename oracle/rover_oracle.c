@@ -218,6 +218,48 @@ static float ray_min_distance(const oracle_knn_map *m, const float *s, const flo
     return best;
 }
 
+/* ray_casting.py:3-66 as ATen evaluates it on float16 tensors: every elementwise op rounds its result to fp16
+ * (computed in f32, so the double rounding is innocuous), `cross` is mul/mul/sub, the dot products are summed left to
+ * right, F.normalize takes the norm with f32 accumulation and rounds it to fp16.  Pinned bit for bit by the as-shipped
+ * golden fixture. */
+#define RH(x) round_h(x)
+static void cross_h(const float *u, const float *v, float *o) {
+    o[0] = RH(RH(u[1]*v[2]) - RH(u[2]*v[1]));
+    o[1] = RH(RH(u[2]*v[0]) - RH(u[0]*v[2]));
+    o[2] = RH(RH(u[0]*v[1]) - RH(u[1]*v[0]));
+}
+static float dot_h(const float *u, const float *v) { return RH(RH(RH(u[0]*v[0]) + RH(u[1]*v[1])) + RH(u[2]*v[2])); }
+
+static float ray_min_distance_h(const oracle_knn_map *m, const float *s, const float *d_in) {
+    float nrm = RH(sqrtf(d_in[0] * d_in[0] + d_in[1] * d_in[1] + d_in[2] * d_in[2]));     /* eps 1e-12 is 0 in fp16 */
+    float d[3] = {-RH(d_in[0] / nrm), -RH(d_in[1] / nrm), -RH(d_in[2] / nrm)};
+    int64_t ix = cell_index(s[0], m->shift_x, m->cell, m->X);
+    int64_t iy = cell_index(s[1], m->shift_y, m->cell, m->X);
+    if (iy > m->Y - 1) iy = m->Y - 1;
+    const int32_t *ids = m->map_idx + ((size_t)ix * m->Y + (size_t)iy) * m->K;
+    float best = INFINITY;
+    for (int t = 0; t < m->K; ++t) {
+        const int32_t *tv = m->tris + 3 * (size_t)ids[t];
+        float v[3][3];
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) v[a][c] = h2f(m->verts[3 * (size_t)tv[a] + c]);
+        float a[3] = {v[2][0], v[2][1], v[2][2]}, b[3], c[3], g[3], bc[3], gc[3], bg[3];
+        for (int q = 0; q < 3; ++q) { b[q] = RH(v[1][q] - a[q]); c[q] = RH(v[0][q] - a[q]); g[q] = RH(s[q] - a[q]); }
+        cross_h(b, c, bc);
+        float det = dot_h(bc, d);
+        cross_h(g, c, gc);
+        float n = RH(dot_h(gc, d) / det);
+        cross_h(b, g, bg);
+        float mm = RH(dot_h(bg, d) / det);
+        float k = RH(dot_h(bc, g) / det);
+        if (det == RAY_NEG_EPS) n = RAY_MISS;
+        if (det == RAY_ONE_EPS) { mm = RAY_MISS; k = RAY_MISS; }
+        float r = ((n >= RAY_NEG_EPS) && (mm >= RAY_NEG_EPS) && (RH(n + mm) <= RAY_ONE_EPS)) ? k : RAY_MISS;
+        if (r < best || r != r) best = r;
+        if (best != best) break;
+    }
+    return best;
+}
+
 /* ---- one full post_physics_step (rl_task.py:250-257 order) ----------------------------- */
 typedef struct {
     int32_t num_envs;           /* local envs in this call */
@@ -225,8 +267,11 @@ typedef struct {
     int32_t P, Ns, Nd;          /* rays, sparse count, dense count */
     int32_t curriculum_level;   /* rover.py:292,514,645 */
     int32_t max_episode_length; /* rover.py:119 */
-    int32_t source_fp16;        /* 1: ray origins / directions rounded to fp16 like the reference as shipped
-                                   (camera.py:55,212; rock_detect.py:319,371); the ray maths stays f32 */
+    int32_t precision;          /* 0: the reference's fp32 mode (parity target).
+                                   1: ray origins / directions rounded to fp16 (camera.py:55,212; rock_detect.py:319,371),
+                                      f32 ray maths.
+                                   2: the reference AS SHIPPED: (1) + every operation of ray_casting.py:31-59 rounded to
+                                      fp16 like ATen's Half kernels do, fp16 collision thresholds (rover.py:667-668) */
     float pos_reward, heading_contraint_reward, motion_contraint_reward, goal_angle_reward,
           boogie_contraint_reward;                      /* cfg/task/Rover.yaml:37-46 */
 } oracle_cfg;
@@ -265,27 +310,30 @@ ORACLE_API void oracle_step(const oracle_cfg *cfg, const oracle_knn_map *terrain
         out->heading[e] = hd;
         float *src = out->ray_src + (size_t)3*P*e, dir[3];
         depth_transform(pos, eul, P, in->distribution, src, dir);
-        if (cfg->source_fp16) { for (int q = 0; q < 3*P; ++q) src[q] = round_h(src[q]); for (int q = 0; q < 3; ++q) dir[q] = round_h(dir[q]); }
+        if (cfg->precision) { for (int q = 0; q < 3*P; ++q) src[q] = round_h(src[q]); for (int q = 0; q < 3; ++q) dir[q] = round_h(dir[q]); }
         float *rd = out->ray_dist + (size_t)P*e;
-        for (int p = 0; p < P; ++p) rd[p] = ray_min_distance(terrain, src + 3*p, dir);
+        const int half = cfg->precision == 2;
+        for (int p = 0; p < P; ++p) rd[p] = half ? ray_min_distance_h(terrain, src + 3*p, dir) : ray_min_distance(terrain, src + 3*p, dir);
         float wsrc[24*3], wdir[6*3], bsrc[2*3], bdir[3];
         wheel_rays(pos, eul, jn, wsrc, wdir);
         body_rays(pos, eul, bsrc, bdir);
-        if (cfg->source_fp16) {
+        if (cfg->precision) {
             for (int q = 0; q < 72; ++q) wsrc[q] = round_h(wsrc[q]);
             for (int q = 0; q < 18; ++q) wdir[q] = round_h(wdir[q]);
             for (int q = 0; q < 6; ++q) bsrc[q] = round_h(bsrc[q]);
             for (int q = 0; q < 3; ++q) bdir[q] = round_h(bdir[q]);
         }
         float *wd = out->wheel_dist + 24*e, *bd = out->body_dist + 2*e;
-        for (int r = 0; r < 24; ++r) wd[r] = ray_min_distance(rocks, wsrc + 3*r, wdir + 3*(r/4));
-        for (int r = 0; r < 2; ++r) bd[r] = ray_min_distance(rocks, bsrc + 3*r, bdir);
+        for (int r = 0; r < 24; ++r) wd[r] = half ? ray_min_distance_h(rocks, wsrc + 3*r, wdir + 3*(r/4)) : ray_min_distance(rocks, wsrc + 3*r, wdir + 3*(r/4));
+        for (int r = 0; r < 2; ++r) bd[r] = half ? ray_min_distance_h(rocks, bsrc + 3*r, bdir) : ray_min_distance(rocks, bsrc + 3*r, bdir);
         int64_t coll = 0;
         if (cfg->curriculum_level >= 2) {                                        /* rover.py:663-668 */
             float mw = wd[0]; for (int r = 1; r < 24; ++r) if (wd[r] < mw || wd[r] != wd[r]) mw = wd[r];
             float mb = bd[0]; if (bd[1] < mb || bd[1] != bd[1]) mb = bd[1];
-            coll = (fabsf(mw) < 0.8f) ? 1 : 0;
-            if (fabsf(mb) < 0.45f) coll = 1;
+            /* rover.py:667-668: on fp16 distances the Python scalars 0.8 / 0.45 are compared as fp16 values */
+            const float thr_w = half ? round_h(0.8f) : 0.8f, thr_b = half ? round_h(0.45f) : 0.45f;
+            coll = (fabsf(mw) < thr_w) ? 1 : 0;
+            if (fabsf(mb) < thr_b) coll = 1;
         }
         out->rock_collision[e] = coll;
         float tx = tgt[0] - pos[0], ty = tgt[1] - pos[1];
@@ -294,8 +342,9 @@ ORACLE_API void oracle_step(const oracle_cfg *cfg, const oracle_knn_map *terrain
         ob[1] = hd / 3.14159265358979323846f;                                    /* :321 math.pi -> f32 */
         ob[2] = in->lin_hist[3*e];                                               /* :322 */
         ob[3] = in->ang_hist[3*e];                                               /* :323 */
-        for (int i = 0; i < Ns; ++i) ob[4 + i] = rd[in->sparse_idx[i]] / 2.0f;   /* :324 */
-        for (int i = 0; i < Nd; ++i) ob[4 + Ns + i] = rd[in->dense_idx[i]] / 2.0f; /* :325 */
+        /* :324-325 `sparse / 2`: an fp16 division in the as-shipped mode (it rounds in the fp16 subnormal range) */
+        for (int i = 0; i < Ns; ++i) { float v = rd[in->sparse_idx[i]] / 2.0f; ob[4 + i] = half ? round_h(v) : v; }
+        for (int i = 0; i < Nd; ++i) { float v = rd[in->dense_idx[i]] / 2.0f; ob[4 + Ns + i] = half ? round_h(v) : v; }
         /* ---- calculate_metrics, rover.py:460-531 ---- */
         float lin = in->lin_hist[3*e], lin_prev = in->lin_hist[3*e+1];
         float ang = in->ang_hist[3*e], ang_prev = in->ang_hist[3*e+1];

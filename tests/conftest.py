@@ -54,6 +54,9 @@ def states_of(fixture):
 STEP_FIXTURES_FP32 = ["step_e256_p9_fp32", "step_e64_p37_fp32", "step_e64_p120_fp32", "step_e8_native_fp32",
                       "step_e64_p37_fp32_level1"]
 
+STEP_FIXTURES_AS_SHIPPED = ["step_e64_p37_fp16_as_shipped", "step_e256_p9_fp16_as_shipped", "step_e64_p120_fp16_as_shipped",
+                            "step_e8_native_fp16_as_shipped"]
+
 # ---- stated parity tolerances, shared by the oracle and the HIP tests ----------
 TOL_SCALAR = 1e-5        # euler / heading / obs[:,0:4] / reward / extras: abs and rel
 TOL_RAY = 2e-3           # ray distances: abs, on >= 99.9 % of rays

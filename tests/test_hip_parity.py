@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import STEP_FIXTURES_FP32, assert_step_close, load_golden, scene_for, states_of
+from conftest import STEP_FIXTURES_AS_SHIPPED, STEP_FIXTURES_FP32, assert_step_close, load_golden, scene_for, states_of
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +70,7 @@ def test_raycast_variants_bit_identical(dist_name, num_envs, k):
 
 
 def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
-    """Option ray_source_fp16: origins / directions rounded to fp16 like the reference as shipped, f32 maths after."""
+    """ray_precision 1: origins / directions rounded to fp16 like the reference as shipped, f32 maths after."""
     from hip_helpers import hip_step, make_engine
     from oracle import oracle as orc
     fx16 = load_golden("step_e64_p37_fp16_as_shipped")
@@ -78,16 +78,53 @@ def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
     st = states_of(fx16)
     distn = (fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"])
     eng = make_engine(scene, distn, 64)
-    eng.set_option("ray_source_fp16", 1)
+    eng.set_option("ray_precision", 1)
     got = hip_step(eng, st)
     t, r = _oracle_maps(scene)
-    want = orc.step(t, r, st, *distn, source_fp16=True)
+    want = orc.step(t, r, st, *distn, precision="fp16_sources")
     assert_step_close(got, {"out_" + k: v for k, v in want.items()}, "fp16-sources vs oracle")
     d = np.abs(got["ray_dist"].astype(np.float64) - fx16["out_ray_dist"])
     assert d.mean() < 1e-3 and (d > 0.05).mean() == 0.0                     # vs the reference AS SHIPPED
     np.testing.assert_array_equal(got["reset_buf"], fx16["out_reset_buf"])
     np.testing.assert_array_equal(got["rock_collision"], fx16["out_rock_collision"])
     eng.close()
+
+
+@pytest.mark.parametrize("name", STEP_FIXTURES_AS_SHIPPED)
+def test_as_shipped_fp16_mode_is_bit_identical_to_the_reference(name):
+    """ray_precision 2: the reference AS SHIPPED (Camera.dtype = float16).  Ray distances, wheel / body distances, the
+    collision mask, done flags and the heightmap part of obs are bit-identical to the golden vectors captured from the
+    unmodified reference (9 / 37 / 120 / native 1634 rays); reward differs by sin/cos/atan2 ulps only."""
+    from hip_helpers import hip_step, make_engine
+    from oracle import oracle as orc
+    fx16 = load_golden(name)
+    scene = scene_for(fx16)
+    st = states_of(fx16)
+    distn = (fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"])
+    eng = make_engine(scene, distn, st["pos"].shape[0])
+    eng.set_option("ray_precision", 2)
+    got = hip_step(eng, st)
+    for k in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf", "progress_buf", "extras_collision_penalty"):
+        np.testing.assert_array_equal(got[k], fx16["out_" + k], err_msg=k)
+    np.testing.assert_array_equal(got["obs_buf"][:, 4:], fx16["out_obs_buf"][:, 4:])
+    np.testing.assert_allclose(got["obs_buf"][:, :4], fx16["out_obs_buf"][:, :4], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got["rew_buf"], fx16["out_rew_buf"], rtol=1e-5, atol=1e-5)
+    if name != "step_e64_p37_fp16_as_shipped":
+        eng.close()
+        return
+    # and against the oracle's fp16 mode on a bigger random batch
+    from isaac_rover_amd import synth
+    st2 = synth.make_states(2048, 12.8, seed=77)
+    t, r = _oracle_maps(scene)
+    want = orc.step(t, r, st2, *distn, precision="fp16_as_shipped")
+    eng2 = make_engine(scene, distn, 2048)
+    eng2.set_option("ray_precision", 2)
+    got2 = hip_step(eng2, st2)
+    for k in ("ray_dist", "wheel_dist", "body_dist"):
+        bad = (got2[k] != want[k])
+        assert bad.mean() < 2e-3, f"{k}: {bad.mean():.4%} of rays differ (trig ulps moving an fp16 rounding)"
+    assert (got2["reset_buf"] != want["reset_buf"]).mean() < 2e-3
+    eng.close(); eng2.close()
 
 
 def _custom_scene(n_x, n_y, k_t, k_r, shift=(0.0, 0.0, 0.0), seed=0):

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import STEP_FIXTURES_FP32, assert_step_close, load_golden, scene_for, states_of
+from conftest import STEP_FIXTURES_AS_SHIPPED, STEP_FIXTURES_FP32, assert_step_close, load_golden, scene_for, states_of
 from oracle import oracle as orc
 
 
@@ -58,7 +58,7 @@ def test_fp16_source_mode_tracks_the_reference_as_shipped():
     scene = scene_for(fx16)
     t, r = _maps(scene)
     args = (fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"])
-    o = orc.step(t, r, states_of(fx16), *args, source_fp16=True)
+    o = orc.step(t, r, states_of(fx16), *args, precision="fp16_sources")
     np.testing.assert_array_equal(o["ray_sources"], fx16["out_ray_sources"])
     d = np.abs(o["ray_dist"].astype(np.float64) - fx16["out_ray_dist"])
     assert d.mean() < 1e-3 and (d > 0.05).mean() == 0.0 and d.max() < 2e-2
@@ -69,6 +69,26 @@ def test_fp16_source_mode_tracks_the_reference_as_shipped():
     np.testing.assert_allclose(o["rew_buf"], fx16["out_rew_buf"], rtol=1e-5, atol=1e-5)
     d32 = np.abs(orc.step(t, r, states_of(fx16), *args)["ray_dist"].astype(np.float64) - fx16["out_ray_dist"])
     assert d.mean() < 0.05 * d32.mean()
+
+
+@pytest.mark.parametrize("name", STEP_FIXTURES_AS_SHIPPED)
+def test_as_shipped_fp16_mode_is_bit_exact(name):
+    """precision = fp16_as_shipped: every op of ray_casting.py rounded to fp16 like ATen's Half kernels.  Against the golden
+    vectors captured from the UNMODIFIED reference (9 / 37 / 120 / native 1634 rays): ray origins, every ray distance, the
+    collision mask and the done flags are bit-identical; only f32 transcendental ulps (euler, heading) remain."""
+    fx16 = load_golden(name)
+    scene = scene_for(fx16)
+    t, r = _maps(scene)
+    o = orc.step(t, r, states_of(fx16), fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"], precision="fp16_as_shipped")
+    keys = ["ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf", "progress_buf", "extras_collision_penalty",
+            "extras_pos_reward", "extras_motion_contraint_penalty"]
+    if "out_ray_sources" in fx16:
+        keys.append("ray_sources")
+    for k in keys:
+        np.testing.assert_array_equal(o[k], fx16["out_" + k], err_msg=k)
+    np.testing.assert_array_equal(o["obs_buf"][:, 4:], fx16["out_obs_buf"][:, 4:])
+    np.testing.assert_allclose(o["obs_buf"][:, :4], fx16["out_obs_buf"][:, :4], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o["rew_buf"], fx16["out_rew_buf"], rtol=1e-6, atol=1e-9)
 
 
 def test_shards_equal_whole():
