@@ -57,6 +57,7 @@ struct rover_ctx {
     bool sorted_valid = false;
     uint32_t run = 16;
     uint64_t workspace_bytes = 0;
+    bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
     bool rays_valid = false;
     // in-situ ray-cast timing (rover_set_profiling)
     bool profiling = false;
@@ -98,10 +99,28 @@ static int fail(rover_ctx* c, int code, const char* fmt, ...) {
         if (e__ != hipSuccess) return fail((c), ROVER_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
-static int use_device(rover_ctx* c) {
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return ROVER_OK;
-}
+// Makes the ctx's device current for the duration of one entry point and restores the caller's device afterwards
+// (the reference's task pins everything to one device, rover.py:90; a library must not change the caller's).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define USE_DEVICE(c)                                                                                          \
+    DeviceGuard device_guard__((c)->cfg.device);                                                               \
+    if (device_guard__.err != hipSuccess)                                                                      \
+        return fail((c), ROVER_E_HIP, "hipSetDevice(%d): %s", (c)->cfg.device, hipGetErrorString(device_guard__.err))
 
 template <typename T>
 static void dfree(T*& p) {
@@ -117,6 +136,7 @@ static int effective_variant(const rover_ctx* c) {
 static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
 
 static int alloc_bins(rover_ctx* c) {
+    c->bins_ok = false;
     if (!c->have_map[0] || !c->have_map[1]) return ROVER_OK;
     const uint64_t nb = (uint64_t)c->map[0].X * c->map[0].Y + (uint64_t)c->map[1].X * c->map[1].Y;
     if (nb > 0xfffffffeull) return fail(c, ROVER_E_INVALID, "too many map cells for ray binning");
@@ -127,11 +147,13 @@ static int alloc_bins(rover_ctx* c) {
         dfree(c->d_bkt_table);
         const uint64_t n_blocks = ((uint64_t)c->cfg.num_envs * c->R8 + 4095) / 4096;
         HIP_TRY(c, hipMalloc((void**)&c->d_bkt_table, ((uint64_t)bucket_count(c) * n_blocks + 1) * sizeof(uint32_t)));
+        c->bins_ok = true;
     }
     return ROVER_OK;
 }
 
 static int alloc_workspace(rover_ctx* c) {
+    c->ws_ok = false;
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_sorted);
     dfree(c->d_env_rec); dfree(c->d_bins); dfree(c->d_pairs);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
@@ -150,6 +172,7 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
     c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (52 * sizeof(float) + sizeof(int64_t));
     c->rays_valid = false;
+    c->ws_ok = true;
     return alloc_bins(c);
 }
 
@@ -175,7 +198,8 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 2) ? x : 0; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
-    e = hipSetDevice(cfg->device);
+    DeviceGuard guard(cfg->device);
+    e = guard.err;
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_block_cnt, ((size_t)cfg->num_envs / 256 + 2) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_goal_work, 2 * (size_t)cfg->num_envs * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ids_work, (size_t)cfg->num_envs * sizeof(int64_t));
@@ -186,7 +210,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->cfg.device);
+    DeviceGuard guard(c->cfg.device);
     for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
@@ -209,7 +233,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     if (X <= 0 || Y <= 0 || K <= 0 || T <= 0 || V <= 0 || !(cell > 0.0f))
         return fail(c, ROVER_E_INVALID, "set_knn_map: bad shape X=%d Y=%d K=%d T=%d V=%d cell=%g", X, Y, K, T, V, (double)cell);
     if ((uint64_t)X * (uint64_t)Y > 0xffffffffull) return fail(c, ROVER_E_INVALID, "set_knn_map: X*Y exceeds 2^32 cells");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     const uint64_t n_cells = (uint64_t)X * Y;
     const uint32_t K8 = (uint32_t)((K + 7) / 8 * 8);
     const uint64_t bytes = n_cells * 9ull * K8 * sizeof(uint16_t);
@@ -247,7 +271,7 @@ int rover_set_distribution(rover_ctx* c, const double* pts, int32_t P, const int
     if (!c) return ROVER_E_INVALID;
     if (!pts || P <= 0 || Ns < 0 || Nd < 0 || (Ns > 0 && !sparse_idx) || (Nd > 0 && !dense_idx))
         return fail(c, ROVER_E_INVALID, "set_distribution: bad arguments (P=%d Ns=%d Nd=%d)", P, Ns, Nd);
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     std::vector<double> hp((size_t)P * 3);
     std::vector<int64_t> hs((size_t)Ns), hd((size_t)Nd);
     HIP_TRY(c, hipMemcpy(hp.data(), pts, hp.size() * sizeof(double), hipMemcpyDefault));
@@ -259,6 +283,7 @@ int rover_set_distribution(rover_ctx* c, const double* pts, int32_t P, const int
     for (int64_t v : hd) idx.push_back((int32_t)v);
     for (int32_t v : idx)
         if (v < 0 || v >= P) return fail(c, ROVER_E_INVALID, "set_distribution: index %d outside [0,%d)", v, P);
+    c->have_dist = false;
     dfree(c->d_dist); dfree(c->d_obs_idx);
     HIP_TRY(c, hipMalloc((void**)&c->d_dist, hp.size() * sizeof(double)));
     HIP_TRY(c, hipMemcpy(c->d_dist, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -272,7 +297,7 @@ int rover_set_distribution(rover_ctx* c, const double* pts, int32_t P, const int
 int rover_set_heightfield(rover_ctx* c, const float* hm, int32_t N0, int32_t N1, float hscale, float vscale, float sx, float sy) {
     if (!c) return ROVER_E_INVALID;
     if (!hm || N0 <= 0 || N1 <= 0 || !(hscale > 0.0f)) return fail(c, ROVER_E_INVALID, "set_heightfield: bad arguments");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     float* d = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d, (uint64_t)N0 * N1 * sizeof(float)));
     hipError_t e = hipMemcpy(d, hm, (uint64_t)N0 * N1 * sizeof(float), hipMemcpyDefault);
@@ -287,7 +312,7 @@ int rover_set_heightfield(rover_ctx* c, const float* hm, int32_t N0, int32_t N1,
 int rover_set_stones(rover_ctx* c, const float* info7, int32_t S) {
     if (!c) return ROVER_E_INVALID;
     if (S < 0 || (S > 0 && !info7)) return fail(c, ROVER_E_INVALID, "set_stones: bad arguments");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     std::vector<float> h((size_t)S * 7);
     if (S) HIP_TRY(c, hipMemcpy(h.data(), info7, h.size() * sizeof(float), hipMemcpyDefault));
     // stone-occupancy grid: 2 m cells over the stones' bounding box padded by r_max + 1.4 m (the largest threshold the
@@ -323,14 +348,20 @@ int rover_set_stones(rover_ctx* c, const float* info7, int32_t S) {
     std::vector<uint32_t> start((size_t)nx * ny + 1, 0), idx;
     for (size_t k = 0; k < lists.size(); ++k) { start[k + 1] = start[k] + (uint32_t)lists[k].size(); idx.insert(idx.end(), lists[k].begin(), lists[k].end()); }
     uint32_t *d_start = nullptr, *d_idx = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_start, start.size() * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&d_idx, (idx.size() + 1) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemcpy(d_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!idx.empty()) HIP_TRY(c, hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    float* d_info = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_start, start.size() * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_idx, (idx.size() + 1) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_info, ((uint64_t)S * 7 + 1) * sizeof(float))) != hipSuccess ||
+        (e = hipMemcpy(d_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (!idx.empty() && (e = hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) ||
+        (S && (e = hipMemcpy(d_info, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)) {
+        dfree(d_start); dfree(d_idx); dfree(d_info);
+        return fail(c, ROVER_E_HIP, "set_stones: %s", hipGetErrorString(e));        // the previous stone tables stay in place
+    }
     dfree(c->d_stones);
     { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); p = const_cast<uint32_t*>(c->sgrid.stone_idx); dfree(p); }
-    HIP_TRY(c, hipMalloc((void**)&c->d_stones, ((uint64_t)S * 7 + 1) * sizeof(float)));
-    if (S) HIP_TRY(c, hipMemcpy(c->d_stones, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->d_stones = d_info;
     c->sgrid = StoneGridDev{d_start, d_idx, x0, y0, 1.0f / cell, nx, ny};
     c->S = S;
     c->have_stones = true;
@@ -355,6 +386,7 @@ static int check_precision(rover_ctx* c) {
 static int check_ready(rover_ctx* c) {
     if (!c->have_map[0] || !c->have_map[1]) return fail(c, ROVER_E_STATE, "terrain and rocks maps must be set (rover_set_knn_map)");
     if (!c->have_dist) return fail(c, ROVER_E_STATE, "ray distribution must be set (rover_set_distribution)");
+    if (!c->ws_ok || !c->bins_ok) return fail(c, ROVER_E_STATE, "the step workspace is not allocated (an earlier rover_set_* call failed)");
     return check_precision(c);
 }
 
@@ -442,7 +474,7 @@ int rover_get_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     if (!c) return ROVER_E_INVALID;
     if (!in || !out) return fail(c, ROVER_E_INVALID, "get_observations: null struct");
     if (int r = check_ready(c)) return r;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     if (int r = do_observations(c, in, out, s)) return r;
     if (!out->rock_collision) return ROVER_OK;
@@ -455,7 +487,7 @@ int rover_calculate_metrics(rover_ctx* c, const rover_step_in* in, const rover_s
     if (!in || !out) return fail(c, ROVER_E_INVALID, "calculate_metrics: null struct");
     if (int r = check_ready(c)) return r;
     if (!c->rays_valid) return fail(c, ROVER_E_STATE, "calculate_metrics: call rover_get_observations first (rover.py:479 reads self.heading_diff)");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     return do_metrics(c, in, out, 0, 0, 1, 0, (hipStream_t)stream);
 }
 
@@ -463,14 +495,14 @@ int rover_is_done(rover_ctx* c, const rover_step_in* in, const rover_step_out* o
     if (!c) return ROVER_E_INVALID;
     if (!in || !out) return fail(c, ROVER_E_INVALID, "is_done: null struct");
     if (int r = check_ready(c)) return r;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     return do_metrics(c, in, out, 0, 0, 0, 1, (hipStream_t)stream);
 }
 
 int rover_compact_resets(rover_ctx* c, const int64_t* reset, int64_t* ids, int32_t* n_reset, void* stream) {
     if (!c) return ROVER_E_INVALID;
     if (!reset || !ids || !n_reset) return fail(c, ROVER_E_INVALID, "compact_resets: null pointer");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     HIP_TRY(c, launch_compact(reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, c->d_block_cnt, false, ids, n_reset,
                               (hipStream_t)stream));
     return ROVER_OK;
@@ -480,7 +512,7 @@ int rover_step(rover_ctx* c, const rover_step_in* in, const rover_step_out* out,
     if (!c) return ROVER_E_INVALID;
     if (!in || !out) return fail(c, ROVER_E_INVALID, "step: null struct");
     if (int r = check_ready(c)) return r;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     if ((flags & ROVER_STEP_COMPACT) && (!out->reset_ids || !out->n_reset))
         return fail(c, ROVER_E_INVALID, "step: ROVER_STEP_COMPACT needs reset_ids and n_reset");
@@ -497,7 +529,7 @@ int rover_quat_to_euler(rover_ctx* c, const float* quat, float* euler, int32_t n
     if (!c) return ROVER_E_INVALID;
     if (!quat || !euler || n < 0) return fail(c, ROVER_E_INVALID, "quat_to_euler: bad arguments");
     if (n == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     HIP_TRY(c, launch_quat_to_euler(quat, euler, (uint32_t)n, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -508,7 +540,7 @@ int rover_clearance(rover_ctx* c, const float* xy, int32_t n, float* out, void* 
     if (!c->have_stones) return fail(c, ROVER_E_STATE, "clearance: rover_set_stones first");
     if (n < 0 || (n > 0 && (!xy || !out))) return fail(c, ROVER_E_INVALID, "clearance: bad arguments");
     if (n == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     HIP_TRY(c, launch_clearance(c->d_stones, (uint32_t)c->S, xy, (uint32_t)n, out, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -518,7 +550,7 @@ int rover_shift_spawns(rover_ctx* c, float* pos3, int32_t n, int32_t max_iter, v
     if (!c->have_stones) return fail(c, ROVER_E_STATE, "shift_spawns: rover_set_stones first");
     if (n < 0 || (n > 0 && !pos3) || max_iter < 0) return fail(c, ROVER_E_INVALID, "shift_spawns: bad arguments");
     if (n == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     HIP_TRY(c, launch_shift_spawns(c->sgrid, c->d_stones, pos3, (uint32_t)n, max_iter, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -528,7 +560,7 @@ int rover_sample_height(rover_ctx* c, const float* xy, int32_t n, float* out, vo
     if (!c->have_hf) return fail(c, ROVER_E_STATE, "sample_height: rover_set_heightfield first");
     if (n < 0 || (n > 0 && (!xy || !out))) return fail(c, ROVER_E_INVALID, "sample_height: bad arguments");
     if (n == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     HIP_TRY(c, launch_sample_height(c->hf, xy, (uint32_t)n, out, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -540,7 +572,7 @@ int rover_generate_goals(rover_ctx* c, const int64_t* env_ids, int32_t n, const 
     if (n < 0 || n > c->cfg.num_envs || (n > 0 && (!env_ids || !initial_pos3 || !target3)) || max_draws <= 0)
         return fail(c, ROVER_E_INVALID, "generate_goals: bad arguments (n=%d, max_draws=%d)", n, max_draws);
     if (n == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     GoalArgs g{c->d_stones, (uint32_t)c->S, c->hf, c->sgrid, env_ids, 0, (uint32_t)n, nullptr, initial_pos3, target3, radius, draws,
                max_draws, seed, (int32_t*)c->d_goal_work, n_draws_used};
     HIP_TRY(c, launch_generate_goals(g, (uint32_t)n, (hipStream_t)stream));
@@ -558,7 +590,7 @@ int rover_reset_envs(rover_ctx* c, const rover_reset_io* io, void* stream) {
     if (io->target3 && (!c->have_stones || !c->have_hf))
         return fail(c, ROVER_E_STATE, "reset_envs: goal validation needs rover_set_stones and rover_set_heightfield");
     if (!io->n_reset_dev && io->n_reset_host == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     ResetArgs a{};
     a.ids = io->reset_ids; a.id_offset = c->cfg.env_offset; a.n_host = (uint32_t)io->n_reset_host; a.n_dev = io->n_reset_dev;
@@ -581,7 +613,7 @@ int rover_pre_physics_step(rover_ctx* c, const float* actions, const float* quat
     if (!c) return ROVER_E_INVALID;
     if (!actions || !lin_hist || !ang_hist) return fail(c, ROVER_E_INVALID, "pre_physics_step: actions and both histories are required");
     if (euler_pre && !quat) return fail(c, ROVER_E_INVALID, "pre_physics_step: euler_pre needs quat");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     PrePhysicsArgs a{(uint32_t)c->cfg.num_envs, actions, quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13};
     HIP_TRY(c, launch_pre_physics(a, (hipStream_t)stream));
     return ROVER_OK;
@@ -591,7 +623,7 @@ int rover_ackermann(rover_ctx* c, const float* lin, const float* ang, int32_t n,
     if (!c) return ROVER_E_INVALID;
     if (n < 0 || (n > 0 && (!lin || !ang || !steering || !velocities))) return fail(c, ROVER_E_INVALID, "ackermann: bad arguments");
     if (n == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     HIP_TRY(c, launch_ackermann(lin, ang, (uint32_t)n, steering, velocities, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -616,7 +648,7 @@ int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const in
         return fail(c, ROVER_E_INVALID, "build_knn_map: bad arguments");
     if (T < K) return fail(c, ROVER_E_INVALID, "build_knn_map: the mesh has %d triangles, fewer than K=%d", T, K);
     if (K > 4096) return fail(c, ROVER_E_INVALID, "build_knn_map: K=%d exceeds the builder's limit of 4096", K);
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     float *d_v = nullptr, *d_cx = nullptr, *d_cy = nullptr;
     int32_t *d_t = nullptr, *d_over = nullptr;
     uint32_t *d_cur = nullptr, *d_items = nullptr, *d_bs = nullptr;
@@ -680,7 +712,7 @@ int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t
     if (!x || !weight || !y || M < 0 || K <= 0 || N <= 0 || N > 256 || x_stride < K || y_stride < N || activation < 0 || activation > 4)
         return fail(c, ROVER_E_INVALID, "linear_forward: bad arguments (M=%d K=%d N=%d act=%d)", M, K, N, activation);
     if (M == 0) return ROVER_OK;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     LinearArgs a{x, x_stride, weight, bias, y, y_stride, M, K, N, activation};
     HIP_TRY(c, launch_linear_act(a, (hipStream_t)stream));
     return ROVER_OK;
@@ -714,7 +746,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
 
 int rover_set_profiling(rover_ctx* c, int32_t enable) {
     if (!c) return ROVER_E_INVALID;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     if (enable && c->ev0.empty()) {
         c->ev0.resize(kProfRing); c->ev1.resize(kProfRing);
         for (int i = 0; i < kProfRing; ++i) { HIP_TRY(c, hipEventCreate(&c->ev0[i])); HIP_TRY(c, hipEventCreate(&c->ev1[i])); }
@@ -727,7 +759,7 @@ int rover_set_profiling(rover_ctx* c, int32_t enable) {
 
 int rover_get_profile(rover_ctx* c, rover_profile* out) {
     if (!c || !out) return ROVER_E_INVALID;
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     if (prof_drain(c)) return fail(c, ROVER_E_HIP, "get_profile: event drain failed");
     out->raycast_ms = c->prof_ms;
     out->launches = c->prof_launches;
@@ -739,7 +771,7 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (!c) return ROVER_E_INVALID;
     if (int r = check_ready(c)) return r;
     if (!c->rays_valid) return fail(c, ROVER_E_STATE, "replay_raycast: no ray records yet (run a step first)");
-    if (int r = use_device(c)) return r;
+    USE_DEVICE(c);
     int v = effective_variant(c);
     if (v == 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
