@@ -220,6 +220,120 @@ def make_scene(n_cells: int = 600, k: int = 200, n_stones: int = 1024, device="c
     )
 
 
+# fp16(-0.1) and fp16(1.1) as exact fractions: the padded barycentric thresholds of ray_casting.py:59 and the
+# values its det / n / m substitutions compare against (:46,:51,:56)
+NEG_EPS_H = 819.0 / 8192.0          # 0.0999755859375
+ONE_EPS_H = 1126.0 / 1024.0         # 1.099609375
+
+
+def make_lattice_scene(k: int = 48, n_cells: int = 64) -> Scene:
+    """Adversarial scene for exact-tie parity: every coordinate is a small dyadic rational, so rays from
+    lattice-aligned poses meet vertices, edges, the padded barycentric thresholds and the reference's
+    ``det ==`` guards EXACTLY (no rounding anywhere in fp32).  On top of a 0.25 m base lattice it holds:
+
+    * S1  a unit right triangle (thresholds n, m = -fp16(0.1) and n + m = fp16(1.1) are hit exactly);
+    * S2 / S3  right triangles whose doubled area is fp16(0.1) / fp16(1.1): |det| of a vertical ray equals the
+      guard constants of ray_casting.py:46,:51,:56;
+    * S4  zero-area and collinear triangles (det = 0); S5 a vertical wall (det = 0 for vertical rays);
+    * every special in both windings, S1 also duplicated (equal distances inside one K list).
+
+    The K nearest centroids per 0.1 m cell are ranked on integer keys, ties by triangle id (deterministic).
+    """
+    nv = 27                                                    # 0 .. 6.5 m at 0.25 m
+    ii, jj = np.meshgrid(np.arange(nv), np.arange(nv), indexing="ij")
+    base = np.zeros((nv * nv, 3), dtype=np.float64)
+    base[:, 0] = (0.25 * ii).reshape(-1)
+    base[:, 1] = (0.25 * jj).reshape(-1)
+    base[:, 2] = np.where((ii + jj) % 3 == 0, 0.125, 0.0).reshape(-1)
+    nc = nv - 1
+    ci, cj = np.meshgrid(np.arange(nc), np.arange(nc), indexing="ij")
+    i0 = (ci * nv + cj).reshape(-1)
+    tris = [np.stack((i0, i0 + nv + 1, i0 + 1), axis=1), np.stack((i0, i0 + nv, i0 + nv + 1), axis=1)]
+    verts = [base]
+    n_v = base.shape[0]
+
+    def add(points, faces):
+        nonlocal n_v
+        verts.append(np.asarray(points, dtype=np.float64))
+        f = np.asarray(faces, dtype=np.int64) + n_v
+        tris.append(f)
+        tris.append(f[:, ::-1].copy())                         # the other winding
+        n_v += len(points)
+
+    z = 0.5
+    add([(1, 1, z), (2, 1, z), (1, 2, z)], [(0, 1, 2), (0, 1, 2)])                                   # S1 (+ duplicate)
+    add([(0.125, 1, z), (0.125 + 819.0 / 1024.0, 1, z), (0.125, 1.125, z)], [(0, 1, 2)])            # S2: 2A = fp16(0.1)
+    add([(0.5, 3, z), (0.5 + ONE_EPS_H, 3, z), (0.5, 4, z)], [(0, 1, 2)])                            # S3: 2A = fp16(1.1)
+    add([(1, 3, z), (1.5, 3, z), (2, 3, z)], [(0, 0, 1), (0, 1, 0), (0, 1, 2)])                       # S4: degenerate
+    add([(2, 2, 0.25), (2, 2.5, 0.25), (2, 2, 1.0), (2, 2.5, 1.0)], [(0, 1, 2), (1, 3, 2)])          # S5: vertical wall
+    v64 = np.concatenate(verts, axis=0)
+    vertices = torch.from_numpy(v64.astype(np.float32)).to(torch.float16)
+    assert bool((vertices.double() == torch.from_numpy(v64)).all()), "lattice vertices must be fp16-exact"
+    t_all = np.concatenate(tris, axis=0).astype(np.int32)
+    triangles = torch.from_numpy(t_all)
+
+    # integer keys: coordinates in units of 2^-13 m, cell positions x * 0.1 m rounded to the same grid
+    q = np.round(v64 * 8192.0).astype(np.int64)
+    c3 = q[t_all[:, 0]] + q[t_all[:, 1]] + q[t_all[:, 2]]                      # 3 x centroid
+    cell = np.round(np.arange(n_cells, dtype=np.float64) * 0.1 * 8192.0).astype(np.int64) * 3
+    n_t = t_all.shape[0]
+    tid = np.arange(n_t, dtype=np.int64)
+    special = tid[2 * nc * nc:]
+    rock_ids = np.concatenate([tid[(tid % 7 == 0) & (tid < 2 * nc * nc)], special])      # rocks map: a sparse subset
+
+    def knn(ids):
+        out = np.empty((n_cells, n_cells, k), dtype=np.int32)
+        cx, cy = c3[ids, 0], c3[ids, 1]
+        for x in range(n_cells):
+            dx2 = (cx - cell[x]) ** 2
+            for y in range(n_cells):
+                key = (dx2 + (cy - cell[y]) ** 2) * n_t + ids
+                out[x, y] = ids[np.argsort(key, kind="stable")[:k]]
+        return torch.from_numpy(out)
+
+    raw = make_stones(8, n_cells * 0.1, seed=5)
+    hm = np.zeros((n_cells * 4, n_cells * 4), dtype=np.float32)
+    return Scene(terrain=KnnMap(knn(tid), triangles, vertices),
+                 rocks=KnnMap(knn(rock_ids), triangles.clone(), vertices.clone()),
+                 stone_info_raw=raw, heightmap=torch.from_numpy(hm))
+
+
+def lattice_distribution():
+    """9 dyadic sample offsets (0, +-0.125)^2, 0.25 m below the body frame; all in the sparse block."""
+    pts = [(dx, dy, -0.25) for dx in (0.0, 0.125, -0.125) for dy in (0.0, 0.125, -0.125)]
+    return (np.asarray(pts, dtype=np.float64), np.arange(9, dtype=np.int64), np.zeros(0, dtype=np.int64))
+
+
+def lattice_states(num_general: int = 24, seed: int = 11):
+    """Identity-orientation poses whose centre ray meets the special spots of :func:`make_lattice_scene` exactly
+    (plus one f32 ulp either side of each threshold), followed by ``num_general`` randomly oriented poses."""
+    f32 = np.float32
+    spots = []
+    for a in range(4):                                          # base lattice: vertices and edge midpoints
+        for b in range(3):
+            spots.append((3.0 + 0.25 * a, 0.5 + 0.125 * b))
+    lo, hi = 1.0 - NEG_EPS_H, 1.0 + 563.0 / 1024.0             # S1: n or m = -fp16(0.1);  n + m = fp16(1.1)
+    for base in (lo, 2.0 + NEG_EPS_H):
+        for v in (np.nextafter(f32(base), f32(-9)), f32(base), np.nextafter(f32(base), f32(9))):
+            spots.append((float(v), 1.25))
+            spots.append((1.25, float(v)))
+    for v in (np.nextafter(f32(hi), f32(-9)), f32(hi), np.nextafter(f32(hi), f32(9)), f32(hi) + f32(2.0 ** -21)):
+        spots.append((float(v), hi))        # + 1 ulp still rounds n + m to fp16(1.1) (tie to even); + 4 ulp does not
+    spots += [(1.0, 1.0), (2.0, 1.0), (1.0, 2.0), (1.5, 1.5), (1.25, 1.25)]         # S1 corners, hypotenuse, inside
+    spots += [(0.25, 1.03125), (0.5, 1.0625)]                                       # S2 (det guard fp16(0.1))
+    spots += [(0.75, 3.25), (1.0, 3.5), (0.5, 3.0)]                                 # S3 (det guard fp16(1.1))
+    spots += [(1.25, 3.0), (1.5, 3.0), (1.0, 3.0)]                                  # S4 degenerate
+    spots += [(2.0, 2.125), (2.0, 2.0), (2.0, 2.5)]                                 # S5 in the wall's plane
+    n_exact = len(spots)
+    st = make_states(n_exact + num_general, 6.4, seed=seed)
+    st["pos"][:n_exact, 0:2] = torch.tensor(spots, dtype=torch.float32)
+    st["pos"][:n_exact, 2] = 1.5
+    st["quat"][:n_exact] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    st["joints"][:n_exact] = 0.0
+    st["pos"][n_exact:, 2] = 1.25
+    return st, n_exact
+
+
 def quat_from_euler(roll, pitch, yaw):
     """(w,x,y,z) of the ZYX rotation; inverse of tensor_quat_to_euler.py:17-29."""
     cr, sr = torch.cos(roll / 2), torch.sin(roll / 2)

@@ -98,6 +98,22 @@ def step_fixture(name, scene, digest, dist_name, num_envs, seed, fp32=True, edge
     save(name, **arrays)
 
 
+def lattice_fixture(name, fp32):
+    """Dyadic scene + lattice-aligned poses: exact hits of vertices, edges, the padded thresholds and the det guards."""
+    kw = dict(kind="lattice", k=48)
+    scene = synth.make_lattice_scene(k=kw["k"])
+    distn = synth.lattice_distribution()
+    st, n_exact = synth.lattice_states()
+    ref = rh.Reference(scene, fp32=fp32, distribution=distn)
+    out = ref.step(st)
+    arrays = {"in_" + k: v for k, v in tonp(st).items()}
+    arrays.update({"out_" + k: v for k, v in tonp(out).items()})
+    arrays.update(distribution=distn[0], sparse_idx=distn[1], dense_idx=distn[2], scene_digest=np.array(scene_digest(scene)),
+                  scene_kw=np.array(repr(kw)), fp32=np.array(fp32), curriculum_level=np.array(2),
+                  num_envs_global=np.array(st["pos"].shape[0]), exact_envs=np.array(n_exact))
+    save(name, **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -120,6 +136,9 @@ def main():
     step_fixture("step_e256_p9_fp16_as_shipped", scene, digest, "9", 256, seed=0, fp32=False)
     step_fixture("step_e64_p120_fp16_as_shipped", scene, digest, "120", 64, seed=2, fp32=False, edges=True)
     step_fixture("step_e8_native_fp16_as_shipped", scene, digest, None, 8, seed=3, fp32=False, native=True)
+
+    lattice_fixture("step_lattice_fp32", fp32=True)
+    lattice_fixture("step_lattice_fp16_as_shipped", fp32=False)
 
     # ---- native distribution table (heightmap_distribution.py:36-115) -----------------------
     ref = rh.Reference(scene, fp32=True)

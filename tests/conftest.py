@@ -34,7 +34,10 @@ def scene_for(fixture):
     kw = ast.literal_eval(str(fixture["scene_kw"]))  # repr of a plain dict of ints written by oracle/gen_golden.py
     key = tuple(sorted(kw.items()))
     if key not in _scene_cache:
-        scene = synth.make_scene(**kw)
+        if kw.get("kind") == "lattice":
+            scene = synth.make_lattice_scene(k=kw["k"])
+        else:
+            scene = synth.make_scene(**kw)
         h = hashlib.sha256()
         for t in (scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices.view(torch.int16),
                   scene.rocks.map_indices, scene.heightmap):
@@ -52,10 +55,10 @@ def states_of(fixture):
 
 
 STEP_FIXTURES_FP32 = ["step_e256_p9_fp32", "step_e64_p37_fp32", "step_e64_p120_fp32", "step_e8_native_fp32",
-                      "step_e64_p37_fp32_level1"]
+                      "step_e64_p37_fp32_level1", "step_lattice_fp32"]
 
 STEP_FIXTURES_AS_SHIPPED = ["step_e64_p37_fp16_as_shipped", "step_e256_p9_fp16_as_shipped", "step_e64_p120_fp16_as_shipped",
-                            "step_e8_native_fp16_as_shipped"]
+                            "step_e8_native_fp16_as_shipped", "step_lattice_fp16_as_shipped"]
 
 # ---- stated parity tolerances, shared by the oracle and the HIP tests ----------
 TOL_SCALAR = 1e-5        # euler / heading / obs[:,0:4] / reward / extras: abs and rel

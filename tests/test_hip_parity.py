@@ -30,6 +30,27 @@ def test_step_matches_reference_golden(name, fused):
     eng.close()
 
 
+@pytest.mark.parametrize("name,precision", [("step_lattice_fp32", "fp32"), ("step_lattice_fp16_as_shipped", "fp16_as_shipped")])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_exact_ties_follow_the_reference(name, precision, variant):
+    """The lattice fixture (exact threshold / det-guard / degenerate-triangle hits, see tests/test_oracle_golden.py):
+    on its rounding-free envs the HIP ray casts equal the reference bit for bit, in both kernels."""
+    from hip_helpers import hip_step, make_engine
+    if precision == "fp16_as_shipped" and variant == 1:
+        pytest.skip("the as-shipped fp16 maths exist in the binned kernel only")
+    fx = load_golden(name)
+    scene = scene_for(fx)
+    st = states_of(fx)
+    eng = make_engine(scene, (fx["distribution"], fx["sparse_idx"], fx["dense_idx"]), st["pos"].shape[0], variant=variant)
+    eng.set_option("ray_precision", {"fp32": 0, "fp16_as_shipped": 2}[precision])
+    out = hip_step(eng, st)
+    n = int(fx["exact_envs"])
+    for key in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
+        np.testing.assert_array_equal(out[key][:n], fx["out_" + key][:n], err_msg=key)
+    np.testing.assert_array_equal(out["obs_buf"][:n, 4:], fx["out_obs_buf"][:n, 4:])
+    eng.close()
+
+
 @pytest.mark.parametrize("dist_name,num_envs,seed", [("37", 4096, 11), ("120", 1024, 12), ("9", 2048, 13)])
 def test_step_matches_oracle(dist_name, num_envs, seed):
     """BASELINE.json configs[1] size (4096 envs, 37 rays) against the CPU oracle on the same seeded inputs."""

@@ -27,6 +27,31 @@ def test_step_matches_reference(name):
     np.testing.assert_array_equal(out["rock_collision"], fx["out_rock_collision"])
 
 
+@pytest.mark.parametrize("name,precision", [("step_lattice_fp32", "fp32"), ("step_lattice_fp16_as_shipped", "fp16_as_shipped")])
+def test_exact_ties_follow_the_reference(name, precision):
+    """Dyadic scene, lattice-aligned poses (synth.make_lattice_scene): rays through vertices / along edges, n, m and
+    n + m exactly ON the padded thresholds and one ulp either side, |det| exactly equal to the guard constants of
+    ray_casting.py:46,:51,:56, zero-area triangles, a wall in the ray's plane.  No rounding happens in fp32 on these
+    envs, so the restatement must equal the reference BIT FOR BIT there (not just within the stated tolerance)."""
+    fx = load_golden(name)
+    scene = scene_for(fx)
+    t, r = _maps(scene)
+    out = orc.step(t, r, states_of(fx), fx["distribution"], fx["sparse_idx"], fx["dense_idx"], precision=precision)
+    n = int(fx["exact_envs"])
+    for key in ("ray_sources", "ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
+        np.testing.assert_array_equal(out[key][:n], fx["out_" + key][:n], err_msg=key)
+    np.testing.assert_array_equal(out["obs_buf"][:n, 4:], fx["out_obs_buf"][:n, 4:])
+    # the cases the scene was built for are really in the fixture
+    d0 = fx["out_ray_dist"][:n, 0]
+    assert (d0 == 0.75).sum() >= 12            # S1 / S2 / S3 hit at z = 0.5 from 1.25 m
+    if precision == "fp32":
+        lo = np.float32(1.0 - 819.0 / 8192.0)
+        x = fx["in_pos"][:n, 0]
+        on, below = np.where(x == lo)[0], np.where(x == np.nextafter(lo, np.float32(-9)))[0]
+        assert len(on) and len(below)
+        assert (d0[on] == 0.75).all() and (d0[below] > 1.0).all()      # n == -fp16(0.1) accepted, one ulp less is not
+
+
 def test_edge_cases_are_exercised():
     fx = load_golden("step_e64_p37_fp32")
     assert fx["out_extras_pos_reward"][0] > 1.0            # goal reached: 1.03*(3000-progress)
