@@ -7,8 +7,8 @@ A "step" is one fused RLTask.post_physics_step (rl_task.py:239-259) over one bat
 that are already resident in HBM: get_observations (P terrain rays + 26 rock rays per rover against the
 K triangles of their 0.1 m cell) + calculate_metrics + is_done + done compaction, through the C ABI
 (rover_step).  Default workload = BASELINE.json configs[2] — the config the north star's >= 4 M env-steps/s
-target is quoted on: 65 536 envs per GPU, 37-point radial heightmap + 26 rock-collision rays, 600 x 600 cell
-maps with K = 200.  For N > 1 every rank runs the same number of envs (weak scaling) and
+target is quoted on: 65 536 envs per GPU, 37-point radial heightmap + 26 rock-collision rays + the stone_info
+occupancy mask, 600 x 600 cell maps with K = 200.  For N > 1 every rank runs the same number of envs (weak scaling) and
 the step ends with the RCCL gather of (obs, reward, done) to rank 0.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -138,7 +138,10 @@ def main():
               for k in _lib.EXTRAS}
     reset_ids = torch.zeros(E, dtype=torch.int64, device=device)
     n_reset = torch.zeros(1, dtype=torch.int32, device=device)
-    sout = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, extras=extras, reset_ids=reset_ids, n_reset=n_reset)
+    # configs[2]/[4]: "+ stone_info collision mask" — the additional occupancy-mask output of the step (margin 0 m)
+    stone_mask = torch.zeros(E, dtype=torch.int64, device=device)
+    sout = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, extras=extras, reset_ids=reset_ids, n_reset=n_reset,
+                        stone_collision=stone_mask, stone_margin=0.0)
     sins = [eng.make_in(b["pos"], b["quat"], b["joints"], b["target"], b["lin_hist"], b["ang_hist"], b["euler_pre"],
                         b["progress"]) for b in batches]
     if args.validate_goals:
@@ -218,7 +221,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{4 if args.validate_goals else 2}]: {E} envs/GPU x {world} GPU, "
                                    f"{args.rays}-point heightmap + 26 rock rays, K={args.k}, {args.cells}x{args.cells} "
-                                   f"cells @0.1 m, stones={args.stones}"
+                                   f"cells @0.1 m, stone_info mask over {args.stones} stones"
                                    + (", + goal validation" if args.validate_goals else "")
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
                                    + (", RCCL gather(obs,rew,done)->rank0" if world > 1 else ""),

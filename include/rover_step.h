@@ -95,6 +95,13 @@ typedef struct {
     float *ray_dist;               /* optional [E,P] Camera.get_depths distances (camera.py:145)          */
     float *wheel_dist;             /* optional [E,24] rock_detect.py:146                                  */
     float *body_dist;              /* optional [E,2]  rock_detect.py:147                                  */
+    /* ADDITIONAL output, not part of the reference's step (its per-step collision term is the ray-based
+     * rock_collision above): the stone_info occupancy mask BASELINE.json configs[2] names.  1 where
+     * nearest_rock(pos_xy) = min_s(|pos_xy - stone_s| - r_s) <= stone_margin, the clearance test of
+     * check_goal_collision / avoid_pos_rock_collision (rover.py:536-539,655-658) applied to the rover itself.
+     * Written by the collision stage (rover_get_observations / rover_step); never feeds reward or done. */
+    int64_t *stone_collision;      /* optional [E]; needs rover_set_stones                                */
+    float stone_margin;            /* metres, <= 1.4 (the reach of the occupancy grid); 0 = centre inside a disc */
 } rover_step_out;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

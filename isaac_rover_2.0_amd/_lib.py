@@ -48,7 +48,7 @@ class StepOut(C.Structure):
                 ("ex_torque_penalty_driving", C.c_void_p), ("ex_torque_penalty_steering", C.c_void_p),
                 ("reset_ids", C.c_void_p), ("n_reset", C.c_void_p), ("euler", C.c_void_p),
                 ("heading_diff", C.c_void_p), ("ray_dist", C.c_void_p), ("wheel_dist", C.c_void_p),
-                ("body_dist", C.c_void_p)]
+                ("body_dist", C.c_void_p), ("stone_collision", C.c_void_p), ("stone_margin", C.c_float)]
 
 
 class Info(C.Structure):
@@ -263,7 +263,8 @@ class Engine:
         return StepIn(*[_ptr(t) for t in (pos, quat, joints, target, lin_hist, ang_hist, euler_pre, progress)])
 
     def make_out(self, obs, rew=None, reset=None, rock_collision=None, extras=None, reset_ids=None, n_reset=None,
-                 euler=None, heading_diff=None, ray_dist=None, wheel_dist=None, body_dist=None):
+                 euler=None, heading_diff=None, ray_dist=None, wheel_dist=None, body_dist=None, stone_collision=None,
+                 stone_margin=0.0):
         e, f, i64 = self.num_envs, torch.float32, torch.int64
         stride = 0
         if obs is not None:
@@ -282,12 +283,14 @@ class Engine:
         self._chk(ray_dist, (e, self.P), f, "ray_dist")
         self._chk(wheel_dist, (e, 24), f, "wheel_dist")
         self._chk(body_dist, (e, 2), f, "body_dist")
+        self._chk(stone_collision, (e,), i64, "stone_collision")
         ex = extras or {}
         for k in EXTRAS:
             self._chk(ex.get(k), (e,), i64 if k == "collision_penalty" else f, "extras." + k)
         return StepOut(_ptr(obs), stride, _ptr(rew), _ptr(reset), _ptr(rock_collision),
                        *[_ptr(ex.get(k)) for k in EXTRAS], _ptr(reset_ids), _ptr(n_reset), _ptr(euler),
-                       _ptr(heading_diff), _ptr(ray_dist), _ptr(wheel_dist), _ptr(body_dist))
+                       _ptr(heading_diff), _ptr(ray_dist), _ptr(wheel_dist), _ptr(body_dist), _ptr(stone_collision),
+                       float(stone_margin))
 
     def step(self, sin: StepIn, sout: StepOut, increment_progress=True, compact=False):
         flags = (STEP_INCREMENT_PROGRESS if increment_progress else 0) | (STEP_COMPACT if compact else 0)

@@ -449,6 +449,10 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     if (met && (!in->joints || !in->lin_hist || !in->ang_hist || !out->rew))
         return fail(c, ROVER_E_INVALID, "calculate_metrics: joints, lin_hist, ang_hist and rew are required");
     if (done && (!in->euler_pre || !out->reset)) return fail(c, ROVER_E_INVALID, "is_done: euler_pre and reset are required");
+    if (coll && out->stone_collision) {
+        if (!c->have_stones) return fail(c, ROVER_E_STATE, "stone_collision: rover_set_stones first");
+        if (!(out->stone_margin <= 1.4f)) return fail(c, ROVER_E_INVALID, "stone_margin %g exceeds the 1.4 m reach of the stone grid", (double)out->stone_margin);
+    }
     MetricsArgs m{};
     m.E = (uint32_t)c->cfg.num_envs; m.R8 = c->R8;
     m.curriculum_level = c->cfg.curriculum_level; m.max_episode_length = c->cfg.max_episode_length;
@@ -465,6 +469,8 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.ex_pos_reward = out->ex_pos_reward; m.ex_collision = out->ex_collision_penalty; m.ex_upright = out->ex_uprightness_penalty;
     m.ex_heading = out->ex_heading_contraint_penalty; m.ex_motion = out->ex_motion_contraint_penalty;
     m.block_cnt = count_done ? c->d_block_cnt : nullptr;
+    m.stone_collision = coll ? out->stone_collision : nullptr; m.stone_margin = out->stone_margin;
+    m.sgrid = c->sgrid; m.info7 = c->d_stones;
     m.ex_goal_angle = out->ex_goal_angle_penalty; m.ex_lin = out->ex_torque_penalty_driving; m.ex_ang = out->ex_torque_penalty_steering;
     HIP_TRY(c, launch_metrics_done(m, s));
     return ROVER_OK;

@@ -71,6 +71,10 @@ struct MetricsArgs {
     int64_t* reset;
     uint32_t* block_cnt;         // optional [ceil(E/256)]: per-block done count for the compaction
     float* ex_pos_reward; int64_t* ex_collision; float *ex_upright, *ex_heading, *ex_motion, *ex_goal_angle, *ex_lin, *ex_ang;
+    int64_t* stone_collision;    // optional additional output: stone_info occupancy mask at pos_xy (collision stage)
+    float stone_margin;
+    StoneGridDev sgrid;
+    const float* info7;
 };
 
 struct ResetArgs {

@@ -371,6 +371,8 @@ __device__ __forceinline__ void block_count_flags(bool flag, uint32_t* __restric
     if (threadIdx.x == 0) block_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
+__device__ __forceinline__ bool collides_grid(const StoneGridDev& g, const float* __restrict__ info7, float x, float y, float thr);
+
 __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t e, bool& done_flag) {
     int64_t progress = (a.do_increment | a.do_metrics | a.do_done) ? a.progress[e] : 0;
     if (a.do_increment) { progress += 1; a.progress[e] = progress; }       // rl_task.py:250
@@ -387,6 +389,10 @@ __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t 
             if (fabsf(mb) < a.body_thr) coll = 1;
         }
         a.rock_collision[e] = coll;
+        // additional output (not in the reference's step): stone_info occupancy mask at the rover's position,
+        // the clearance test of rover.py:536-539 through the stone-occupancy grid
+        if (a.stone_collision)
+            a.stone_collision[e] = collides_grid(a.sgrid, a.info7, a.pos[3ull * e], a.pos[3ull * e + 1], a.stone_margin) ? 1 : 0;
     } else {
         coll = a.rock_collision[e];
     }

@@ -63,10 +63,13 @@ class _Camera:
 
 class RoverTask(RLTask):
     def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
-                 device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0) -> None:
+                 device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0, stone_mask_margin=None) -> None:
         """``scene``: a ``synth.Scene`` (or ``assets.load_reference_assets(root)``) with the terrain / rocks KNN maps,
         stone list and heightfield the reference loads from disk (:92-94,:144,:210).  ``distribution``: optional
-        (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set."""
+        (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set.
+        ``stone_mask_margin``: if not None, every step also fills ``self.stone_collision`` [E] int64 with the stone_info
+        occupancy mask ``nearest_rock(pos_xy) <= margin`` (the clearance of :536-539) — an ADDITIONAL output that
+        the reference's step does not have and that never feeds reward or done."""
         if scene is None:
             raise ValueError("RoverTask needs the terrain assets: pass scene=assets.load_reference_assets(root) "
                              "or a synth.Scene")
@@ -126,6 +129,8 @@ class RoverTask(RLTask):
         self.heading_diff = torch.zeros(e, device=dev)
         self.rover_rot = torch.zeros(e, 3, device=dev)
         self.rock_collison = torch.zeros(e, dtype=torch.long, device=dev)
+        self._stone_margin = stone_mask_margin
+        self.stone_collision = None if stone_mask_margin is None else torch.zeros(e, dtype=torch.long, device=dev)
         self.reset_env_ids_buf = torch.zeros(e, dtype=torch.long, device=dev)
         self._n_reset = torch.zeros(1, dtype=torch.int32, device=dev)
         self._compaction_fresh = False
@@ -171,7 +176,8 @@ class RoverTask(RLTask):
                                 self.progress_buf)
         self._sout = eng.make_out(self.obs_buf, rew=self.rew_buf, reset=self.reset_buf, rock_collision=self.rock_collison,
                                   extras=self.extras, reset_ids=self.reset_env_ids_buf, n_reset=self._n_reset,
-                                  euler=self.rover_rotation, heading_diff=self.heading_diff)
+                                  euler=self.rover_rotation, heading_diff=self.heading_diff,
+                                  stone_collision=self.stone_collision, stone_margin=self._stone_margin or 0.0)
         self.rover_positions = pos
 
     def reset(self):

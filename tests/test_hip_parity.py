@@ -290,6 +290,52 @@ def test_generate_goals_matches_sequential_oracle_random_cases():
         np.testing.assert_allclose(target[:, 0:2].cpu().numpy(), want[:, 0:2], rtol=1e-6, atol=1e-5, err_msg=f"case {case}")
 
 
+def test_stone_mask_matches_reference_clearance():
+    """The additional stone_info occupancy mask of the step (BASELINE.json configs[2]): positions = the query points
+    of the reset-path golden fixture, expected = (the REFERENCE's clearance values <= margin), for the three margins the
+    reference's own tests of that clearance use (0 here, 1.0 rover.py:539, 1.4 rover.py:660).  Exact except where the
+    reference's clearance is within its own cdist tolerance (2e-4) of the margin.  Reward / done are untouched."""
+    from hip_helpers import make_engine
+    from isaac_rover_amd import synth
+    fx = load_golden("reset_path")
+    scene = scene_for(fx)
+    distn = synth.ray_distribution("9")
+    xy = torch.from_numpy(fx["xy"])
+    n = xy.shape[0]
+    st = synth.make_states(n, 12.8, seed=5)
+    st["pos"][:, 0:2] = xy
+    eng = make_engine(scene, distn, n)
+    dev = eng.device
+    d = {k: v.to(dev).contiguous() for k, v in st.items()}
+    sin = eng.make_in(d["pos"], d["quat"], d["joints"], d["target"], d["lin_hist"], d["ang_hist"], d["euler_pre"], d["progress"])
+    base = None
+    for margin in (0.0, 1.0, 1.4):
+        obs = torch.zeros(n, eng.num_observations, device=dev)
+        rew = torch.zeros(n, device=dev)
+        reset = torch.zeros(n, dtype=torch.int64, device=dev)
+        rock = torch.zeros(n, dtype=torch.int64, device=dev)
+        mask = torch.full((n,), -7, dtype=torch.int64, device=dev)
+        sout = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, stone_collision=mask, stone_margin=margin)
+        eng.step(sin, sout, increment_progress=False)
+        torch.cuda.synchronize()
+        want = fx["clearance"] <= margin
+        decided = np.abs(fx["clearance"] - margin) > 2e-4
+        got = mask.cpu().numpy()
+        assert set(np.unique(got)) <= {0, 1}
+        np.testing.assert_array_equal(got[decided] != 0, want[decided])
+        assert want.any() or margin == 0.0
+        cur = (obs.cpu().numpy(), rew.cpu().numpy(), reset.cpu().numpy(), rock.cpu().numpy())
+        if base is not None:
+            for a, b in zip(base, cur):
+                np.testing.assert_array_equal(a, b)
+        base = cur
+    # the mask needs the stone list; a margin beyond the grid's reach is refused
+    bad = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, stone_collision=mask, stone_margin=2.0)
+    with pytest.raises(Exception, match="stone_margin"):
+        eng.step(sin, bad, increment_progress=False)
+    eng.close()
+
+
 def test_reset_envs_with_zero_resets_is_a_no_op():
     """Empty input: no env flagged done -> nothing moves, no goal is redrawn (count read from device memory)."""
     from isaac_rover_amd import _lib, synth
