@@ -89,7 +89,13 @@ def cpu_baseline(args, scene, distn, states):
         best = min(best, time.perf_counter() - t0)
         reps += 1
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": n / best, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": n / best, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": model,
             "sample": f"{n} envs x {reps} reps of the same workload (P={distn[0].shape[0]}, K={args.k}, "
                       f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp"}
 
