@@ -224,7 +224,8 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers
- *        (needs K <= 256 on both maps; the default when it applies).  Both give bit-identical results.
+ *        (needs K <= 256 on both maps).  Both give bit-identical results; auto picks 2 when it applies and a step casts
+ *        more than 131 072 rays (below that the binning passes cost more than they save), or when ray_precision = 2.
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
  *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
  *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.
@@ -232,7 +233,7 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
  *        and fp16 collision thresholds (rover.py:667-668).  Bit-identical to the as-shipped reference on ray origins,
  *        distances, collision mask and done flags (needs ray-cast variant 2).
  * name = "bin_low_bits": width of the low digit of the ray bucket sort, 8..12 (default 10).
- * name = "raycast_run": sorted rays per wave for variant 2 (default 16). */
+ * name = "raycast_run": sorted rays per wave for variant 2 (default 0 = auto: 16 on full batches, down to 4 on small ones). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
 
 /* ---- introspection (bench / roofline) ---------------------------------------------------------------- */

@@ -55,7 +55,7 @@ struct rover_ctx {
     int variant = 0;                    // 0 = auto
     int last_variant = 1;
     bool sorted_valid = false;
-    uint32_t run = 16;
+    uint32_t run = 0;                   // option "raycast_run": 0 = auto (effective_run)
     uint64_t workspace_bytes = 0;
     bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
     bool rays_valid = false;
@@ -127,10 +127,23 @@ static void dfree(T*& p) {
     if (p) { (void)hipFree((void*)p); p = nullptr; }
 }
 
+static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_envs * (26u + (uint64_t)c->P); }
+
+// Auto choice, measured on MI355X at K = 200 (tools/ab_raycast.py --step): below ~128 k rays fewer than one ray shares a
+// cell, so the binning passes cost more than they save and the env-order kernel wins (1 024 envs: 72 vs 84 us per step).
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
+    if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
     return 2;
+}
+
+// Sorted rays per wave.  16 amortises a cell's set-up best on full batches; small batches need more, shorter waves to
+// fill 256 CUs (4 096 envs: run 4 -> 0.2145 ms per step, run 16 -> 0.2264 ms).
+static uint32_t effective_run(const rover_ctx* c) {
+    if (c->run) return c->run;
+    const uint64_t r = valid_rays(c) / 65536u;
+    return (uint32_t)(r < 4 ? 4 : (r > 16 ? 16 : r));
 }
 
 static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
@@ -417,7 +430,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     }
     if (variant == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
-                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->run, c->precision == 2, c->d_dist_out, s));
+                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
                                   (uint32_t)c->map[1].K8, c->d_dist_out, s));
@@ -743,7 +756,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         return alloc_bins(c);
     }
     if (!strcmp(name, "raycast_run")) {
-        if (value < 1 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be in [1, 4096]");
+        if (value < 0 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be 0 (auto) or in [1, 4096]");
         c->run = (uint32_t)value;
         return ROVER_OK;
     }
@@ -784,7 +797,7 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (v == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
-                                         (uint32_t)c->map[1].K8, c->run, c->precision == 2, c->d_dist_out, s));
+                                         (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
                                   (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, s));

@@ -31,7 +31,7 @@ def test_step_matches_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("name,precision", [("step_lattice_fp32", "fp32"), ("step_lattice_fp16_as_shipped", "fp16_as_shipped")])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [2, 1])
 def test_exact_ties_follow_the_reference(name, precision, variant):
     """The lattice fixture (exact threshold / det-guard / degenerate-triangle hits, see tests/test_oracle_golden.py):
     on its rounding-free envs the HIP ray casts equal the reference bit for bit, in both kernels."""
@@ -179,7 +179,7 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
     r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices, shift=shift[0:2])
     want = orc.step(t, r, st, *distn)
     results = []
-    for variant in (0, 1):
+    for variant in (2, 1):
         eng = _lib.Engine(num_envs, device=0)
         eng.set_scene(scene, distn)
         eng.set_option("raycast_variant", variant)
@@ -190,6 +190,28 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
         eng.close()
     for k in results[0]:
         np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+
+
+def test_auto_variant_and_run_selection():
+    """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the binned kernel above and whenever the
+    as-shipped fp16 maths are asked for; K8 > 256 always falls back to the env-order kernel."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=64, k=16, n_stones=8)
+    distn = synth.ray_distribution("37")
+    small = make_engine(scene, distn, 256, variant=None)
+    assert small.info().raycast_variant == 1
+    small.set_option("ray_precision", 2)
+    assert small.info().raycast_variant == 2
+    big = make_engine(scene, distn, 4096, variant=None)
+    assert big.info().raycast_variant == 2
+    st = synth.make_states(4096, 6.4, seed=3)
+    a = hip_step(big, st)                                   # auto run length
+    big.set_option("raycast_run", 16)
+    b = hip_step(big, st)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    small.close(); big.close()
 
 
 def test_nan_pose_does_not_fault():

@@ -9,10 +9,8 @@ from isaac_rover_amd import _lib, synth
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-ARMS = [dict(raycast_variant=2, raycast_run=16, bin_low_bits=10), dict(raycast_variant=2, raycast_run=24, bin_low_bits=10),
-        dict(raycast_variant=2, raycast_run=32, bin_low_bits=10), dict(raycast_variant=2, raycast_run=48, bin_low_bits=10),
-        dict(raycast_variant=2, raycast_run=32, bin_low_bits=9), dict(raycast_variant=2, raycast_run=32, bin_low_bits=11),
-        dict(raycast_variant=2, raycast_run=32, bin_low_bits=12)]
+ARMS = [dict(raycast_variant=2, raycast_run=16), dict(raycast_variant=1, raycast_run=16), dict(raycast_variant=2, raycast_run=8),
+        dict(raycast_variant=2, raycast_run=4)]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
 distn = synth.ray_distribution("37")
