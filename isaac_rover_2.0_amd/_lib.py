@@ -260,7 +260,10 @@ class Engine:
                         (euler_pre, (e, 3), "euler_pre")):
             self._chk(t, s, f, n)
         self._chk(progress, (e,), torch.int64, "progress")
-        return StepIn(*[_ptr(t) for t in (pos, quat, joints, target, lin_hist, ang_hist, euler_pre, progress)])
+        tensors = (pos, quat, joints, target, lin_hist, ang_hist, euler_pre, progress)
+        sin = StepIn(*[_ptr(t) for t in tensors])
+        sin._keep = tensors          # the struct holds raw device pointers: keep the tensors alive as long as it lives
+        return sin
 
     def make_out(self, obs, rew=None, reset=None, rock_collision=None, extras=None, reset_ids=None, n_reset=None,
                  euler=None, heading_diff=None, ray_dist=None, wheel_dist=None, body_dist=None, stone_collision=None,
@@ -287,10 +290,13 @@ class Engine:
         ex = extras or {}
         for k in EXTRAS:
             self._chk(ex.get(k), (e,), i64 if k == "collision_penalty" else f, "extras." + k)
-        return StepOut(_ptr(obs), stride, _ptr(rew), _ptr(reset), _ptr(rock_collision),
+        sout = StepOut(_ptr(obs), stride, _ptr(rew), _ptr(reset), _ptr(rock_collision),
                        *[_ptr(ex.get(k)) for k in EXTRAS], _ptr(reset_ids), _ptr(n_reset), _ptr(euler),
                        _ptr(heading_diff), _ptr(ray_dist), _ptr(wheel_dist), _ptr(body_dist), _ptr(stone_collision),
                        float(stone_margin))
+        sout._keep = (obs, rew, reset, rock_collision, dict(ex), reset_ids, n_reset, euler, heading_diff, ray_dist, wheel_dist,
+                      body_dist, stone_collision)
+        return sout
 
     def step(self, sin: StepIn, sout: StepOut, increment_progress=True, compact=False):
         flags = (STEP_INCREMENT_PROGRESS if increment_progress else 0) | (STEP_COMPACT if compact else 0)
