@@ -56,6 +56,7 @@ struct rover_ctx {
     int last_variant = 1;
     bool sorted_valid = false;
     uint32_t run = 0;                   // option "raycast_run": 0 = auto (effective_run)
+    uint32_t early_out = 1;             // option "raycast_early_out": conservative whole-pair rejection (bit-identical results)
     uint64_t workspace_bytes = 0;
     bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
     bool rays_valid = false;
@@ -430,7 +431,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     }
     if (variant == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
-                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->d_dist_out, s));
+                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
                                   (uint32_t)c->map[1].K8, c->d_dist_out, s));
@@ -755,6 +756,11 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->low_bits = (uint32_t)value;
         return alloc_bins(c);
     }
+    if (!strcmp(name, "raycast_early_out")) {
+        if (value < 0 || value > 1) return fail(c, ROVER_E_INVALID, "raycast_early_out must be 0 or 1");
+        c->early_out = (uint32_t)value;
+        return ROVER_OK;
+    }
     if (!strcmp(name, "raycast_run")) {
         if (value < 0 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be 0 (auto) or in [1, 4096]");
         c->run = (uint32_t)value;
@@ -797,7 +803,7 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (v == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
-                                         (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->d_dist_out, s));
+                                         (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
     else
         HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
                                   (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, s));

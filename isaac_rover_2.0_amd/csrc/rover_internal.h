@@ -121,7 +121,7 @@ hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* t
 hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_valid, uint32_t n_bins, uint32_t low_bits,
                            uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, hipStream_t s);
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
-                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, float* out,
+                                 const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, uint32_t early_out, float* out,
                                  hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, float* cx, float* cy, hipStream_t s);
 hipError_t launch_knn_bucket(const float* cx, const float* cy, uint32_t T, float ox, float oy, float inv_g, uint32_t nbx, uint32_t nby,

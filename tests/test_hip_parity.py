@@ -76,18 +76,20 @@ def test_step_matches_oracle(dist_name, num_envs, seed):
                                                   ("9", 200, 16)])
 def test_raycast_variants_bit_identical(dist_name, num_envs, k):
     """Variant 1 (half-wave per ray, env order) and variant 2 (rays binned by cell, shared-reciprocal IEEE division,
-    any run length) must agree bit for bit, and with the oracle's ray maths given the same rays."""
+    any run length, early out on or off) must agree bit for bit, and with the oracle's ray maths given the same rays."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=k, n_stones=24)
     distn = synth.ray_distribution(dist_name)
     st = synth.make_states(num_envs, 6.4, seed=21)
     ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
-    for variant in (2,):
-        for run in (1, 5, 16, 64):
-            got = hip_step(make_engine(scene, distn, num_envs, variant=variant, run=run), st)
-            for key in ref:
-                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} run={run}")
+    for run, early_out in ((1, 1), (5, 0), (16, 1), (16, 0), (64, 1)):
+        eng = make_engine(scene, distn, num_envs, variant=2, run=run)
+        eng.set_option("raycast_early_out", early_out)       # conservative whole-pair rejection: same bits on or off
+        got = hip_step(eng, st)
+        for key in ref:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run} early_out={early_out}")
+        eng.close()
 
 
 def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
@@ -190,6 +192,29 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
         eng.close()
     for k in results[0]:
         np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+@pytest.mark.parametrize("k", [200, 40])
+def test_early_out_changes_no_bit(precision, k):
+    """The conservative whole-pair rejection of the binned kernels (f32 and as-shipped fp16) on a batch large enough to
+    hit its margins from both sides: every distance identical with the option off."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=96, k=k, n_stones=40)
+    distn = synth.ray_distribution("120")
+    st = synth.make_states(3000, 9.6, seed=77)
+    st["quat"] = synth.quat_from_euler(0.5 * torch.randn(3000), 0.5 * torch.randn(3000), 3.0 * torch.randn(3000))   # steep tilts
+    outs = []
+    for early_out in (1, 0):
+        eng = make_engine(scene, distn, 3000)
+        eng.set_option("ray_precision", precision)
+        eng.set_option("raycast_early_out", early_out)
+        outs.append(hip_step(eng, st))
+        eng.close()
+    for key in outs[0]:
+        np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
+    assert (outs[0]["ray_dist"] < 11.0).mean() > 0.5
 
 
 def test_auto_variant_and_run_selection():

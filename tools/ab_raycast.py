@@ -9,8 +9,9 @@ from isaac_rover_amd import _lib, synth
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-ARMS = [dict(raycast_variant=2, raycast_run=16), dict(raycast_variant=1, raycast_run=16), dict(raycast_variant=2, raycast_run=8),
-        dict(raycast_variant=2, raycast_run=4)]
+# keys starting with ENV_ set / clear an environment variable the launcher reads (experiments only)
+ARMS = [dict(raycast_variant=2, ENV_ROVER_PRE_BITS="0"), dict(raycast_variant=2, ENV_ROVER_PRE_BITS=None),
+        dict(raycast_variant=2, ENV_ROVER_PRE_BITS="10"), dict(raycast_variant=2, ENV_ROVER_PRE_BITS="15")]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
 distn = synth.ray_distribution("37")
@@ -27,7 +28,13 @@ times = {i: [] for i in range(len(ARMS))}
 for r in range(ROUNDS + 2):
     for i, arm in enumerate(ARMS):
         for k, v in arm.items():
-            eng.set_option(k, v)
+            if k.startswith("ENV_"):
+                if v is None:
+                    os.environ.pop(k[4:], None)
+                else:
+                    os.environ[k[4:]] = v
+            else:
+                eng.set_option(k, v)
         eng.step(sin, sout, compact=True)      # (re)build this arm's ray records / bins
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
