@@ -36,8 +36,11 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll-ms", type=float, default=400.0,
+                    help="untimed load before the warm-up steps so that the GPU clocks have ramped (DVFS: the first ~60 ms of "
+                         "load run up to 30 %% slower, measured with --debug-timing); 0 disables")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--rays", default="37", choices=["9", "37", "120"])
     ap.add_argument("--cells", type=int, default=600)
@@ -176,6 +179,15 @@ def main():
     # Event timing is switched on BEFORE the warm-up: the first timed hipEventRecord on a stream makes the runtime
     # enable queue profiling once (tens of ms); the warm-up absorbs that, then the counters are reset.
     eng.set_profiling(True)
+    if args.preroll_ms > 0:                  # clock ramp: not part of the W warm-up steps or the K timed steps
+        t_pre, i_pre = time.perf_counter(), 0
+        while time.perf_counter() - t_pre < args.preroll_ms * 1e-3:      # local compute only: no collective, so the
+            for _ in range(8):                                           # ranks need not agree on the iteration count
+                eng.step(sins[i_pre % len(sins)], sout, increment_progress=True, compact=True)
+                i_pre += 1
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
     for i in range(args.warmup):
         one_step(i)
     fence()

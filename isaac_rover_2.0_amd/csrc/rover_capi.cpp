@@ -229,7 +229,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
-    { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); p = const_cast<uint32_t*>(c->sgrid.stone_idx); dfree(p); }
+    { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); float4* q = const_cast<float4*>(c->sgrid.stone_xyr); dfree(q); }
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
     dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
     dfree(c->d_block_cnt);
@@ -361,20 +361,27 @@ int rover_set_stones(rover_ctx* c, const float* info7, int32_t S) {
     }
     std::vector<uint32_t> start((size_t)nx * ny + 1, 0), idx;
     for (size_t k = 0; k < lists.size(); ++k) { start[k + 1] = start[k] + (uint32_t)lists[k].size(); idx.insert(idx.end(), lists[k].begin(), lists[k].end()); }
-    uint32_t *d_start = nullptr, *d_idx = nullptr;
+    std::vector<float4> xyr(idx.size() + 1);
+    for (size_t k = 0; k < idx.size(); ++k) {
+        const uint32_t sidx = idx[k];
+        float fid; memcpy(&fid, &sidx, sizeof fid);
+        xyr[k] = float4{h[7 * (size_t)sidx], h[7 * (size_t)sidx + 1], h[7 * (size_t)sidx + 6], fid};
+    }
+    uint32_t* d_start = nullptr;
+    float4* d_idx = nullptr;
     float* d_info = nullptr;
     hipError_t e;
     if ((e = hipMalloc((void**)&d_start, start.size() * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void**)&d_idx, (idx.size() + 1) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_idx, xyr.size() * sizeof(float4))) != hipSuccess ||
         (e = hipMalloc((void**)&d_info, ((uint64_t)S * 7 + 1) * sizeof(float))) != hipSuccess ||
         (e = hipMemcpy(d_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
-        (!idx.empty() && (e = hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) ||
+        (e = hipMemcpy(d_idx, xyr.data(), xyr.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
         (S && (e = hipMemcpy(d_info, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)) {
         dfree(d_start); dfree(d_idx); dfree(d_info);
         return fail(c, ROVER_E_HIP, "set_stones: %s", hipGetErrorString(e));        // the previous stone tables stay in place
     }
     dfree(c->d_stones);
-    { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); p = const_cast<uint32_t*>(c->sgrid.stone_idx); dfree(p); }
+    { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); float4* q = const_cast<float4*>(c->sgrid.stone_xyr); dfree(q); }
     c->d_stones = d_info;
     c->sgrid = StoneGridDev{d_start, d_idx, x0, y0, 1.0f / cell, nx, ny};
     c->S = S;

@@ -30,7 +30,7 @@ struct HeightDev {
 // stone-occupancy grid (built on the host at rover_set_stones): CSR lists of the stones that can matter per grid cell
 struct StoneGridDev {
     const uint32_t* cell_start;  // [nx*ny + 1]
-    const uint32_t* stone_idx;
+    const float4* stone_xyr;     // per list entry: (x, y, radius, stone id as float bits) — one independent 16-B load per stone
     float x0, y0, inv_cell;
     int32_t nx, ny;
 };

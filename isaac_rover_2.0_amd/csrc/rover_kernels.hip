@@ -534,11 +534,17 @@ __device__ __forceinline__ bool collides_grid(const StoneGridDev& g, const float
     if (!(fx >= 0.0f) || !(fy >= 0.0f) || !(fx < (float)g.nx) || !(fy < (float)g.ny)) return false;   // also NaN
     uint32_t c = (uint32_t)fx * (uint32_t)g.ny + (uint32_t)fy;
     uint32_t k0 = g.cell_start[c], k1 = g.cell_start[c + 1];
-    for (uint32_t k = k0; k < k1; ++k) {
-        const float* r = info7 + 7ull * g.stone_idx[k];
-        float dx = x - r[0], dy = y - r[1];
-        float d = sqrtf(dx * dx + dy * dy) - r[6];                          // rover.py:536-537 / :655-656
-        if (d <= thr) return true;
+    (void)info7;
+    for (uint32_t k = k0; k < k1; k += 4u) {                                // 4 independent 16-B loads in flight per trip
+        bool hit = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const float4 r = g.stone_xyr[min(k + j, k1 - 1u)];                 // past the end: the last entry again
+            float dx = x - r.x, dy = y - r.y;
+            float d = sqrtf(dx * dx + dy * dy) - r.z;                       // rover.py:536-537 / :655-656
+            hit |= d <= thr;
+        }
+        if (hit) return true;
     }
     return false;
 }
@@ -615,22 +621,46 @@ __device__ __forceinline__ float height_at(const HeightDev& h, float x, float y)
     return h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
 }
 
+// GOAL_LANES lanes share one entry and test GOAL_LANES consecutive draws at once (the first clear one wins, exactly what the
+// sequential loop finds): with dense stones most draws collide and the per-entry chain of draw -> grid lookup was the cost.
+#define GOAL_LANES 8u
+
 __global__ void __launch_bounds__(256) goals_draw_kernel(GoalArgs a) {
     const uint32_t n = a.n_dev ? (uint32_t)max(*a.n_dev, 0) : a.n_host;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const int64_t id = a.env_ids[i] - a.id_offset;
-    if (id == 0) { a.t_acc[i] = -1; return; }                                // zero-id entry from the start
-    int32_t t = 0, t_acc = a.max_draws;
-    float x = 0.0f, y = 0.0f;
-    for (; t < a.max_draws; ++t) {
-        float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed, (uint32_t)t, i);
-        goal_from_draw(u, a.radius, a.initial_pos3, id, x, y);
-        if (!collides_grid(a.grid, a.info7, x, y, 1.0f)) { t_acc = t; break; }   // :539: redraw while nearest_rock <= 1.0
+    const uint32_t gt = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = gt / GOAL_LANES, j = gt % GOAL_LANES;
+    const uint32_t shift = (threadIdx.x & 63u) & ~(GOAL_LANES - 1u);             // first lane of this entry's group
+    const bool live = i < n;
+    const int64_t id = live ? a.env_ids[i] - a.id_offset : 0;
+    if (live && id == 0 && j == 0) a.t_acc[i] = -1;                            // zero-id entry from the start
+    bool active = live && id != 0;
+    // whole waves iterate together (ballot); finished / idle groups just stop contributing
+    for (int32_t t0 = 0; t0 < a.max_draws; t0 += (int32_t)GOAL_LANES) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        const int32_t t = t0 + (int32_t)j;
+        bool clear = false;
+        float x = 0.0f, y = 0.0f;
+        if (active && t < a.max_draws) {
+            float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed, (uint32_t)t, i);
+            goal_from_draw(u, a.radius, a.initial_pos3, id, x, y);
+            clear = !collides_grid(a.grid, a.info7, x, y, 1.0f);               // :539: redraw while nearest_rock <= 1.0
+        }
+        const uint32_t m = (uint32_t)(__builtin_amdgcn_ballot_w64(clear) >> shift) & ((1u << GOAL_LANES) - 1u);
+        if (active) {
+            const bool last_trip = t0 + (int32_t)GOAL_LANES >= a.max_draws;
+            int32_t winner = -1;                                               // lane of the group whose draw is kept
+            if (m) winner = (int32_t)__builtin_ctz(m);
+            else if (last_trip) winner = a.max_draws - 1 - t0;                 // never clear: the last draw stays (t_acc = max)
+            if (winner >= 0) {
+                if ((int32_t)j == winner) {
+                    a.t_acc[i] = m ? t : a.max_draws;
+                    a.target3[3ull * id] = x; a.target3[3ull * id + 1] = y;
+                    a.target3[3ull * id + 2] = height_at(a.h, x, y);            // set_targets :581-583
+                }
+                active = false;
+            }
+        }
     }
-    a.t_acc[i] = t_acc;
-    a.target3[3ull * id] = x; a.target3[3ull * id + 1] = y;
-    a.target3[3ull * id + 2] = height_at(a.h, x, y);                        // set_targets :581-583
 }
 
 __global__ void __launch_bounds__(1024) goals_env0_kernel(GoalArgs a) {
@@ -640,35 +670,71 @@ __global__ void __launch_bounds__(1024) goals_env0_kernel(GoalArgs a) {
     if (n == 0) { if (tid == 0 && a.n_draws_used) *a.n_draws_used = 0; return; }
     if (tid == 0) { s_tmax = -1; s_lz = -1; s_has_zero = 0; s_fail = 0; }
     __syncthreads();
+    // per-thread partial results, one wave reduction, one LDS atomic per wave (n can be all 65 536 envs)
+    int my_tmax = -1;
+    bool my_zero = false, my_fail = false;
     for (uint32_t i = tid; i < n; i += blockDim.x) {
         int32_t t = a.t_acc[i];
-        if (t >= a.max_draws) s_fail = 1;
-        else if (t < 0) s_has_zero = 1;
-        else atomicMax(&s_tmax, t);
+        if (t >= a.max_draws) my_fail = true;
+        else if (t < 0) my_zero = true;
+        else my_tmax = max(my_tmax, t);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_tmax = max(my_tmax, __shfl_xor(my_tmax, o));
+    const bool w_zero = __builtin_amdgcn_ballot_w64(my_zero) != 0, w_fail = __builtin_amdgcn_ballot_w64(my_fail) != 0;
+    if ((tid & 63u) == 0u) {
+        if (my_tmax >= 0) atomicMax(&s_tmax, my_tmax);
+        if (w_zero) s_has_zero = 1;
+        if (w_fail) s_fail = 1;
     }
     __syncthreads();
     if (s_fail) { if (tid == 0 && a.n_draws_used) *a.n_draws_used = -1; return; }
     const int tmax = s_tmax;                          // -1 when every entry was a zero-id entry
     // zero-id set before the draw of iteration max(tmax, 0): original zeros and entries accepted earlier
+    int my_lz = -1;
     for (uint32_t i = tid; i < n; i += blockDim.x) {
         int32_t t = a.t_acc[i];
-        if (t < 0 || t < tmax) atomicMax(&s_lz, (int)i);
+        if (t < 0 || t < tmax) my_lz = max(my_lz, (int)i);
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_lz = max(my_lz, __shfl_xor(my_lz, o));
+    if ((tid & 63u) == 0u && my_lz >= 0) atomicMax(&s_lz, my_lz);
     __syncthreads();
-    if (tid != 0) return;
-    int32_t t = max(tmax, 0), used = -1;
-    int lz = s_lz;
+    if (tid >= 64u) return;
+    // env 0's own sequence, 64 iterations per trip on one wave: iteration t0 is written by entry lz, every later one by
+    // entry n - 1 (from iteration tmax + 1 on every entry has id 0); the first clear draw ends the loop.
+    const int32_t t0 = max(tmax, 0);
+    const int lz0 = s_lz;
+    int32_t used = -1;
     float x = 0.0f, y = 0.0f;
     bool wrote = false;
-    while (t < a.max_draws) {
-        if (lz < 0) { used = t + 1; break; }          // nobody writes env 0 in this iteration: bad == 0
-        float u = a.draws ? a.draws[(uint64_t)t * n + (uint32_t)lz] : philox_uniform(a.seed, (uint32_t)t, (uint32_t)lz);
-        goal_from_draw(u, a.radius, a.initial_pos3, 0, x, y);
-        wrote = true;
-        if (!collides_grid(a.grid, a.info7, x, y, 1.0f)) { used = t + 1; break; }
-        ++t;
-        lz = (int)n - 1;                              // from iteration tmax+1 on every entry has id 0
+    if (lz0 < 0) {
+        used = t0 + 1;                                // nobody writes env 0 in this iteration: bad == 0
+    } else {
+        for (int32_t base = t0; base < a.max_draws; base += 64) {
+            const int32_t t = base + (int32_t)tid;
+            const uint32_t src = (t == t0) ? (uint32_t)lz0 : n - 1u;
+            bool clear = false;
+            float cx = 0.0f, cy = 0.0f;
+            if (t < a.max_draws) {
+                float u = a.draws ? a.draws[(uint64_t)t * n + src] : philox_uniform(a.seed, (uint32_t)t, src);
+                goal_from_draw(u, a.radius, a.initial_pos3, 0, cx, cy);
+                clear = !collides_grid(a.grid, a.info7, cx, cy, 1.0f);
+            }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(clear);
+            const bool last_trip = base + 64 >= a.max_draws;
+            int32_t winner = -1;
+            if (m) winner = (int32_t)__builtin_ctzll(m);
+            else if (last_trip) winner = a.max_draws - 1 - base;
+            if (winner >= 0) {
+                x = __shfl(cx, winner); y = __shfl(cy, winner);
+                wrote = true;
+                if (m) used = base + winner + 1;
+                break;
+            }
+        }
     }
+    if (tid != 0) return;
     if (wrote) {
         a.target3[0] = x; a.target3[1] = y;
         if (s_has_zero) a.target3[2] = height_at(a.h, x, y);               // env 0 was listed: set_targets :581-583
@@ -1454,7 +1520,7 @@ hipError_t launch_sample_height(const HeightDev& h, const float* xy, uint32_t n,
 }
 
 hipError_t launch_generate_goals(const GoalArgs& a, uint32_t n_max, hipStream_t s) {
-    hipLaunchKernelGGL(goals_draw_kernel, dim3(blocks_for(n_max, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(goals_draw_kernel, dim3(blocks_for((uint64_t)n_max * GOAL_LANES, 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(goals_env0_kernel, dim3(1), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
