@@ -10,8 +10,7 @@ from isaac_rover_amd import _lib, synth
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 # keys starting with ENV_ set / clear an environment variable the launcher reads (experiments only)
-ARMS = [dict(raycast_variant=2, ENV_ROVER_PRE_BITS="0"), dict(raycast_variant=2, ENV_ROVER_PRE_BITS=None),
-        dict(raycast_variant=2, ENV_ROVER_PRE_BITS="10"), dict(raycast_variant=2, ENV_ROVER_PRE_BITS="15")]
+ARMS = [dict(raycast_variant=2, raycast_early_out=0), dict(raycast_variant=2, raycast_early_out=1)]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
 distn = synth.ray_distribution("37")
