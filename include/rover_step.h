@@ -236,7 +236,7 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
  * name = "raycast_early_out": 1 (default) = the binned kernel drops a whole packed pair of triangles per lane (the far half
  *        of a cell's K-nearest list; on the rocks map also the near half) when a conservative test on the numerators shows that
  *        every triangle of it fails the barycentric test; results are bit-identical with 0 (A/B and tests).
- * name = "raycast_run": sorted rays per wave for variant 2 (default 0 = auto: 16 on full batches, down to 4 on small ones). */
+ * name = "raycast_run": sorted rays per wave for variant 2 (default 0 = auto: 32 on full batches, down to 4 on small ones). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
 
 /* ---- introspection (bench / roofline) ---------------------------------------------------------------- */

@@ -139,12 +139,13 @@ static int effective_variant(const rover_ctx* c) {
     return 2;
 }
 
-// Sorted rays per wave.  16 amortises a cell's set-up best on full batches; small batches need more, shorter waves to
-// fill 256 CUs (4 096 envs: run 4 -> 0.2145 ms per step, run 16 -> 0.2264 ms).
+// Sorted rays per wave.  Long runs amortise a cell's set-up (65 536 envs, ray cast only: run 12 -> 1.183 ms, 16 -> 1.171,
+// 24 -> 1.153, 32 -> 1.144, 64 -> 1.150); small batches need more, shorter waves to fill 256 CUs (4 096 envs: run 4 ->
+// 0.2145 ms per step, run 16 -> 0.2264 ms).
 static uint32_t effective_run(const rover_ctx* c) {
     if (c->run) return c->run;
     const uint64_t r = valid_rays(c) / 65536u;
-    return (uint32_t)(r < 4 ? 4 : (r > 16 ? 16 : r));
+    return (uint32_t)(r < 4 ? 4 : (r > 32 ? 32 : r));
 }
 
 static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
