@@ -9,7 +9,8 @@ K triangles of their 0.1 m cell) + calculate_metrics + is_done + done compaction
 (rover_step).  Default workload = BASELINE.json configs[2] — the config the north star's >= 4 M env-steps/s
 target is quoted on: 65 536 envs per GPU, 37-point radial heightmap + 26 rock-collision rays + the stone_info
 occupancy mask, 600 x 600 cell maps with K = 200.  For N > 1 every rank runs the same number of envs (weak scaling) and
-the step ends with the RCCL gather of (obs, reward, done) to rank 0.
+every step hands (obs, reward, done) to rank 0 with one grouped RCCL send/recv; by default that transfer runs on
+RCCL's stream under the kernels of the next step (double-buffered outputs; --sync-gather serialises it).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     — the ray-cast kernel: algorithmic bytes (18 B per ray-triangle pair) / HIP-event time vs 8 TB/s
@@ -51,6 +52,9 @@ def parse():
     ap.add_argument("--ray-precision", default="fp32", choices=["fp32", "fp16_sources", "fp16_as_shipped"],
                     help="fp32 = the reference's fp32 mode (default, the north star's parity mode); fp16_as_shipped = bit-identical to the "
                          "reference as shipped (Camera.dtype = float16)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: wait for the RCCL gather of a step before the next step starts (default: the gather of step i "
+                         "runs on RCCL's stream under the kernels of step i + 1, double-buffered outputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-timing", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
@@ -140,8 +144,9 @@ def main():
     for b in range(4):
         st = synth.make_states(E, args.cells * 0.1, seed=100 * rank + b)
         batches.append({k: v.to(device) for k, v in st.items()})
-    gather = StepGather(E, W, device, world, rank)
-    obs, rew, reset = gather.local_views()
+    overlap = world > 1 and not args.sync_gather and not args.validate_goals
+    depth = 2 if overlap else 1
+    gather = StepGather(E, W, device, world, rank, depth=depth)
     rock = torch.zeros(E, dtype=torch.int64, device=device)
     extras = {k: torch.zeros(E, dtype=(torch.int64 if k == "collision_penalty" else torch.float32), device=device)
               for k in _lib.EXTRAS}
@@ -149,8 +154,13 @@ def main():
     n_reset = torch.zeros(1, dtype=torch.int32, device=device)
     # configs[2]/[4]: "+ stone_info collision mask" — the additional occupancy-mask output of the step (margin 0 m)
     stone_mask = torch.zeros(E, dtype=torch.int64, device=device)
-    sout = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, extras=extras, reset_ids=reset_ids, n_reset=n_reset,
-                        stone_collision=stone_mask, stone_margin=0.0)
+    souts = []
+    for d in range(depth):
+        obs_d, rew_d, reset_d = gather.local_views(d)
+        souts.append(eng.make_out(obs_d, rew=rew_d, reset=reset_d, rock_collision=rock, extras=extras, reset_ids=reset_ids,
+                                  n_reset=n_reset, stone_collision=stone_mask, stone_margin=0.0))
+    sout = souts[0]
+    obs, rew, reset = gather.local_views(0)
     sins = [eng.make_in(b["pos"], b["quat"], b["joints"], b["target"], b["lin_hist"], b["ang_hist"], b["euler_pre"],
                         b["progress"]) for b in batches]
     if args.validate_goals:
@@ -160,7 +170,10 @@ def main():
 
     def one_step(i):
         b = i % len(batches)
-        eng.step(sins[b], sout, increment_progress=True, compact=True)
+        d = i % depth
+        gather.wait(d)                       # overlapped mode: the transfer that last read buffer set d must be through
+        eng.step(sins[b], souts[d], increment_progress=True, compact=True)
+        gather.gather(d, wait=not overlap)   # (obs, rew, done) of this step to the learner rank
         if args.validate_goals:
             # configs[4]: reset_idx + set_targets (goal re-draw + stone-clearance validation + goal z) for the envs the
             # step flagged done, consuming the compacted ids on the device — no host sync (rover.py:356-361 has one)
@@ -168,9 +181,10 @@ def main():
             eng.reset_envs(reset_ids, initial[b], st["pos"], st["quat"], reset, st["progress"], n_reset_dev=n_reset,
                            joint_pos13=st["joints"], joint_vel13=joint_vel, target3=st["target"], radius=8.0, seed=i,
                            max_draws=256, n_draws_used=n_used)
-        gather.gather()
 
     def fence():
+        for d in range(depth):
+            gather.wait(d)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -242,7 +256,8 @@ def main():
                                    f"cells @0.1 m, stone_info mask over {args.stones} stones"
                                    + (", + goal validation" if args.validate_goals else "")
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
-                                   + (", RCCL gather(obs,rew,done)->rank0" if world > 1 else ""),
+                                   + ((", RCCL gather(obs,rew,done)->rank0" + (" overlapped with the next step" if overlap else ""))
+                                      if world > 1 else ""),
                        "envs_total": E_global, "rays_per_env": int(args.rays) + 26, "obs_dim": W,
                        "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(int(args.rays), args.k, eng.Ns, eng.Nd),
                        "table_bytes": int(info.table_bytes[0] + info.table_bytes[1])},

@@ -163,6 +163,27 @@ for step in range(3):
         assert D.dtype == torch.int64
     else:
         assert out is None
+# overlapped mode: two buffer sets, the transfer of step i is only waited for when set i % 2 is needed again
+g2 = StepGather(E, W, "cpu", world, rank, depth=2)
+for step in range(5):
+    d = step % 2
+    g2.wait(d)
+    if rank == 0 and step >= 2:                      # the learner reads step - 2 before the set is overwritten
+        O, R, D = g2.global_views(d)
+        allids = torch.arange(E * world, dtype=torch.float32)
+        assert torch.equal(O, allids[:, None] * 10 + torch.arange(W) + (step - 2))
+        assert torch.equal(D, (torch.arange(E * world) + step - 2) % 2)
+    obs, rew, reset = g2.local_views(d)
+    ids = torch.arange(lo, hi, dtype=torch.float32)
+    obs.copy_(ids[:, None] * 10 + torch.arange(W) + step)
+    rew.copy_(ids + 0.5 * step)
+    reset.copy_((torch.arange(lo, hi) + step) % 2)
+    g2.gather(d, wait=False)
+for d in range(2):
+    g2.wait(d)
+if rank == 0:
+    O, R, D = g2.global_views(0)
+    assert torch.equal(R, torch.arange(E * world, dtype=torch.float32) + 0.5 * 4)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
