@@ -49,7 +49,7 @@ struct rover_ctx {
     uint2* d_pairs = nullptr;           // [E*R8] (bin, slot) after the coarse partition
     uint32_t low_bits = 10;             // option "bin_low_bits"
     int precision = 0;                  // option "ray_precision": 0 fp32 mode, 1 fp16 sources, 2 as shipped (fp16 maths)
-    uint32_t* d_block_sums = nullptr;   // [8192]
+    uint32_t* d_block_sums = nullptr;   // [4096] bucket totals + [4097] bucket starts
     uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
     uint32_t n_bins = 0;
     int variant = 0;                    // 0 = auto
@@ -157,7 +157,7 @@ static int alloc_bins(rover_ctx* c) {
     if (nb > 0xfffffffeull) return fail(c, ROVER_E_INVALID, "too many map cells for ray binning");
     c->n_bins = (uint32_t)nb;
     while (c->low_bits < 12u && bucket_count(c) > 4096u) ++c->low_bits;
-    if (!c->d_block_sums) HIP_TRY(c, hipMalloc((void**)&c->d_block_sums, 8192 * sizeof(uint32_t)));
+    if (!c->d_block_sums) HIP_TRY(c, hipMalloc((void**)&c->d_block_sums, (2 * 4096 + 8) * sizeof(uint32_t)));   // bucket totals + bucket starts
     if (c->have_dist) {                                   // table size depends on E*R8 too
         dfree(c->d_bkt_table);
         const uint64_t n_blocks = ((uint64_t)c->cfg.num_envs * c->R8 + 4095) / 4096;

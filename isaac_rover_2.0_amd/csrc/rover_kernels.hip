@@ -908,7 +908,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __rest
 
 // ---- bucket sort of the ray slots by bin = (map, cell), without global atomics ------------------------------------
 //   bucket_hist_kernel     per 4096-slot block: LDS histogram over the coarse buckets (bin >> low_bits) -> counts[bucket][block]
-//   (exclusive scan of counts, bucket-major: every bucket becomes one contiguous range)
+//   bucket_rowscan_kernel  one workgroup per bucket: exclusive prefix along its row of block counts + the bucket total
+//                          (the scan over the bucket totals is redone by every scatter block in LDS: <= 4096 values)
 //   bucket_scatter_kernel  same blocks: (bin, slot) pairs to their bucket range, position from an LDS cursor per bucket
 //   bucket_sort_kernel     one workgroup per bucket: LDS counting sort on the low bits -> sorted slot ids
 // The order of equal bins is whatever the LDS atomics produce; the ray cast does not depend on it.
@@ -931,11 +932,44 @@ __global__ void __launch_bounds__(256) bucket_hist_kernel(const uint32_t* __rest
     for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) counts[(size_t)i * n_blocks + blockIdx.x] = h[i];
 }
 
+// counts[bucket][block] -> exclusive prefix inside every bucket row (one workgroup per bucket) + the row total
+__global__ void __launch_bounds__(256) bucket_rowscan_kernel(uint32_t* __restrict__ counts, uint32_t n_blocks,
+                                                             uint32_t* __restrict__ bucket_tot) {
+    __shared__ uint32_t wl[4];
+    uint32_t* row = counts + (size_t)blockIdx.x * n_blocks;
+    const uint32_t per = (n_blocks + 255u) >> 8, first = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_blocks) ? row[first + j] : 0u;
+    uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
+    for (uint32_t j = 0; j < per; ++j) {
+        if (first + j < n_blocks) { const uint32_t c = row[first + j]; row[first + j] = run; run += c; }
+    }
+    if (threadIdx.x == 0) bucket_tot[blockIdx.x] = total;
+}
+
+// every block turns the bucket totals into bucket start offsets in LDS (n_buckets <= 4096: 16 values per thread);
+// block 0 also publishes them (plus the grand total) for bucket_sort_kernel
 __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
                                                              uint32_t n_buckets, uint32_t n_blocks, const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ bucket_tot, uint32_t* __restrict__ bucket_base,
                                                              uint2* __restrict__ pairs) {
     __shared__ uint32_t cur[BKT_MAX];
-    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) cur[i] = offsets[(size_t)i * n_blocks + blockIdx.x];
+    __shared__ uint32_t wl[4];
+    {
+        const uint32_t per = (n_buckets + 255u) >> 8, first = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_buckets) ? bucket_tot[first + j] : 0u;
+        uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t i = first + j;
+            if (i < n_buckets) {
+                cur[i] = run + offsets[(size_t)i * n_blocks + blockIdx.x];
+                if (blockIdx.x == 0) bucket_base[i] = run;
+                run += bucket_tot[i];
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) bucket_base[n_buckets] = total;
+    }
     __syncthreads();
     const uint32_t base = blockIdx.x * BKT_TILE;
 #pragma unroll 4
@@ -948,13 +982,12 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
     }
 }
 
-__global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ offsets,
-                                                          uint32_t n_blocks, uint32_t n_buckets, uint32_t n_total, uint32_t low_bits,
-                                                          uint32_t* __restrict__ sorted) {
+__global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ bucket_base,
+                                                          uint32_t low_bits, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t h[BKT_MAX];
     __shared__ uint32_t wl[4];
     const uint32_t b = blockIdx.x, tid = threadIdx.x, nl = 1u << low_bits, mask = nl - 1u;
-    const uint32_t s0 = offsets[(size_t)b * n_blocks], s1 = (b + 1u < n_buckets) ? offsets[(size_t)(b + 1u) * n_blocks] : n_total;
+    const uint32_t s0 = bucket_base[b], s1 = bucket_base[b + 1u];
     if (s1 <= s0) return;
     for (uint32_t i = tid; i < nl; i += 256) h[i] = 0;
     __syncthreads();
@@ -1416,11 +1449,14 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
     const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
     if (low_bits < 8u || low_bits > 12u || n_buckets > BKT_MAX) return hipErrorInvalidValue;
     const uint32_t n_blocks = blocks_for(n_slots, BKT_TILE);
+    (void)n_valid;
+    uint32_t* bucket_tot = block_sums;                 // [BKT_MAX]
+    uint32_t* bucket_base = block_sums + BKT_MAX;      // [BKT_MAX + 1]
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table);
-    hipError_t e = launch_scan_exclusive(table, n_buckets * n_blocks, block_sums, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table, pairs);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(256), 0, s, pairs, table, n_blocks, n_buckets, n_valid, low_bits, sorted);
+    hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(n_buckets), dim3(256), 0, s, table, n_blocks, bucket_tot);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table,
+                       bucket_tot, bucket_base, pairs);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(256), 0, s, pairs, bucket_base, low_bits, sorted);
     return hipGetLastError();
 }
 
