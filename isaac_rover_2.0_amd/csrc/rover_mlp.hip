@@ -8,7 +8,8 @@
 // (pointer, row stride) so a layer reads an obs slice and writes straight into the concat buffer (no torch.cat).
 // f32-input MFMA (v_mfma_f32_32x32x2_f32): exact f32 products, one rounding per accumulate — fp32 like the reference's
 // nn.Linear, at the matrix pipe's f32 rate.  A workgroup = 4 waves x 32 rows; A (128 x 32) and W (N x 32) k-slabs are
-// staged through LDS with a 33-word pitch (conflict-free column reads); each wave keeps N/32 accumulator tiles.
+// staged through LDS with a 33-word pitch (conflict-free column reads), the next slab prefetched into registers while the
+// current one is multiplied; each wave keeps N/32 accumulator tiles.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rover_internal.h"
@@ -17,7 +18,6 @@ namespace rover {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define MLP_BM 128
 #define MLP_BK 32
 #define MLP_PITCH 33
 #define MLP_MAX_NT 8          // N <= 256
@@ -32,31 +32,49 @@ __device__ __forceinline__ float mlp_act(float v, int act) {
     }
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256) linear_act_kernel(LinearArgs a) {
-    __shared__ float As[MLP_BM * MLP_PITCH];
+// NW waves per workgroup, 32 rows each: 4 for large batches, 1 when M / 128 workgroups would leave most of the 256 CUs idle
+template <int NT, int NW>
+__global__ void __launch_bounds__(64 * NW) linear_act_kernel(LinearArgs a) {
+    constexpr uint32_t BM = 32u * NW, RSTEP = 2u * NW;               // rows per workgroup; rows staged per pass
+    __shared__ float As[BM * MLP_PITCH];
     __shared__ float Ws[NT * 32 * MLP_PITCH];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t row0 = blockIdx.x * MLP_BM;
+    const uint32_t row0 = blockIdx.x * BM, n0 = blockIdx.y * (NT * 32u);     // blockIdx.y: column tile (small-batch launch)
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const uint32_t ar = lane & 31u, ak = lane >> 5;                  // A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
+    // k-slab staging: thread (r = tid / 32 + RSTEP j, c = tid % 32) — 128-byte coalesced rows, zero-padded past M / N / K.
+    // The slab for step s + 1 is fetched into registers while step s is multiplied out of LDS (one LDS buffer, two syncs).
+    const uint32_t sc = tid & 31u, sr = tid >> 5;
+    float pa[BM / RSTEP], pw[NT * 32 / RSTEP];
+    auto fetch = [&](uint32_t k0) {
+        const uint32_t gk = k0 + sc;
+        const bool kin = gk < (uint32_t)a.K;
+#pragma unroll
+        for (int j = 0; j < (int)(BM / RSTEP); ++j) {
+            const uint32_t gr = row0 + sr + RSTEP * j;
+            pa[j] = (kin && gr < (uint32_t)a.M) ? a.x[(size_t)gr * a.x_stride + gk] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(NT * 32 / RSTEP); ++j) {
+            const uint32_t n = n0 + sr + RSTEP * j;
+            pw[j] = (kin && n < (uint32_t)a.N) ? a.w[(size_t)n * a.K + gk] : 0.0f;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < (int)(BM / RSTEP); ++j) As[(sr + RSTEP * j) * MLP_PITCH + sc] = pa[j];
+#pragma unroll
+        for (int j = 0; j < (int)(NT * 32 / RSTEP); ++j) Ws[(sr + RSTEP * j) * MLP_PITCH + sc] = pw[j];
+    };
+    fetch(0);
     for (uint32_t k0 = 0; k0 < (uint32_t)a.K; k0 += MLP_BK) {
-        // stage the k-slab: rows x 32 contiguous floats (128 B per row, coalesced), zero-padded past M / N / K
-        for (uint32_t e = tid; e < MLP_BM * MLP_BK; e += 256) {
-            uint32_t r = e >> 5, c = e & 31u;
-            uint32_t gr = row0 + r, gk = k0 + c;
-            As[r * MLP_PITCH + c] = (gr < (uint32_t)a.M && gk < (uint32_t)a.K) ? a.x[(size_t)gr * a.x_stride + gk] : 0.0f;
-        }
-        for (uint32_t e = tid; e < NT * 32 * MLP_BK; e += 256) {
-            uint32_t n = e >> 5, c = e & 31u;
-            uint32_t gk = k0 + c;
-            Ws[n * MLP_PITCH + c] = (n < (uint32_t)a.N && gk < (uint32_t)a.K) ? a.w[(size_t)n * a.K + gk] : 0.0f;
-        }
+        stash();
         __syncthreads();
+        if (k0 + MLP_BK < (uint32_t)a.K) fetch(k0 + MLP_BK);           // in flight during the MFMAs below
 #pragma unroll 4
         for (uint32_t kk = 0; kk < MLP_BK; kk += 2) {
             const float av = As[(wave * 32u + ar) * MLP_PITCH + kk + ak];
@@ -71,7 +89,7 @@ __global__ void __launch_bounds__(256) linear_act_kernel(LinearArgs a) {
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const uint32_t col = t * 32u + (lane & 31u);
+        const uint32_t col = n0 + t * 32u + (lane & 31u);
         if (col >= (uint32_t)a.N) continue;
         const float bias = a.b ? a.b[col] : 0.0f;
 #pragma unroll
@@ -82,20 +100,30 @@ __global__ void __launch_bounds__(256) linear_act_kernel(LinearArgs a) {
     }
 }
 
-hipError_t launch_linear_act(const LinearArgs& a, hipStream_t s) {
-    const uint32_t nb = (uint32_t)((a.M + MLP_BM - 1) / MLP_BM);
+template <int NW>
+static hipError_t launch_linear_nw(const LinearArgs& a, hipStream_t s) {
+    const uint32_t nb = (uint32_t)((a.M + 32 * NW - 1) / (32 * NW));
     const int nt = (a.N + 31) / 32;
     switch (nt) {
-        case 1: hipLaunchKernelGGL(linear_act_kernel<1>, dim3(nb), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(linear_act_kernel<2>, dim3(nb), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(linear_act_kernel<3>, dim3(nb), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(linear_act_kernel<4>, dim3(nb), dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL(linear_act_kernel<5>, dim3(nb), dim3(256), 0, s, a); break;
-        case 6: hipLaunchKernelGGL(linear_act_kernel<6>, dim3(nb), dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL(linear_act_kernel<7>, dim3(nb), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(linear_act_kernel<8>, dim3(nb), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((linear_act_kernel<1, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((linear_act_kernel<2, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((linear_act_kernel<3, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((linear_act_kernel<4, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((linear_act_kernel<5, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((linear_act_kernel<6, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((linear_act_kernel<7, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((linear_act_kernel<8, NW>), dim3(nb), dim3(64 * NW), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_act(const LinearArgs& a, hipStream_t s) {
+    // 128-row workgroups holding all N columns need M >= 128 * 512 rows to put two of them on each of the 256 CUs; below that
+    // one wave per workgroup and one 32-column tile per workgroup (grid.y), e.g. 4 096 x 80 -> 128 x 3 workgroups
+    if (a.M >= 128 * 512) return launch_linear_nw<4>(a, s);
+    if (a.N > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((linear_act_kernel<1, 1>), dim3((uint32_t)((a.M + 31) / 32), (uint32_t)((a.N + 31) / 32)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -526,7 +526,7 @@ def _torch_net_reference(net, states):
     return run(net.network, torch.cat((states[:, 0:p], x0, x1), dim=1))
 
 
-@pytest.mark.parametrize("num_envs,ns,nd", [(300, 634, 1112), (4096, 37, 0 + 5), (1, 9, 3)])
+@pytest.mark.parametrize("num_envs,ns,nd", [(300, 634, 1112), (4096, 37, 0 + 5), (1, 9, 3), (65536 + 100, 37, 5)])
 def test_policy_forward_matches_torch_fp32(num_envs, ns, nd):
     """f-4: actor and critic forward (f32 MFMA linear layers reading obs slices in place) vs a PyTorch fp32 reference."""
     from isaac_rover_amd import _lib
@@ -558,7 +558,8 @@ def test_linear_forward_shapes_and_activations(act):
     import torch.nn.functional as F
     eng = _lib.Engine(8, device=0)
     g = torch.Generator().manual_seed(3)
-    for m, k, n in ((257, 33, 1), (64, 634, 80), (130, 5, 256), (31, 1112, 80)):
+    # m >= 65 536 takes the 128-row workgroups (all columns per workgroup), smaller m the 32 x 32 tiles
+    for m, k, n in ((257, 33, 1), (64, 634, 80), (130, 5, 256), (31, 1112, 80), (65536 + 77, 40, 100), (65536, 70, 256)):
         wide = torch.randn(m, k + 9, generator=g).cuda()
         x = wide[:, 4:4 + k]
         w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
