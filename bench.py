@@ -43,7 +43,8 @@ def parse():
                     help="untimed load before the warm-up steps so that the GPU clocks have ramped (DVFS: the first ~60 ms of "
                          "load run up to 30 %% slower, measured with --debug-timing); 0 disables")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
-    ap.add_argument("--rays", default="37", choices=["9", "37", "120"])
+    ap.add_argument("--rays", default="37", choices=["9", "37", "120", "native"],
+                    help="BASELINE ray sets; native = the reference's own 1634-point distribution (1750-float obs)")
     ap.add_argument("--cells", type=int, default=600)
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--stones", type=int, default=1024)
@@ -132,7 +133,12 @@ def main():
     E = args.envs_per_gpu
     E_global = E * world
     scene = load_scene(args, device)
-    distn = synth.ray_distribution(args.rays)
+    if args.rays == "native":
+        from isaac_rover_amd.tasks.utils.heightmap_distribution import generate_native
+        distn = tuple(np.asarray(x) for x in generate_native())
+    else:
+        distn = synth.ray_distribution(args.rays)
+    n_rays = int(distn[0].shape[0])
     eng = _lib.Engine(E, device=local_rank, num_envs_global=E_global, env_offset=rank * E)
     eng.set_scene(scene, distn)
     eng.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[args.ray_precision])
@@ -258,8 +264,8 @@ def main():
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
                                    + ((", RCCL gather(obs,rew,done)->rank0" + (" overlapped with the next step" if overlap else ""))
                                       if world > 1 else ""),
-                       "envs_total": E_global, "rays_per_env": int(args.rays) + 26, "obs_dim": W,
-                       "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(int(args.rays), args.k, eng.Ns, eng.Nd),
+                       "envs_total": E_global, "rays_per_env": n_rays + 26, "obs_dim": W,
+                       "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(n_rays, args.k, eng.Ns, eng.Nd),
                        "table_bytes": int(info.table_bytes[0] + info.table_bytes[1])},
             "roofline": {"bound": "hbm", "kernel": "raycast_binned_kernel" if info.raycast_variant == 2 else "raycast_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
