@@ -126,3 +126,25 @@ def build_knn_map(engine, vertices, triangles, n_cells: int = 600, res: float = 
     idx = engine.build_knn_map(vertices, triangles, n_cells, n_cells, res, k)
     return KnnMap(idx.cpu(), torch.as_tensor(np.asarray(triangles), dtype=torch.int32),
                   torch.as_tensor(np.asarray(vertices), dtype=torch.float32).to(torch.float16), res)
+
+
+def generate_knn_triangles(engine, terrain_dir: str, res_x: int = 600, res_y: int = 600, res: float = 0.1,
+                           n_triangles: int = 200, files=(("map.ply", "knn_terrain"), ("big_stones.ply", "knn_rocks"))):
+    """``generate_knn_triangles`` of the reference (rover_utils.py:48-50): for ``map.ply`` and ``big_stones.ply`` in
+    ``terrain_dir`` build the K-nearest-triangle map on the GPU and write ``map_indices.pt`` [K,X,Y] int32,
+    ``vertices.pt`` fp16 and ``triangles.pt`` int32 into ``knn_terrain/`` and ``knn_rocks/`` (rover_utils.py:113-118) —
+    the files ``Camera`` / ``Rock_Detection`` (and ``load_reference_assets`` here) open.  No open3d / pymeshlab needed.
+    Returns {sub-directory: KnnMap}."""
+    if res_x != res_y:
+        raise ValueError("the reference's maps are square (camera.py:243 clamps both axes with the dim-0 size)")
+    out = {}
+    for ply, sub in files:
+        vertices, triangles = load_ply(os.path.join(terrain_dir, ply))
+        m = build_knn_map(engine, vertices, triangles, n_cells=res_x, res=res, k=n_triangles)
+        d = os.path.join(terrain_dir, sub)
+        os.makedirs(d, exist_ok=True)
+        torch.save(m.map_indices.permute(2, 0, 1).contiguous().to(torch.int32), os.path.join(d, "map_indices.pt"))
+        torch.save(m.vertices.to(torch.float16), os.path.join(d, "vertices.pt"))
+        torch.save(m.triangles.to(torch.int32), os.path.join(d, "triangles.pt"))
+        out[sub] = m
+    return out

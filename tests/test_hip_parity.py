@@ -512,6 +512,53 @@ def test_built_map_drives_the_step():
     assert (got["ray_dist"] < 11.0).mean() > 0.5
 
 
+def _write_binary_ply(path, verts, tris):
+    with open(path, "wb") as fh:
+        fh.write(f"ply\nformat binary_little_endian 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\n"
+                 f"property float z\nelement face {len(tris)}\nproperty list uchar int vertex_indices\nend_header\n".encode())
+        fh.write(np.asarray(verts, "<f4").tobytes())
+        rec = np.zeros(len(tris), dtype=[("n", "u1"), ("i", "<i4", 3)])
+        rec["n"] = 3
+        rec["i"] = tris
+        fh.write(rec.tobytes())
+
+
+def test_generate_knn_triangles_from_ply(tmp_path):
+    """f-3 end to end: map.ply + big_stones.ply -> knn_terrain/ + knn_rocks/ in the reference's on-disk format
+    (rover_utils.py:48-50,113-118) -> load_reference_assets -> a step equal to the one on the maps built in memory."""
+    from hip_helpers import hip_step
+    from isaac_rover_amd import _lib, assets, synth
+    verts, tris, _ = synth.grid_mesh(41, seed=4)
+    rock_tris = tris[::5]
+    terrain_dir = tmp_path / "tasks" / "utils" / "terrain"
+    terrain_dir.mkdir(parents=True)
+    _write_binary_ply(terrain_dir / "map.ply", verts, tris)
+    _write_binary_ply(terrain_dir / "big_stones.ply", verts, rock_tris)
+    eng = _lib.Engine(32, device=0)
+    maps = assets.generate_knn_triangles(eng, str(terrain_dir), res_x=40, res_y=40, res=0.1, n_triangles=24)
+    raw = torch.load(terrain_dir / "knn_terrain" / "map_indices.pt")
+    assert tuple(raw.shape) == (24, 40, 40) and raw.dtype == torch.int32                       # [K, X, Y] like :108,116
+    assert torch.load(terrain_dir / "knn_rocks" / "vertices.pt").dtype == torch.float16
+    base = synth.make_scene(n_cells=40, k=24, n_stones=6, seed=4)
+    np.save(terrain_dir / "stone_info.npy", base.stone_info_raw)
+    torch.save(base.heightmap, terrain_dir / "heightmap_tensor.pt")
+    scene = assets.load_reference_assets(str(tmp_path))
+    assert torch.equal(scene.terrain.map_indices, maps["knn_terrain"].map_indices)
+    assert torch.equal(scene.rocks.triangles, torch.as_tensor(rock_tris, dtype=torch.int32))
+    distn = synth.ray_distribution("9")
+    st = synth.make_states(32, 4.0, seed=6)
+    eng.set_scene(scene, distn)
+    a = hip_step(eng, st)
+    mem = synth.Scene(terrain=maps["knn_terrain"], rocks=maps["knn_rocks"], stone_info_raw=base.stone_info_raw, heightmap=base.heightmap)
+    eng2 = _lib.Engine(32, device=0)
+    eng2.set_scene(mem, distn)
+    b = hip_step(eng2, st)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert (a["ray_dist"] < 11.0).mean() > 0.5
+    eng.close(); eng2.close()
+
+
 def _torch_net_reference(net, states):
     """fp32 PyTorch restatement of model.py:185-195 on the same weights."""
     import torch.nn.functional as F
