@@ -108,6 +108,28 @@ def cpu_baseline(args, scene, distn, states):
                       f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp"}
 
 
+# The three touch points with the GPU runtime, as functions so that tests/test_host_logic.py can drive main()'s N > 1 control
+# flow (rank bookkeeping, overlapped gather, max-over-ranks timing, the JSON line) on CPU with gloo and a stand-in engine.
+def _device(local_rank):
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rover step path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    return torch.device("cuda", local_rank)
+
+
+def _init_process_group(dist, device):
+    dist.init_process_group("nccl", device_id=device)
+
+
+def _make_engine(num_envs, local_rank, num_envs_global, env_offset):
+    from isaac_rover_amd import _lib
+    return _lib.Engine(num_envs, device=local_rank, num_envs_global=num_envs_global, env_offset=env_offset)
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,15 +139,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the rover step path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = _device(local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        _init_process_group(dist, device)
 
     from isaac_rover_amd import _lib, synth
     from isaac_rover_amd.distributed import StepGather
@@ -139,7 +158,7 @@ def main():
     else:
         distn = synth.ray_distribution(args.rays)
     n_rays = int(distn[0].shape[0])
-    eng = _lib.Engine(E, device=local_rank, num_envs_global=E_global, env_offset=rank * E)
+    eng = _make_engine(E, local_rank, E_global, rank * E)
     eng.set_scene(scene, distn)
     eng.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[args.ray_precision])
     info = eng.info()
@@ -191,10 +210,10 @@ def main():
     def fence():
         for d in range(depth):
             gather.wait(d)
-        torch.cuda.synchronize()
+        _sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            _sync()
 
     # Event timing is switched on BEFORE the warm-up: the first timed hipEventRecord on a stream makes the runtime
     # enable queue profiling once (tens of ms); the warm-up absorbs that, then the counters are reset.
@@ -205,7 +224,7 @@ def main():
             for _ in range(8):                                           # ranks need not agree on the iteration count
                 eng.step(sins[i_pre % len(sins)], sout, increment_progress=True, compact=True)
                 i_pre += 1
-            torch.cuda.synchronize()
+            _sync()
         if world > 1:
             dist.barrier()
     for i in range(args.warmup):

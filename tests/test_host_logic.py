@@ -203,3 +203,68 @@ def test_gather_world_size_2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+_BENCH_WORKER = r"""
+import os, sys, json, types, torch
+root = os.environ["ROVER_ROOT"]
+sys.path.insert(0, root)
+import bench
+
+class FakeEngine:
+    # stands in for _lib.Engine: same call surface as bench.py uses, writes recognisable values with torch on CPU
+    def __init__(self, n, rank_offset):
+        self.n, self.off, self.num_observations, self.Ns, self.Nd, self.P = n, rank_offset, 41, 37, 0, 37
+        self.steps = 0
+    def set_scene(self, scene, distn): pass
+    def set_option(self, k, v): pass
+    def info(self): return types.SimpleNamespace(table_bytes=[1, 1], raycast_variant=2)
+    def make_in(self, *t): return t
+    def make_out(self, obs, **kw): return dict(obs=obs, **kw)
+    def step(self, sin, sout, increment_progress=True, compact=False):
+        self.steps += 1
+        ids = torch.arange(self.off, self.off + self.n, dtype=torch.float32)
+        sout["obs"].copy_(ids[:, None] + 0.001 * self.steps)
+        sout["rew"].copy_(ids)
+        sout["reset"].copy_((torch.arange(self.off, self.off + self.n) + self.steps) % 2)
+    def reset_envs(self, *a, **k): pass
+    def set_profiling(self, on): pass
+    def get_profile(self): return types.SimpleNamespace(raycast_ms=1.0 * self.steps, launches=self.steps, pairs_per_launch=self.n * 63 * 200)
+
+bench._device = lambda local_rank: torch.device("cpu")
+bench._init_process_group = lambda dist, device: dist.init_process_group("gloo")
+bench._make_engine = lambda n, local_rank, n_global, off: FakeEngine(n, off)
+bench._sync = lambda: None
+bench.load_scene = lambda args, device: None
+sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "7", "--warmup", "3", "--envs-per-gpu", "64",
+            "--preroll-ms", "20"] + os.environ.get("BENCH_EXTRA", "").split()
+bench.main()
+print("rank", os.environ["RANK"], "done")
+"""
+
+
+@pytest.mark.parametrize("extra", ["", "--sync-gather"])
+def test_bench_distributed_control_flow_gloo(tmp_path, extra):
+    """bench.py's N > 1 path (rank bookkeeping, pre-roll without collectives, overlapped / blocking gather, barrier + max over
+    ranks, ONE JSON line on rank 0) driven on CPU: gloo, 2 processes, a stand-in engine.  Guards the multi-GPU run the driver
+    does at round end against Python-level mistakes; the kernels and RCCL are not involved."""
+    import json
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER)
+    port = 31000 + (os.getpid() % 2000) + (7 if extra else 0)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ROVER_ROOT=ROOT, BENCH_EXTRA=extra)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} done" in o
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not any(l.startswith("{") for l in outs[1].splitlines())
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 3 and d["scaling"] == "weak" and d["config"]["envs_total"] == 128
+    assert d["value"] > 0 and abs(d["value"] - 128 * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
+    assert ("overlapped" in d["config"]["workload"]) == (extra == "")
+    assert "cpu_baseline" not in d and set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
