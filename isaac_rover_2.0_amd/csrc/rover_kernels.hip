@@ -11,14 +11,20 @@
 // evaluation order, so that given identical rays the ray kernel agrees bit for bit with the CPU oracle and
 // differs from the reference's fp32 mode only through sin/cos/atan2/asin ulps.
 //
-// Kernels:
-//   repack_knn_kernel      init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8]
-//   prep_rays_kernel       1 thread / (env, ray slot): pose -> ray origin, unit direction, cell id   (G1,G2,G3,G6)
-//   raycast_kernel         32 lanes / ray, 8 triangles / lane / pass, 16-B loads, wave shuffle min   (G4,G5,G7)  <- roofline kernel
-//   assemble_obs_kernel    1 thread / obs element, coalesced row writes                              (A1)
-//   metrics_done_kernel    1 thread / env: collision mask, reward, extras, done                      (G8,G9,G10)
-//   compact_kernel         ballot/popc ordered stream compaction of reset ids                        (G11)
-//   clearance / shift_spawns / sample_height / generate_goals kernels                                (G12)
+// Kernels (one step = the ten launches marked *):
+//   repack_knn_kernel        init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8], near/far halves per lane
+// * prep_env_kernel          1 thread / env: quat -> euler, heading, every sin/cos of the pose and joint chain
+// * prep_rays_kernel         1 thread / (env, ray slot): ray origin, unit direction, cell id, bin key               (A4, A6)
+// * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell) without global atomics
+// * raycast_binned_kernel    1 wave / run of sorted rays, 4 triangles per lane in registers, conservative early out  (A4, A5) <- roofline kernel
+//   raycast_binned_h_kernel  the same in the reference's as-shipped fp16 arithmetic (ray_precision 2)
+//   raycast_kernel           env order, half-wave per ray, streams the cell blocks (small batches, K8 > 256)
+// * assemble_obs_kernel      1 thread / obs element, coalesced row writes                                           (A1)
+// * metrics_done_kernel      1 thread / env: collision mask, stone mask, reward, extras, done, done count           (A7, A8, A10)
+// * compact_write_kernel     ballot/popc ordered stream compaction of the reset ids                                 (A12)
+//   clearance / shift_spawns / sample_height / goals_draw / goals_env0 / reset_envs kernels                          (A9, f-2)
+//   pre_physics / ackermann / quat_to_euler kernels                                                                  (f-1)
+//   knn_centroid / knn_bucket / knn_select kernels                                                                   (f-3)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rover_internal.h"
@@ -841,13 +847,10 @@ __global__ void __launch_bounds__(256) ackermann_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ray binning: counting sort of the step's rays by (map, cell).  At 65 536 envs every cell of the spawn area
-// is hit by ~10 rays per step; sorted, the 3.6 KB cell block is fetched from HBM once and served from
-// registers / L1 / the XCD's L2 to the other rays.  Results do not depend on the order
-// inside a bin, so the atomics do not make the step non-deterministic.
-//   prep_rays_kernel        histogram (atomicAdd per ray)
-//   scan_*_kernel           exclusive scan of the bin counts -> bin cursors (3 small launches)
-//   scatter_rays_kernel     sorted[cursor[bin]++] = ray slot
+// ray binning: sort of the step's rays by (map, cell).  At 65 536 envs a bin holds ~4-5 rays per step; sorted, the
+// 3.6 KB cell block is fetched from HBM once per bin and served from registers to its rays.
+// Results do not depend on the order inside a bin, so the LDS atomics do not make the step non-deterministic.
+// The generic 3-level scan below now only serves the KNN map builder; the binning has its own row scan.
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK 256
