@@ -8,12 +8,24 @@ that are already resident in HBM: get_observations (P terrain rays + 26 rock ray
 K triangles of their 0.1 m cell) + calculate_metrics + is_done + done compaction, through the C ABI
 (rover_step).  Default workload = BASELINE.json configs[2] — the config the north star's >= 4 M env-steps/s
 target is quoted on: 65 536 envs per GPU, 37-point radial heightmap + 26 rock-collision rays + the stone_info
-occupancy mask, 600 x 600 cell maps with K = 200.  For N > 1 every rank runs the same number of envs (weak scaling) and
-every step hands (obs, reward, done) to rank 0 with one grouped RCCL send/recv; by default that transfer runs on
-RCCL's stream under the kernels of the next step (double-buffered outputs; --sync-gather serialises it).
+occupancy mask, 600 x 600 cell maps with K = 200.
+
+N > 1 (weak scaling, 65 536 envs per GPU, one process per GPU over RCCL):
+  * `python bench.py --gpus N` with no rank environment starts the N ranks ITSELF: the parent process never touches
+    the GPU runtime, spawns N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays
+    rank 0's single JSON line and exits non-zero if any child fails.
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE already set) nothing is
+    spawned: the process is one rank.
+  Every step hands (obs f32, reward f32, done u8) of every shard to rank 0 with one grouped RCCL send/recv.  Two timed
+  passes of K steps each: the headline pass lets that transfer run on RCCL's stream under the kernels of the next step
+  (double-buffered outputs), the second pass serialises it (`alt_sync_gather` in the JSON line); --sync-gather makes the
+  serialised pass the headline one.  After each pass the root compares integer checksums of what it received with
+  checksums every rank computed of what it sent (`gather_check`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the ray-cast kernel: algorithmic bytes (18 B per ray-triangle pair) / HIP-event time vs 8 TB/s
+  roofline     — the ray-cast kernel: f32 VALU issue utilisation (instructions per launch from profiles/valu.json x 4
+                 cycles / (1 024 SIMDs x 2.4 GHz x HIP-event time)), with the HBM side (PMC traffic, GB/s, fraction of
+                 8 TB/s) and SURVEY §8(d)'s no-reuse byte model (`algorithmic_equiv_GBps`, `reuse_factor`) next to it
   cpu_baseline — the CPU oracle (oracle/rover_oracle.c, OpenMP) timed on a bounded sample of the same workload
 """
 from __future__ import annotations
@@ -21,6 +33,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,13 +42,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4              # max shader clock
+VALU_CYCLES_PER_INST = 4     # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.01 quad-cycles (profiles/README.md)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -53,22 +67,84 @@ def parse():
     ap.add_argument("--ray-precision", default="fp32", choices=["fp32", "fp16_sources", "fp16_as_shipped"],
                     help="fp32 = the reference's fp32 mode (default, the north star's parity mode); fp16_as_shipped = bit-identical to the "
                          "reference as shipped (Camera.dtype = float16)")
+    ap.add_argument("--cell-index-mode", default="cpu_div", choices=["cpu_div", "cuda_rcp"],
+                    help="camera.py:241 `x / 0.1`: a true division as ATen evaluates it on CPU (what the golden vectors pin) or the "
+                         "multiply by the reciprocal ATen's CUDA kernels turn it into")
     ap.add_argument("--sync-gather", action="store_true",
-                    help="N > 1: wait for the RCCL gather of a step before the next step starts (default: the gather of step i "
-                         "runs on RCCL's stream under the kernels of step i + 1, double-buffered outputs)")
+                    help="N > 1: headline pass waits for the RCCL gather of a step before the next step starts (default: the gather "
+                         "of step i runs on RCCL's stream under the kernels of step i + 1; the other mode is timed as the alt pass)")
+    ap.add_argument("--no-alt-pass", action="store_true", help="N > 1: skip the second timed pass in the other gather mode")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (A/B of the launch overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-timing", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     ap.add_argument("--scene-cache", default=os.environ.get("ROVER_SCENE_CACHE", ""))
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# parent: start one process per GPU.  Nothing here may initialise the GPU runtime (no torch.cuda call, no HIP call): on
+# this pool a process that has touched the GPU must not exec / be replaced, and the children must start from a clean slate.
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Spawn ``n`` rank processes of this script, relay rank 0's JSON line to stdout; returns the exit code."""
+    child = os.environ.get("ROVER_BENCH_CHILD", os.path.abspath(__file__))      # tests substitute a stand-in engine here
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL between processes on this host
+        procs.append(subprocess.Popen([sys.executable, child] + list(argv), env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = ""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        # rank 0 ends last by construction (final barrier), but a crashed peer must not leave the others hanging
+        deadline = time.time() + 60.0
+        for p in procs[1:]:
+            try:
+                p.wait(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                pass
+    finally:
+        for r, p in enumerate(procs):
+            if p.poll() is None:
+                p.kill()                     # exactly the PIDs started above
+                p.wait()
+                rc = rc or 1
+            elif p.returncode != 0:
+                print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+                rc = rc or (p.returncode if p.returncode > 0 else 1)
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    for ln in out0.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(lines[0], flush=True)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
 def algorithmic_bytes_per_env_step(p, k, ns, nd, r=26):
     """B = (P + R) K 18 + 128 + (4 + Ns + Nd) 4 + 56."""
     return (p + r) * k * 18 + 128 + (4 + ns + nd) * 4 + 56
 
 
 def load_scene(args, device):
+    import torch
     from isaac_rover_amd import synth
     key = f"scene_c{args.cells}_k{args.k}_s{args.stones}.pt"
     path = os.path.join(args.scene_cache, key) if args.scene_cache else ""
@@ -96,21 +172,36 @@ def cpu_baseline(args, scene, distn, states):
         orc.step(t, r, st, *distn, **prec)
         best = min(best, time.perf_counter() - t0)
         reps += 1
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    model = ""
+    logical = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", logical))
+    model, sockets, phys = "", set(), set()
     try:
         with open("/proc/cpuinfo") as f:
-            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+            pid = cid = None
+            for ln in f:
+                if ln.startswith("model name") and not model:
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                    sockets.add(pid)
+                elif ln.startswith("core id"):
+                    cid = ln.split(":", 1)[1].strip()
+                    phys.add((pid, cid))
     except OSError:
         pass
-    return {"value": n / best, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": model,
+    return {"value": n / best, "unit": "env-steps/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "host": {"sockets": len(sockets) or None, "physical_cores": len(phys) or None, "logical_cpus": logical,
+                     "omp_threads": threads},
             "sample": f"{n} envs x {reps} reps of the same workload (P={distn[0].shape[0]}, K={args.k}, "
-                      f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp"}
+                      f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp on every logical CPU",
+            "reference_pytorch": "the reference's own PyTorch path is not runnable on the GPU box (it cannot travel); measured in the "
+                                 "build container (8 threads): 303-1525 env-steps/s, BASELINE.md §2"}
 
 
-# The three touch points with the GPU runtime, as functions so that tests/test_host_logic.py can drive main()'s N > 1 control
-# flow (rank bookkeeping, overlapped gather, max-over-ranks timing, the JSON line) on CPU with gloo and a stand-in engine.
+# The touch points with the GPU runtime, as functions so that tests/test_host_logic.py can drive the N > 1 control flow (rank
+# bookkeeping, overlapped gather, checksums, max-over-ranks timing, the JSON line) on CPU with gloo and a stand-in engine.
 def _device(local_rank):
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rover step path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -127,21 +218,71 @@ def _make_engine(num_envs, local_rank, num_envs_global, env_offset):
 
 
 def _sync():
+    import torch
     torch.cuda.synchronize()
 
 
-def main():
-    args = parse()
+def _profile_entry(fname, key):
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        with open(path) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline(args, E, n_rays, prof, info):
+    """The ray-cast kernel's roofline object.  Live: HIP-event time per launch.  From profiles/: VALU instructions and HBM
+    bytes per launch of the same workload (rocprofv3 --pmc, tools/collect_profiles.sh), see profiles/README.md."""
+    ray_ms = prof.raycast_ms / max(prof.launches, 1)
+    t = ray_ms * 1e-3
+    key = f"E{E}_P{args.rays}_K{args.k}_C{args.cells}" + ("" if args.ray_precision == "fp32" else "_" + args.ray_precision)
+    valu = _profile_entry("valu.json", key)
+    traf = _profile_entry("traffic.json", key)
+    rays = E * (n_rays + 26)
+    peak = N_SIMD * CLOCK_GHZ                      # G SIMD-cycles per second
+    achieved = frac = insts_per_ray = None
+    if valu and t > 0:
+        insts = float(valu["valu_insts_per_launch"])
+        achieved = insts * VALU_CYCLES_PER_INST / t / 1e9
+        frac = achieved / peak
+        insts_per_ray = insts / rays
+    traffic = traf.get("hbm_bytes_per_launch") if traf else None
+    algo = 18.0 * prof.pairs_per_launch            # SURVEY §8(d): 18 B per (ray, triangle), no reuse credited
+    algo_gbs = algo / t / 1e9 if t > 0 else None
+    hbm = None
+    if traffic and t > 0:
+        hbm = {"traffic": traffic, "GBps": traffic / t / 1e9, "frac_of_8TBps": traffic / t / 1e9 / HBM_PEAK_GBS}
+    return {"bound": "valu", "kernel": "raycast_binned_kernel" if info.raycast_variant == 2 else "raycast_kernel",
+            "achieved": achieved, "peak": peak, "unit": "G VALU-issue cycles/s (1024 SIMDs x 2.4 GHz)", "frac": frac,
+            "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches),
+            "valu_insts_per_ray": insts_per_ray, "rays_per_launch": rays, "hbm": hbm,
+            "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
+            "reuse_factor": (algo / traffic) if traffic else None,
+            "note": "frac = SQ_INSTS_VALU per launch (profiles/valu.json) x 4 cycles / (1024 SIMDs x 2.4 GHz x live HIP-event "
+                    "time): the binned kernel serves most (ray, triangle) pairs from registers, so it is bound by f32 VALU issue, "
+                    "not by HBM; hbm.* = PMC-measured bytes per launch (profiles/traffic.json) at the live time; "
+                    "algorithmic_equiv_GBps = SURVEY 8(d)'s no-reuse byte model, kept for reference"}
+
+
+def _checksums(torch, obs, rew, done):
+    """Order-independent exact checksums of one (obs, rew, done) set: int64 sums of the raw bits."""
+    return torch.stack((obs.contiguous().view(torch.int32).sum(dtype=torch.int64),
+                        rew.contiguous().view(torch.int32).sum(dtype=torch.int64),
+                        done.sum(dtype=torch.int64)))
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     device = _device(local_rank)
-
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         _init_process_group(dist, device)
@@ -161,6 +302,7 @@ def main():
     eng = _make_engine(E, local_rank, E_global, rank * E)
     eng.set_scene(scene, distn)
     eng.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[args.ray_precision])
+    eng.set_option("cell_index_mode", {"cpu_div": 0, "cuda_rcp": 1}[args.cell_index_mode])
     info = eng.info()
     W = eng.num_observations
 
@@ -169,9 +311,10 @@ def main():
     for b in range(4):
         st = synth.make_states(E, args.cells * 0.1, seed=100 * rank + b)
         batches.append({k: v.to(device) for k, v in st.items()})
-    overlap = world > 1 and not args.sync_gather and not args.validate_goals
-    depth = 2 if overlap else 1
+    can_overlap = world > 1 and not args.validate_goals
+    depth = 2 if can_overlap else 1
     gather = StepGather(E, W, device, world, rank, depth=depth)
+    reset = torch.ones(E, dtype=torch.int64, device=device)          # reset_buf (rl_task.py:105); the u8 copy travels
     rock = torch.zeros(E, dtype=torch.int64, device=device)
     extras = {k: torch.zeros(E, dtype=(torch.int64 if k == "collision_penalty" else torch.float32), device=device)
               for k in _lib.EXTRAS}
@@ -181,11 +324,9 @@ def main():
     stone_mask = torch.zeros(E, dtype=torch.int64, device=device)
     souts = []
     for d in range(depth):
-        obs_d, rew_d, reset_d = gather.local_views(d)
-        souts.append(eng.make_out(obs_d, rew=rew_d, reset=reset_d, rock_collision=rock, extras=extras, reset_ids=reset_ids,
-                                  n_reset=n_reset, stone_collision=stone_mask, stone_margin=0.0))
-    sout = souts[0]
-    obs, rew, reset = gather.local_views(0)
+        obs_d, rew_d, done_d = gather.local_views(d)
+        souts.append(eng.make_out(obs_d, rew=rew_d, reset=reset, rock_collision=rock, extras=extras, reset_ids=reset_ids,
+                                  n_reset=n_reset, stone_collision=stone_mask, stone_margin=0.0, done_u8=done_d))
     sins = [eng.make_in(b["pos"], b["quat"], b["joints"], b["target"], b["lin_hist"], b["ang_hist"], b["euler_pre"],
                         b["progress"]) for b in batches]
     if args.validate_goals:
@@ -193,11 +334,25 @@ def main():
         initial = [b["pos"].clone() for b in batches]
         joint_vel = torch.zeros(E, 13, device=device)
 
-    def one_step(i):
+    graphs = {}
+
+    def launch_step(b, d):
+        if not args.graph:
+            eng.step(sins[b], souts[d], increment_progress=True, compact=True)
+            return
+        g = graphs.get((b, d))
+        if g is None:                        # one captured graph per (state batch, output set)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.step(sins[b], souts[d], increment_progress=True, compact=True)
+            graphs[(b, d)] = g
+        g.replay()
+
+    def one_step(i, overlap):
         b = i % len(batches)
         d = i % depth
         gather.wait(d)                       # overlapped mode: the transfer that last read buffer set d must be through
-        eng.step(sins[b], souts[d], increment_progress=True, compact=True)
+        launch_step(b, d)
         gather.gather(d, wait=not overlap)   # (obs, rew, done) of this step to the learner rank
         if args.validate_goals:
             # configs[4]: reset_idx + set_targets (goal re-draw + stone-clearance validation + goal z) for the envs the
@@ -215,6 +370,50 @@ def main():
             dist.barrier()
             _sync()
 
+    def gather_check():
+        """Root-side (obs, rew, done) of every buffer set == what every rank sent (exact integer checksums)."""
+        if world == 1:
+            return None
+        mine = torch.stack([_checksums(torch, *gather.local_views(d)) for d in range(depth)])       # [depth, 3]
+        allsums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allsums, mine)
+        ok = True
+        if rank == 0:
+            for d in range(depth):
+                og, rg, dg = gather.global_views(d)
+                for r in range(world):
+                    s = slice(r * E, (r + 1) * E)
+                    ok = ok and bool(torch.equal(_checksums(torch, og[s], rg[s], dg[s]).cpu(), allsums[r][d].cpu()))
+        return ok
+
+    def timed_pass(first_step, overlap):
+        fence()
+        eng.set_profiling(True)              # resets the in-library ray-cast event counters
+        t0 = time.perf_counter()
+        stamps, evs = [], []
+        for i in range(args.steps):
+            one_step(first_step + i, overlap)
+            if args.debug_timing:
+                stamps.append(time.perf_counter())
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                evs.append(ev)
+        t_enq = time.perf_counter()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if args.debug_timing and rank == 0:
+            dd = [1e6 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps)]
+            print("gpu ms/step:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(evs[:-1], evs[1:])), file=sys.stderr)
+            print("enqueue us/step:", " ".join(f"{x:.0f}" for x in dd), "| enqueue total ms", 1e3 * (t_enq - t0),
+                  "| fence ms", 1e3 * (elapsed - (t_enq - t0)), file=sys.stderr)
+        prof = eng.get_profile()
+        ok = gather_check()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof, ok
+
     # Event timing is switched on BEFORE the warm-up: the first timed hipEventRecord on a stream makes the runtime
     # enable queue profiling once (tens of ms); the warm-up absorbs that, then the counters are reset.
     eng.set_profiling(True)
@@ -222,86 +421,72 @@ def main():
         t_pre, i_pre = time.perf_counter(), 0
         while time.perf_counter() - t_pre < args.preroll_ms * 1e-3:      # local compute only: no collective, so the
             for _ in range(8):                                           # ranks need not agree on the iteration count
-                eng.step(sins[i_pre % len(sins)], sout, increment_progress=True, compact=True)
+                launch_step(i_pre % len(sins), 0)
                 i_pre += 1
             _sync()
         if world > 1:
             dist.barrier()
+    overlap = can_overlap and not args.sync_gather
     for i in range(args.warmup):
-        one_step(i)
-    fence()
-    eng.set_profiling(True)
-    t0 = time.perf_counter()
-    stamps = []
-    evs = []
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-        if args.debug_timing:
-            stamps.append(time.perf_counter())
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            evs.append(ev)
-    t_enq = time.perf_counter()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if args.debug_timing and rank == 0:
-        d = [1e6 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps)]
-        print("gpu ms/step:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(evs[:-1], evs[1:])), file=sys.stderr)
-        print("enqueue us/step:", " ".join(f"{x:.0f}" for x in d), "| enqueue total ms", 1e3 * (t_enq - t0),
-              "| fence ms", 1e3 * (elapsed - (t_enq - t0)), file=sys.stderr)
-    prof = eng.get_profile()
+        one_step(i, overlap)
+    elapsed, prof, ok = timed_pass(args.warmup, overlap)
+    alt = None
+    if world > 1 and can_overlap and not args.no_alt_pass:
+        e2, _p2, ok2 = timed_pass(args.warmup + args.steps, not overlap)
+        alt = {"mode": "overlapped" if not overlap else "sync_gather", "value": E_global * args.steps / e2,
+               "ms_per_step": 1e3 * e2 / args.steps, "gather_check": ok2}
     eng.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
+    rc = 0
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = E_global * args.steps / elapsed
-        ray_ms = prof.raycast_ms / max(prof.launches, 1)
-        ray_bytes = 18.0 * prof.pairs_per_launch                       # algorithmic: 18 B per (ray, triangle)
-        achieved = ray_bytes / (ray_ms * 1e-3) / 1e9 if ray_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"E{E}_P{args.rays}_K{args.k}_C{args.cells}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        cfg_idx = 4 if args.validate_goals else (3 if world > 1 else (1 if E == 4096 else 2))
         line = {
             "metric": "env-steps/sec (obs+reward+done)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.ray_precision == "fp16_as_shipped" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{4 if args.validate_goals else 2}]: {E} envs/GPU x {world} GPU, "
+            "config": {"workload": f"BASELINE configs[{cfg_idx}]: {E} envs/GPU x {world} GPU, "
                                    f"{args.rays}-point heightmap + 26 rock rays, K={args.k}, {args.cells}x{args.cells} "
                                    f"cells @0.1 m, stone_info mask over {args.stones} stones"
                                    + (", + goal validation" if args.validate_goals else "")
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
-                                   + ((", RCCL gather(obs,rew,done)->rank0" + (" overlapped with the next step" if overlap else ""))
+                                   + (f", cell_index_mode={args.cell_index_mode}" if args.cell_index_mode != "cpu_div" else "")
+                                   + (", step replayed from a hipGraph" if args.graph else "")
+                                   + ((", RCCL gather(obs f32, rew f32, done u8)->rank0"
+                                       + (" overlapped with the next step" if overlap else " serialised with the steps"))
                                       if world > 1 else ""),
                        "envs_total": E_global, "rays_per_env": n_rays + 26, "obs_dim": W,
                        "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(n_rays, args.k, eng.Ns, eng.Nd),
                        "table_bytes": int(info.table_bytes[0] + info.table_bytes[1])},
-            "roofline": {"bound": "hbm", "kernel": "raycast_binned_kernel" if info.raycast_variant == 2 else "raycast_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches),
-                         "algorithmic_bytes_per_launch": ray_bytes,
-                         "hbm_measured_GBps": (traffic / (ray_ms * 1e-3) / 1e9) if (traffic and ray_ms > 0) else None,
-                         "note": "achieved = 18 B x ray-triangle pairs / HIP-event time (no reuse credited); the binned kernel "
-                                 "serves most pairs from registers/L1/L2 and is f32-VALU-bound, so achieved can exceed the "
-                                 "HBM peak; traffic = PMC-measured HBM bytes per launch (profiles/traffic.json)"},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else None,
+            "roofline": roofline(args, E, n_rays, prof, info),
         }
+        if world > 1:
+            line["gather_check"] = ok
+            line["gather_bytes_per_rank_per_step"] = E * (4 * W + 4 + 1)
+            if alt is not None:
+                line["alt_" + alt.pop("mode")] = alt
+            if ok is False or (alt is not None and alt.get("gather_check") is False):
+                rc = 3
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, scene, distn, batches[0])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None):
+    args = parse(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and (world_env is None or (world_env == "1" and "RANK" not in os.environ)):
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -102,6 +102,9 @@ typedef struct {
      * Written by the collision stage (rover_get_observations / rover_step); never feeds reward or done. */
     int64_t *stone_collision;      /* optional [E]; needs rover_set_stones                                */
     float stone_margin;            /* metres, <= 1.4 (the reach of the occupancy grid); 0 = centre inside a disc */
+    /* ADDITIONAL output: reset != 0 as one byte per env — the form the multi-GPU gather ships (SURVEY.md 8e:
+     * "done [E/8] u8 or i64"); written by the is_done stage next to the int64 reset_buf. */
+    uint8_t *done_u8;              /* optional [E]                                                         */
 } rover_step_out;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -175,13 +178,15 @@ typedef struct {
     float *joint_pos13, *joint_vel13; /* [E,13] optional                                                           */
     float *base_pos3;             /* [E,3] optional self.base_pos                                                  */
     int64_t *reset, *progress;    /* [E] reset_buf, progress_buf                                                   */
-    const int32_t *yaw_deg;       /* [n] optional: replaces random.randint(0, 360) (rover.py:429)                  */
+    const int32_t *yaw_deg;       /* [yaw_deg_len] optional: replaces random.randint(0, 360) (rover.py:429); entry i
+                                   * belongs to reset_ids[i]                                                        */
     float *target3;               /* [E,3] optional self.target_positions: re-draw + validate goals                */
     float radius;                 /* rover.py:578 (8)                                                              */
     const float *draws;           /* optional [max_draws][n] uniforms (needs n_reset_host)                         */
     int32_t max_draws;
     uint64_t seed;
     int32_t *n_draws_used;        /* optional [1]                                                                  */
+    int32_t yaw_deg_len;          /* entries in yaw_deg: >= n_reset_host, or >= num_envs when n_reset_dev is used   */
 } rover_reset_io;
 ROVER_API int rover_reset_envs(rover_ctx *ctx, const rover_reset_io *io, void *stream);
 
@@ -236,6 +241,11 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
  * name = "raycast_early_out": 1 (default) = the binned kernel drops a whole packed pair of triangles per lane (the far half
  *        of a cell's K-nearest list; on the rocks map also the near half) when a conservative test on the numerators shows that
  *        every triangle of it fails the barycentric test; results are bit-identical with 0 (A/B and tests).
+ * name = "cell_index_mode": how `(xy - shift) / 0.1` (camera.py:241, rock_detect.py:381, rover.py:590; a Python-float divisor)
+ *        is evaluated.  0 = cpu_div (default): a correctly rounded division, what ATen's CPU kernel does and what the golden
+ *        vectors (captured from the reference on CPU) pin.  1 = cuda_rcp: multiplication by 1.0f / 0.1f = 10.0f, what ATen's
+ *        CUDA kernel does ("a * reciprocal(b)" for a CPU-scalar divisor) — the device the reference actually runs on.  The
+ *        two differ only for coordinates within an ulp of a .5 tie of the cell grid (tests/test_oracle_golden.py).
  * name = "raycast_run": sorted rays per wave for variant 2 (default 0 = auto: 32 on full batches, down to 4 on small ones). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
 

@@ -48,7 +48,8 @@ class StepOut(C.Structure):
                 ("ex_torque_penalty_driving", C.c_void_p), ("ex_torque_penalty_steering", C.c_void_p),
                 ("reset_ids", C.c_void_p), ("n_reset", C.c_void_p), ("euler", C.c_void_p),
                 ("heading_diff", C.c_void_p), ("ray_dist", C.c_void_p), ("wheel_dist", C.c_void_p),
-                ("body_dist", C.c_void_p), ("stone_collision", C.c_void_p), ("stone_margin", C.c_float)]
+                ("body_dist", C.c_void_p), ("stone_collision", C.c_void_p), ("stone_margin", C.c_float),
+                ("done_u8", C.c_void_p)]
 
 
 class Info(C.Structure):
@@ -62,7 +63,7 @@ class ResetIO(C.Structure):
                 ("initial_pos3", C.c_void_p), ("pos3", C.c_void_p), ("quat4", C.c_void_p), ("joint_pos13", C.c_void_p),
                 ("joint_vel13", C.c_void_p), ("base_pos3", C.c_void_p), ("reset", C.c_void_p), ("progress", C.c_void_p),
                 ("yaw_deg", C.c_void_p), ("target3", C.c_void_p), ("radius", C.c_float), ("draws", C.c_void_p),
-                ("max_draws", C.c_int32), ("seed", C.c_uint64), ("n_draws_used", C.c_void_p)]
+                ("max_draws", C.c_int32), ("seed", C.c_uint64), ("n_draws_used", C.c_void_p), ("yaw_deg_len", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -267,7 +268,7 @@ class Engine:
 
     def make_out(self, obs, rew=None, reset=None, rock_collision=None, extras=None, reset_ids=None, n_reset=None,
                  euler=None, heading_diff=None, ray_dist=None, wheel_dist=None, body_dist=None, stone_collision=None,
-                 stone_margin=0.0):
+                 stone_margin=0.0, done_u8=None):
         e, f, i64 = self.num_envs, torch.float32, torch.int64
         stride = 0
         if obs is not None:
@@ -287,15 +288,16 @@ class Engine:
         self._chk(wheel_dist, (e, 24), f, "wheel_dist")
         self._chk(body_dist, (e, 2), f, "body_dist")
         self._chk(stone_collision, (e,), i64, "stone_collision")
+        self._chk(done_u8, (e,), torch.uint8, "done_u8")
         ex = extras or {}
         for k in EXTRAS:
             self._chk(ex.get(k), (e,), i64 if k == "collision_penalty" else f, "extras." + k)
         sout = StepOut(_ptr(obs), stride, _ptr(rew), _ptr(reset), _ptr(rock_collision),
                        *[_ptr(ex.get(k)) for k in EXTRAS], _ptr(reset_ids), _ptr(n_reset), _ptr(euler),
                        _ptr(heading_diff), _ptr(ray_dist), _ptr(wheel_dist), _ptr(body_dist), _ptr(stone_collision),
-                       float(stone_margin))
+                       float(stone_margin), _ptr(done_u8))
         sout._keep = (obs, rew, reset, rock_collision, dict(ex), reset_ids, n_reset, euler, heading_diff, ray_dist, wheel_dist,
-                      body_dist, stone_collision)
+                      body_dist, stone_collision, done_u8)
         return sout
 
     def step(self, sin: StepIn, sout: StepOut, increment_progress=True, compact=False):
@@ -404,7 +406,7 @@ class Engine:
             max_draws = draws.shape[0]
         self._chk(n_draws_used, (1,), torch.int32, "n_draws_used")
         self._check(self.lib.rover_generate_goals(self._h, _ptr(env_ids), n, _ptr(initial_pos3), _ptr(target3),
-                                                  float(radius), _ptr(draws), int(max_draws), int(seed),
+                                                  float(radius), _ptr(draws), int(max_draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                   _ptr(n_draws_used), _stream()), "rover_generate_goals")
 
     def reset_envs(self, reset_ids, initial_pos3, pos3, quat4, reset, progress, n_reset_dev=None, n_reset_host=0,
@@ -422,12 +424,16 @@ class Engine:
         self._chk(n_draws_used, (1,), torch.int32, "n_draws_used")
         if yaw_deg is not None:
             self._chk(yaw_deg, (yaw_deg.shape[0],), torch.int32, "yaw_deg")
+            need = e if n_reset_dev is not None else int(n_reset_host)      # entry i belongs to reset_ids[i]; with the count on
+            if yaw_deg.shape[0] < need:                                     # the device any i < num_envs may be read
+                raise RoverError(f"yaw_deg: {yaw_deg.shape[0]} entries, but up to {need} may be read")
         if draws is not None:
             self._chk(draws, (draws.shape[0], int(n_reset_host)), f, "draws")
             max_draws = draws.shape[0]
         io = ResetIO(_ptr(reset_ids), _ptr(n_reset_dev), int(n_reset_host), _ptr(initial_pos3), _ptr(pos3), _ptr(quat4),
                      _ptr(joint_pos13), _ptr(joint_vel13), _ptr(base_pos3), _ptr(reset), _ptr(progress), _ptr(yaw_deg),
-                     _ptr(target3), float(radius), _ptr(draws), int(max_draws), int(seed), _ptr(n_draws_used))
+                     _ptr(target3), float(radius), _ptr(draws), int(max_draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                     _ptr(n_draws_used), 0 if yaw_deg is None else int(yaw_deg.shape[0]))
         self._check(self.lib.rover_reset_envs(self._h, C.byref(io), _stream()), "rover_reset_envs")
 
     def pre_physics_step(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None):

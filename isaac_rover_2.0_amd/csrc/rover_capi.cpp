@@ -57,6 +57,7 @@ struct rover_ctx {
     bool sorted_valid = false;
     uint32_t run = 0;                   // option "raycast_run": 0 = auto (effective_run)
     uint32_t early_out = 1;             // option "raycast_early_out": conservative whole-pair rejection (bit-identical results)
+    int32_t cell_rcp = 0;               // option "cell_index_mode": 0 cpu_div (x / 0.1), 1 cuda_rcp (x * (1 / 0.1))
     uint64_t workspace_bytes = 0;
     bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
     bool rays_valid = false;
@@ -274,7 +275,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     cleanup();
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
-    c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y};
+    c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, 1.0f / cell};
     c->table_bytes[which] = bytes;
     c->have_map[which] = true;
     c->rays_valid = false;
@@ -319,7 +320,7 @@ int rover_set_heightfield(rover_ctx* c, const float* hm, int32_t N0, int32_t N1,
     if (e != hipSuccess) { dfree(d); return fail(c, ROVER_E_HIP, "set_heightfield: %s", hipGetErrorString(e)); }
     float* old = const_cast<float*>(c->hf.hm);
     dfree(old);
-    c->hf = HeightDev{d, N0, N1, hscale, vscale, sx, sy};
+    c->hf = HeightDev{d, N0, N1, hscale, vscale, sx, sy, 1.0f / hscale, c->cell_rcp};
     c->have_hf = true;
     return ROVER_OK;
 }
@@ -429,6 +430,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
     if (variant == 2) p.bin_out = c->d_bins;
     p.precision = c->precision;
+    p.cell_rcp = c->cell_rcp;
     HIP_TRY(c, launch_prep(p, s));
     if (variant == 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
@@ -492,6 +494,7 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.ex_heading = out->ex_heading_contraint_penalty; m.ex_motion = out->ex_motion_contraint_penalty;
     m.block_cnt = count_done ? c->d_block_cnt : nullptr;
     m.stone_collision = coll ? out->stone_collision : nullptr; m.stone_margin = out->stone_margin;
+    m.done_u8 = done ? out->done_u8 : nullptr;
     m.sgrid = c->sgrid; m.info7 = c->d_stones;
     m.ex_goal_angle = out->ex_goal_angle_penalty; m.ex_lin = out->ex_torque_penalty_driving; m.ex_ang = out->ex_torque_penalty_steering;
     HIP_TRY(c, launch_metrics_done(m, s));
@@ -615,6 +618,10 @@ int rover_reset_envs(rover_ctx* c, const rover_reset_io* io, void* stream) {
     if (!io->n_reset_dev && (io->n_reset_host < 0 || io->n_reset_host > c->cfg.num_envs))
         return fail(c, ROVER_E_INVALID, "reset_envs: n_reset_host=%d out of range", io->n_reset_host);
     if (io->draws && io->n_reset_dev) return fail(c, ROVER_E_INVALID, "reset_envs: caller-supplied draws need n_reset_host");
+    // yaw_deg[i] is read for every i < n: with the count on the device n can be any value up to num_envs
+    if (io->yaw_deg && io->yaw_deg_len < (io->n_reset_dev ? c->cfg.num_envs : io->n_reset_host))
+        return fail(c, ROVER_E_INVALID, "reset_envs: yaw_deg holds %d entries, %d may be read", io->yaw_deg_len,
+                    io->n_reset_dev ? c->cfg.num_envs : io->n_reset_host);
     if (io->target3 && (!c->have_stones || !c->have_hf))
         return fail(c, ROVER_E_STATE, "reset_envs: goal validation needs rover_set_stones and rover_set_heightfield");
     if (!io->n_reset_dev && io->n_reset_host == 0) return ROVER_OK;
@@ -769,6 +776,13 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->early_out = (uint32_t)value;
         return ROVER_OK;
     }
+    if (!strcmp(name, "cell_index_mode")) {
+        if (value < 0 || value > 1) return fail(c, ROVER_E_INVALID, "cell_index_mode must be 0 (cpu_div) or 1 (cuda_rcp)");
+        c->cell_rcp = (int32_t)value;
+        c->hf.rcp = c->cell_rcp;
+        c->rays_valid = false;
+        return ROVER_OK;
+    }
     if (!strcmp(name, "raycast_run")) {
         if (value < 0 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be 0 (auto) or in [1, 4096]");
         c->run = (uint32_t)value;
@@ -781,8 +795,21 @@ int rover_set_profiling(rover_ctx* c, int32_t enable) {
     if (!c) return ROVER_E_INVALID;
     USE_DEVICE(c);
     if (enable && c->ev0.empty()) {
-        c->ev0.resize(kProfRing); c->ev1.resize(kProfRing);
-        for (int i = 0; i < kProfRing; ++i) { HIP_TRY(c, hipEventCreate(&c->ev0[i])); HIP_TRY(c, hipEventCreate(&c->ev1[i])); }
+        // created into locals and swapped in only when all 2 x 256 exist: a partial failure leaves the ctx without events
+        std::vector<hipEvent_t> e0, e1;
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < kProfRing && e == hipSuccess; ++i) {
+            hipEvent_t a = nullptr, b = nullptr;
+            e = hipEventCreate(&a);
+            if (e == hipSuccess) { e0.push_back(a); e = hipEventCreate(&b); }
+            if (e == hipSuccess) e1.push_back(b);
+        }
+        if (e != hipSuccess) {
+            for (auto& x : e0) (void)hipEventDestroy(x);
+            for (auto& x : e1) (void)hipEventDestroy(x);
+            return fail(c, ROVER_E_HIP, "set_profiling: hipEventCreate: %s", hipGetErrorString(e));
+        }
+        c->ev0.swap(e0); c->ev1.swap(e1);
     }
     if (c->prof_pending) (void)prof_drain(c);
     c->profiling = enable != 0;

@@ -19,12 +19,15 @@ struct KnnDev {
     const uint16_t* table;
     int32_t X, Y, K, K8;         // K8: row pitch of one component inside a cell block (K rounded up to a multiple of 8)
     float cell, shift_x, shift_y;
+    float inv_cell;              // 1.0f / cell rounded to f32: the factor of cell_index_mode 1 (cuda_rcp)
 };
 
 struct HeightDev {
     const float* hm;
     int32_t N0, N1;
     float hscale, vscale, shift_x, shift_y;
+    float inv_hscale;            // 1.0f / hscale (cell_index_mode 1)
+    int32_t rcp;                 // cell_index_mode
 };
 
 // stone-occupancy grid (built on the host at rover_set_stones): CSR lists of the stones that can matter per grid cell
@@ -46,6 +49,7 @@ struct PrepArgs {
     uint32_t* bin_out;           // optional [E*R8]: bin = (map, cell) key of every slot for the bucket sort (binned ray cast)
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
+    int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
 };
 
 struct ObsArgs {
@@ -71,6 +75,7 @@ struct MetricsArgs {
     int64_t* reset;
     uint32_t* block_cnt;         // optional [ceil(E/256)]: per-block done count for the compaction
     float* ex_pos_reward; int64_t* ex_collision; float *ex_upright, *ex_heading, *ex_motion, *ex_goal_angle, *ex_lin, *ex_ang;
+    uint8_t* done_u8;            // optional: reset != 0 as one byte per env (the form that travels in the multi-GPU gather)
     int64_t* stone_collision;    // optional additional output: stone_info occupancy mask at pos_xy (collision stage)
     float stone_margin;
     StoneGridDev sgrid;

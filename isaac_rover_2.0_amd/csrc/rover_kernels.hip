@@ -88,9 +88,11 @@ __device__ __forceinline__ void wheel_chain(float x, float y, float z, const flo
     body_xf(x2, y2, z2, t, px, py, pz, ox, oy, oz);
 }
 
-// camera.py:241-253: clamp bound is the dim-0 size for both axes; torch.round is half-to-even
-__device__ __forceinline__ uint32_t cell_coord(float v, float shift, float cell, int32_t dim0) {
-    float s = (v - shift) / cell;
+// camera.py:241-253: clamp bound is the dim-0 size for both axes; torch.round is half-to-even.
+// `/ horizontal_scale` (a Python float): ATen's CPU kernel divides (rcp = 0, what the golden vectors pin); ATen's CUDA
+// kernel multiplies by 1 / scale rounded to f32 (rcp = 1, option cell_index_mode) — they differ next to .5 ties only.
+__device__ __forceinline__ uint32_t cell_coord(float v, float shift, float cell, float inv_cell, int32_t rcp, int32_t dim0) {
+    float s = rcp ? (v - shift) * inv_cell : (v - shift) / cell;
     float hi = (float)(dim0 - 1);
     s = (s < 0.0f) ? 0.0f : s;
     s = (s > hi) ? hi : s;
@@ -258,8 +260,8 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         } else {
             neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
         }
-        uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->X);
-        uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->X);
+        uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->inv_cell, a.cell_rcp, m->X);
+        uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->inv_cell, a.cell_rcp, m->X);
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
         rec.cell = ix * (uint32_t)m->Y + iy;
         bin = ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell;
@@ -450,6 +452,7 @@ __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t 
         if (td <= 0.18f) reset = 1;
         if (a.curriculum_level >= 2 && coll == 1) reset = 1;
         a.reset[e] = reset;
+        if (a.done_u8) a.done_u8[e] = (uint8_t)reset;
         done_flag = reset != 0;
     }
 }
@@ -581,8 +584,8 @@ __global__ void __launch_bounds__(256) sample_height_kernel(HeightDev h, const f
                                                             float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t ix = cell_coord(xy[2ull * i], h.shift_x, h.hscale, h.N0);
-    uint32_t iy = cell_coord(xy[2ull * i + 1], h.shift_y, h.hscale, h.N0);
+    uint32_t ix = cell_coord(xy[2ull * i], h.shift_x, h.hscale, h.inv_hscale, h.rcp, h.N0);
+    uint32_t iy = cell_coord(xy[2ull * i + 1], h.shift_y, h.hscale, h.inv_hscale, h.rcp, h.N0);
     if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
     out[i] = h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
 }
@@ -621,8 +624,8 @@ __device__ __forceinline__ void goal_from_draw(float u, float radius, const floa
 }
 
 __device__ __forceinline__ float height_at(const HeightDev& h, float x, float y) {
-    uint32_t ix = cell_coord(x, h.shift_x, h.hscale, h.N0);
-    uint32_t iy = cell_coord(y, h.shift_y, h.hscale, h.N0);
+    uint32_t ix = cell_coord(x, h.shift_x, h.hscale, h.inv_hscale, h.rcp, h.N0);
+    uint32_t iy = cell_coord(y, h.shift_y, h.hscale, h.inv_hscale, h.rcp, h.N0);
     if (iy > (uint32_t)(h.N1 - 1)) iy = (uint32_t)(h.N1 - 1);
     return h.hm[(uint64_t)ix * h.N1 + iy] * h.vscale;
 }
@@ -647,7 +650,8 @@ __global__ void __launch_bounds__(256) goals_draw_kernel(GoalArgs a) {
         bool clear = false;
         float x = 0.0f, y = 0.0f;
         if (active && t < a.max_draws) {
-            float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed, (uint32_t)t, i);
+            // library RNG: keyed by the entry's GLOBAL env id, so that the shards of a multi-GPU run draw different streams
+            float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed, (uint32_t)t, (uint32_t)a.env_ids[i]);
             goal_from_draw(u, a.radius, a.initial_pos3, id, x, y);
             clear = !collides_grid(a.grid, a.info7, x, y, 1.0f);               // :539: redraw while nearest_rock <= 1.0
         }
@@ -723,7 +727,7 @@ __global__ void __launch_bounds__(1024) goals_env0_kernel(GoalArgs a) {
             bool clear = false;
             float cx = 0.0f, cy = 0.0f;
             if (t < a.max_draws) {
-                float u = a.draws ? a.draws[(uint64_t)t * n + src] : philox_uniform(a.seed, (uint32_t)t, src);
+                float u = a.draws ? a.draws[(uint64_t)t * n + src] : philox_uniform(a.seed, (uint32_t)t, (uint32_t)a.env_ids[src]);
                 goal_from_draw(u, a.radius, a.initial_pos3, 0, cx, cy);
                 clear = !collides_grid(a.grid, a.info7, cx, cy, 1.0f);
             }
@@ -757,7 +761,7 @@ __global__ void __launch_bounds__(256) reset_envs_kernel(ResetArgs a) {
     if (i >= n) return;
     const int64_t id = a.ids[i] - a.id_offset;
     float deg = a.yaw_deg ? (float)a.yaw_deg[i]
-                          : floorf(philox_uniform(a.seed ^ 0x9E3779B97F4A7C15ull, 0u, (uint32_t)id) * 361.0f);
+                          : floorf(philox_uniform(a.seed ^ 0x9E3779B97F4A7C15ull, 0u, (uint32_t)a.ids[i]) * 361.0f);   // global id
     float half = (deg * (3.14159265358979323846f / 180.0f)) / 2.0f;
     a.quat4[4ull * id] = sinf(half); a.quat4[4ull * id + 1] = 0.0f; a.quat4[4ull * id + 2] = 0.0f; a.quat4[4ull * id + 3] = cosf(half);
 #pragma unroll
@@ -1271,6 +1275,7 @@ __global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict
         }
         __syncthreads();
         const uint32_t n = count;
+        __syncthreads();                 // every wave has read n before any wave appends the next ring to `count`
         if (n > KNN_CAP) { if (tid == 0) *overflow = 1; return; }
         const bool covers_all = (bx - r <= 0) && (by - r <= 0) && (bx + r >= (int)nbx - 1) && (by + r >= (int)nby - 1);
         if (n >= K || covers_all) {

@@ -2,7 +2,9 @@
 
 The reference is single-device (``rover.py:90`` hard-codes ``cuda:0``) and has no collective to mirror.
 Envs are independent, terrain / rock / stone tables are read-only and replicated on every GPU, so the
-only exchange of a step is handing (obs, reward, done) of every shard to the learner rank.  That is done
+only exchange of a step is handing (obs f32, reward f32, done u8) of every shard to the learner rank — done
+travels as one byte per env (``rover_step_out.done_u8``, written by the is_done stage next to the int64
+``reset_buf``), not as the 8-byte flag.  That is done
 as ONE grouped point-to-point operation (``batch_isend_irecv`` = a single ncclGroup of send/recv on RCCL):
 each rank sends its three buffers straight into the root's global tensors, so the 7 inbound shards of an
 8-GPU node arrive over 7 distinct xGMI links and nothing is re-packed or copied afterwards.  (A ring
@@ -25,7 +27,7 @@ def shard_range(num_envs_global: int, world: int, rank: int):
 
 
 class StepGather:
-    """Owns the (obs, rew, reset) buffers of one shard and gathers all shards on ``root``.
+    """Owns the (obs, rew, done) buffers of one shard and gathers all shards on ``root``.
 
     On the root the local buffers are views of chunk ``rank`` of the global tensors, so the step kernels
     write the root's own shard in place; other ranks send directly into the root's chunks.
@@ -48,7 +50,7 @@ class StepGather:
         for _ in range(depth):
             obs_g = torch.zeros(n, obs_dim, dtype=torch.float32, device=device)
             rew_g = torch.zeros(n, dtype=torch.float32, device=device)
-            reset_g = torch.ones(n, dtype=torch.int64, device=device)     # rl_task.py:105: reset_buf starts at 1
+            reset_g = torch.ones(n, dtype=torch.uint8, device=device)     # done flags, 1 B per env (reset_buf starts at 1, rl_task.py:105)
             self._sets.append((obs_g, rew_g, reset_g))
         self._pending = [None] * depth
         self._lo = lo
@@ -62,7 +64,8 @@ class StepGather:
         return o[s], r[s], z[s]
 
     def global_views(self, d: int = 0):
-        """The gathered (obs, rew, reset) of set ``d`` on the root (None elsewhere); valid after ``wait(d)``."""
+        """The gathered (obs f32 [N*E, W], rew f32 [N*E], done u8 [N*E]) of set ``d`` on the root (None elsewhere); valid after
+        ``wait(d)``."""
         return self._sets[d] if self.is_root else None
 
     def wait(self, d: int = 0):

@@ -88,6 +88,8 @@ class RoverTask(RLTask):
         self.Camera = _Camera(hm)
         self.num_exteroceptive = self.Camera.get_num_exteroceptive()
         self.global_step = 0
+        # run seed (cfg/config.yaml `seed`): mixed into every library RNG draw, so that seed sweeps re-randomise the resets
+        self._seed = int(self._cfg.get("seed", 0)) if hasattr(self._cfg, "get") else 0
         self._num_proprioceptive = 4                                                      # :98
         self._num_observations = self._num_proprioceptive + hm.get_num_sparse_vector() + hm.get_num_dense_vector()
         self._num_actions = 2                                                             # :100
@@ -254,7 +256,7 @@ class RoverTask(RLTask):
             self._engine.reset_envs(self.reset_env_ids_buf, self.initial_pos, rv._pos, rv._quat, self.reset_buf,
                                     self.progress_buf, n_reset_dev=self._n_reset, joint_pos13=rv._joint_pos,
                                     joint_vel13=rv._joint_vel, base_pos3=self.base_pos, yaw_deg=reset_yaw_deg,
-                                    target3=self.target_positions, radius=8.0, seed=self.global_step)
+                                    target3=self.target_positions, radius=8.0, seed=self._rng_seed())
             self._balls._pos.copy_(self.target_positions)                                        # :584 (visual only)
             return
         self._engine.quat_to_euler(rv.get_world_poses()[1], out=self.rover_rot)                  # :343
@@ -309,7 +311,13 @@ class RoverTask(RLTask):
         kernel, including the reference's ``env_ids = mask*env_ids`` aliasing.  ``draws`` [n_draws, n] replaces
         ``torch.rand``; otherwise the library's Philox stream keyed by the global step."""
         self._engine.generate_goals(env_ids.long().contiguous(), self.initial_pos, self.target_positions, radius=radius,
-                                    draws=draws, max_draws=256, seed=self.global_step)
+                                    draws=draws, max_draws=256, seed=self._rng_seed())
+
+    def _rng_seed(self):
+        """Philox key of this step's device-side draws: (run seed, global step); the counter is the GLOBAL env id, so every
+        shard of a multi-GPU run and every run seed draws its own stream (the reference's torch.rand / random follow the
+        run seed the same way)."""
+        return ((self._seed * 0x9E3779B97F4A7C15) ^ (self.global_step * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
 
     def check_goal_collision(self, env_ids):
         """rover.py:533-542."""

@@ -195,6 +195,85 @@ def main():
     steer, vel = ref2.ackermann(lin, ang)
     save("ackermann", lin=lin.numpy(), ang=ang.numpy(), steer=steer.numpy(), vel=vel.numpy())
 
+    next_rows(ref2, g)
+
+
+def knn_mesh(kind):
+    """Meshes of the KNN-builder fixtures, rebuilt bit-identically by the tests (only parameters + a digest are stored)."""
+    if kind == "grid10m":                # regular 0.1 m grid mesh over 10 m x 10 m, the terrain generator's triangulation
+        verts, tris, _ = synth.grid_mesh(101, seed=1)
+        return verts.astype(np.float32), tris.astype(np.int32), dict(res_x=100, res_y=100, res=0.1, n_triangles=16)
+    if kind == "soup50m":                # irregular triangle soup over 50 m: coordinates where fp16 spacing is 0.03 m
+        rng = np.random.default_rng(77)
+        n = 6000
+        centers = rng.uniform(-1.0, 50.0, (n, 1, 2))
+        verts = np.concatenate([centers + rng.normal(0, 0.3, (n, 3, 2)), rng.normal(0, 0.2, (n, 3, 1))], axis=2)
+        return verts.reshape(-1, 3).astype(np.float32), np.arange(3 * n, dtype=np.int32).reshape(n, 3), \
+            dict(res_x=100, res_y=100, res=0.5, n_triangles=12)
+    raise ValueError(kind)
+
+
+def mesh_digest(verts, tris):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(verts).tobytes())
+    h.update(np.ascontiguousarray(tris).tobytes())
+    return h.hexdigest()
+
+
+def next_rows(ref2, g):
+    """Golden vectors for the "next" rows f-2 / f-3 / f-4, captured from the reference's own code."""
+    # ---- f-2: RoverTask.reset_idx (rover.py:416-453), random.randint fed from `degrees` ------------------------------
+    e = 48
+    ids = torch.tensor([0, 1, 2, 5, 7, 8, 13, 14, 20, 21, 22, 30, 31, 40, 46, 47])
+    degrees = [0, 360, 90, 180, 270, 359, 1, 45, 181, 17] + [int(x) for x in torch.randint(0, 361, (6,), generator=g)]
+    initial = torch.zeros(e, 3)
+    initial[:, 0:2] = 12.8 * torch.rand(e, 2, generator=g)
+    initial[:, 2] = torch.rand(e, generator=g)
+    base = torch.randn(e, 3, generator=g)
+    reset_buf = torch.zeros(e, dtype=torch.long)
+    reset_buf[ids] = 1
+    reset_buf[3] = 1                      # flagged but not in the list handed to reset_idx: must stay
+    progress = torch.randint(1, 3000, (e,), generator=g)
+    out = ref2.reset_idx(ids, degrees, initial, base, reset_buf, progress)
+    save("reset_idx", env_ids=ids.numpy(), degrees=np.asarray(degrees, dtype=np.int32), initial_pos=initial.numpy(),
+         base_pos_in=base.numpy(), reset_buf_in=reset_buf.numpy(), progress_buf_in=progress.numpy(),
+         **{"out_" + k: v.numpy() for k, v in out.items()})
+
+    # ---- f-3: _get_knn_triangles (tasks/utils/rover_utils.py:52-118) on two small meshes ------------------------------
+    for kind in ("grid10m", "soup50m"):
+        verts, tris, kw = knn_mesh(kind)
+        idx, v16, t32, xx, yy = rh.knn_triangles(verts, tris, "map.ply", **kw)
+        assert idx.max() < 32768
+        save("knn_" + kind, kind=np.array(kind), mesh_digest=np.array(mesh_digest(verts, tris)),
+             map_indices_kxy=idx.numpy().astype(np.int16),        # [K, X, Y] as saved at rover_utils.py:113
+             vertices_f16_digest=np.array(hashlib.sha256(v16.numpy().tobytes()).hexdigest()),
+             triangles_digest=np.array(hashlib.sha256(t32.numpy().tobytes()).hexdigest()),
+             cell_x_f16=xx.numpy(), cell_y_f16=yy.numpy(), **{k: np.array(v) for k, v in kw.items()})
+
+    # ---- f-4: learning/model.py Layer / Encoder / compute (:105-150,185-195,231-241) ----------------------------------
+    for name, nobs, ns, nd, n_rows, seed in (("policy_native", 1750, 634, 1112, 16, 11), ("policy_p37", 41, 37, 0, 64, 12)):
+        actor, critic = rh.policy_models(nobs, ns, nd, seed)
+        arrays = {}
+        with torch.no_grad():
+            for tag, net in (("actor", actor), ("critic", critic)):
+                if name == "policy_native" and tag == "critic":
+                    continue              # the two classes share every layer shape but the head; one native-size net is enough
+                for k, v in net.state_dict().items():
+                    v.copy_(v.half().float())                     # fp16-representable weights: stored exactly in half the bytes
+                    arrays[f"{tag}.{k}"] = v.numpy().astype(np.float16)
+            x = torch.randn(n_rows, nobs, generator=g).half().float()
+            x[:, 4:] = (11.0 * torch.rand(n_rows, nobs - 4, generator=g) / 2).half().float()     # heightmap part like obs: dist / 2
+            arrays["states"] = x.numpy().astype(np.float16)
+            mean, log_std = actor.compute(x, None, "policy")
+            arrays["out_actor"] = mean.numpy()
+            arrays["out_log_std"] = log_std.detach().numpy()
+            p = actor.num_proprioception
+            arrays["out_actor_encoder0"] = actor.encoder0(x[:, p:p + ns]).numpy()
+            arrays["out_actor_encoder1"] = actor.encoder1(x[:, p + ns:p + ns + nd]).numpy()
+            if not (name == "policy_native"):
+                arrays["out_critic"] = critic.compute(x, None, "value").numpy()
+        save(name, num_observations=np.array(nobs), num_sparse=np.array(ns), num_dense=np.array(nd), **arrays)
+
 
 if __name__ == "__main__":
     main()

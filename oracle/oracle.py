@@ -134,6 +134,11 @@ def step(terrain: KnnMap, rocks: KnnMap, st: dict, distribution, sparse_idx, den
     return res
 
 
+def set_cell_index_mode(mode):
+    """'cpu_div' (default; x / 0.1 as ATen-CPU evaluates camera.py:241) or 'cuda_rcp' (x * (1 / 0.1) as ATen-CUDA does)."""
+    lib().oracle_set_cell_index_mode({"cpu_div": 0, "cuda_rcp": 1}[mode])
+
+
 def quat_to_euler(quat):
     q = _np(quat, np.float32)
     out = np.zeros((q.shape[0], 3), np.float32)

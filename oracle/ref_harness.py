@@ -269,3 +269,98 @@ class Reference:
 
     def ackermann(self, lin, ang):
         return self.kin_mod.Ackermann(lin, ang, "cpu")
+
+    # ------------------------------------------------------------ reset_idx (f-2)
+    def reset_idx(self, env_ids, degrees, initial_pos, base_pos, reset_buf, progress_buf):
+        """``RoverTask.reset_idx`` (rover.py:416-453) called unbound, ``random.randint`` (:429) fed from ``degrees``.
+        Returns what the method handed to the RoverView setters and the buffers it changed."""
+        Rover = self.rover_mod.RoverTask
+        calls = {}
+        view = SimpleNamespace(
+            set_joint_positions=lambda x, indices=None: calls.__setitem__("joint_pos", (x.clone(), indices.clone())),
+            set_joint_velocities=lambda x, indices=None: calls.__setitem__("joint_vel", (x.clone(), indices.clone())),
+            set_world_poses=lambda p, q, i: calls.__setitem__("poses", (p.clone(), q.clone(), i.clone())),
+        )
+        t = SimpleNamespace(_rover=view, _device="cpu", save_teacher_data=False, base_pos=base_pos.clone(),
+                            initial_pos=initial_pos.clone(), reset_buf=reset_buf.clone(), progress_buf=progress_buf.clone())
+        feed = [int(d) for d in degrees]
+        real = self.rover_mod.random.randint
+
+        def fake_randint(a, b):
+            assert (a, b) == (0, 360)
+            return feed.pop(0)
+
+        self.rover_mod.random.randint = fake_randint
+        try:
+            Rover.reset_idx(t, env_ids.clone())
+        finally:
+            self.rover_mod.random.randint = real
+        assert not feed
+        return dict(joint_pos=calls["joint_pos"][0], joint_pos_indices=calls["joint_pos"][1],
+                    joint_vel=calls["joint_vel"][0], pose_pos=calls["poses"][0], pose_quat=calls["poses"][1],
+                    pose_indices=calls["poses"][2], base_pos=t.base_pos, reset_buf=t.reset_buf, progress_buf=t.progress_buf)
+
+
+def knn_triangles(vertices, triangles, file_name, res_x, res_y, res, n_triangles):
+    """The reference's own map builder ``_get_knn_triangles`` (tasks/utils/rover_utils.py:52-118) on a caller-supplied mesh:
+    ``o3d.io.read_triangle_mesh`` (:62, open3d is absent here) is replaced by an object carrying that mesh as float64
+    vertices / int32 triangles the way open3d returns them; everything else is the reference's code, run on CPU.  Returns the
+    three tensors it saved (map_indices [K, X, Y] int32, vertices fp16, triangles int32) and the fp16 cell coordinates its
+    ``torch.arange(0, res_x*res, res, dtype=float16)`` produced on this host."""
+    install()
+    mod = importlib.import_module("omniisaacgymenvs.tasks.utils.rover_utils")
+    mesh = SimpleNamespace(vertices=np.asarray(vertices, dtype=np.float64), triangles=np.asarray(triangles, dtype=np.int32))
+    real = mod.o3d
+    mod.o3d = SimpleNamespace(io=SimpleNamespace(read_triangle_mesh=lambda path: mesh))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        save = os.path.join("tasks", "utils", "terrain", "knn_out") + "/"
+        os.makedirs(os.path.join(tmp, save))
+        os.chdir(tmp)
+        try:
+            mod._get_knn_triangles(file_name=file_name, save_path=save, res_x=res_x, res_y=res_y, res=res, n_triangles=n_triangles)
+            out = (torch.load(save + "map_indices.pt"), torch.load(save + "vertices.pt"), torch.load(save + "triangles.pt"))
+        finally:
+            os.chdir(cwd)
+            mod.o3d = real
+    xx = torch.arange(0, res_x * res, res, dtype=torch.float16)
+    yy = torch.arange(0, res_y * res, res, dtype=torch.float16)
+    return out + (xx, yy)
+
+
+def _install_skrl_models():
+    """learning/model.py subclasses skrl's Model / mixins (skrl is absent here).  Minimal stand-ins with the attributes
+    model.py reads: an nn.Module base exposing num_observations / num_actions, and mixins whose __init__ takes anything."""
+    import torch.nn as nn
+
+    class Model(nn.Module):
+        def __init__(self, observation_space, action_space, device=None):
+            nn.Module.__init__(self)
+            self.observation_space, self.action_space, self.device = observation_space, action_space, device
+            self.num_observations = observation_space.shape[0]
+            self.num_actions = action_space.shape[0]
+
+    class _Mixin:
+        def __init__(self, *a, **k):
+            pass
+
+    m = types.ModuleType("skrl.models.torch")
+    m.Model, m.GaussianMixin, m.DeterministicMixin = Model, type("GaussianMixin", (_Mixin,), {}), type("DeterministicMixin", (_Mixin,), {})
+    pkg = _StubModule("skrl"); pkg.__path__ = []
+    pkg_m = _StubModule("skrl.models"); pkg_m.__path__ = []
+    sys.modules.update({"skrl": pkg, "skrl.models": pkg_m, "skrl.models.torch": m})
+
+
+def policy_models(num_observations, num_sparse, num_dense, seed, mlp=(256, 160, 128), encoder=(80, 60), activation="leakyrelu"):
+    """The reference's StochasticActorHeightmap / DeterministicHeightmap (learning/model.py:152-241) built with the
+    reference's own constructors on CPU (network sizes / activation of cfg/trainSKRL/RoverPPOSKRL.yaml:1-10)."""
+    install()
+    _install_skrl_models()
+    mod = importlib.import_module("omniisaacgymenvs.learning.model")
+    torch.manual_seed(seed)
+    net = mod.NetworkInfo(list(mlp), list(encoder), list(encoder), [80, 60], activation)
+    obs = mod.ObserverationInfo(num_observations - num_sparse - num_dense, num_sparse, num_dense, 0)
+    osp, asp = SimpleNamespace(shape=(num_observations,)), SimpleNamespace(shape=(2,))
+    actor = mod.StochasticActorHeightmap(osp, asp, net, obs, device="cpu")
+    critic = mod.DeterministicHeightmap(osp, asp, net, obs, device="cpu")
+    return actor, critic

@@ -171,8 +171,14 @@ static void body_rays(const float *pos, const float *eul, float *src, float *dir
 }
 
 /* camera.py:233-264 / rock_detect.py:373-401: clamp bound is dim-0 size for BOTH axes */
+/* `x / horizontal_scale` with a Python-float divisor: ATen's CPU kernel divides (mode 0, what the golden vectors
+ * captured on CPU pin); ATen's CUDA kernel multiplies by opmath_t(1.0) / scalar, the reciprocal rounded to f32
+ * (BinaryDivTrueKernel.cu, "compute a * reciprocal(b)": mode 1).  1.0f/0.1f == 10.0f and 1.0f/0.025f == 40.0f exactly, so
+ * the two differ only where (v - shift) / 0.1f and (v - shift) * 10.0f round to different floats next to a .5 tie. */
+static int g_cell_rcp = 0;
+ORACLE_API void oracle_set_cell_index_mode(int rcp) { g_cell_rcp = rcp; }
 static inline int64_t cell_index(float v, float shift, float cell, int32_t dim0) {
-    float s = (v - shift) / cell;
+    float s = g_cell_rcp ? (v - shift) * (1.0f / cell) : (v - shift) / cell;
     float hi = (float)(dim0 - 1);
     s = (s < 0.0f) ? 0.0f : s;                                /* clamp(min=0, max=X-1): NaN passes through */
     s = (s > hi) ? hi : s;

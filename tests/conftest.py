@@ -104,3 +104,43 @@ def assert_step_close(got, want, label=""):
             for e in bad:
                 near = abs(abs(wd[e].min()) - 0.8) < 1e-3 or abs(abs(bd[e].min()) - 0.45) < 1e-3
                 assert near, f"{label}:{k} differs at env {e} away from any threshold"
+
+
+def tie_points(cell, n_cells):
+    """float32 coordinates v next to a .5 tie of the cell grid where rint(v / cell) != rint(v * (1 / cell)): the only inputs on
+    which ATen's CPU division and ATen-CUDA's multiply-by-reciprocal (camera.py:241 with a Python-float divisor) pick different
+    cells.  Returns (v [n] float32, cell index under division, cell index under reciprocal multiply)."""
+    c = np.float32(cell)
+    inv = np.float32(1.0) / c
+    vs, a_, b_ = [], [], []
+    for k in range(n_cells - 1):
+        v = np.float32((k + 0.5) * cell)
+        for _ in range(6):
+            v = np.nextafter(v, np.float32(-1))
+        for _ in range(13):
+            a, b = np.rint(v / c), np.rint(v * inv)
+            if a != b:
+                vs.append(v), a_.append(int(a)), b_.append(int(b))
+            v = np.nextafter(v, np.float32(1e9))
+    return np.asarray(vs, np.float32), np.asarray(a_), np.asarray(b_)
+
+
+def tie_scene_and_states(k=2, n_cells=128):
+    """A K = 2 scene (a cell's list holds only its two nearest triangles, so the chosen cell shows in the result) and states
+    whose single ray origin — distribution point (0, 0), identity orientation — sits exactly on tie_points(); every second
+    env is a plain random one."""
+    import torch
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=n_cells, k=k, n_stones=16)
+    v, ia, ib = tie_points(0.1, n_cells)
+    keep = (v > 1.0) & (v < n_cells * 0.1 - 1.0)
+    v, ia, ib = v[keep], ia[keep], ib[keep]
+    n = 2 * len(v)
+    st = synth.make_states(n, n_cells * 0.1, seed=21)
+    for j, x in enumerate(v):
+        e = 2 * j
+        st["pos"][e, 0] = float(x)
+        st["pos"][e, 1] = 3.0 + 0.1 * (j % 40) + 0.013             # y away from any tie
+        st["quat"][e] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    distn = (np.array([[0.0, 0.0, -0.26878]]), np.array([0], dtype=np.int64), np.array([], dtype=np.int64))
+    return scene, distn, st, np.arange(0, n, 2)

@@ -406,6 +406,111 @@ def test_reset_envs_with_zero_resets_is_a_no_op():
     assert bool((progress == 7).all())
 
 
+def test_cell_index_mode_cuda_rcp_matches_oracle_and_differs_on_ties():
+    """Option cell_index_mode: 0 = `x / 0.1` as ATen's CPU kernel divides (what the golden vectors pin), 1 = `x * (1 / 0.1)` as
+    ATen's CUDA kernel evaluates the same line (camera.py:241) on the device the reference really runs on.  Both modes equal
+    the oracle in the same mode bit for bit on the ray results; they differ from each other on tie envs only."""
+    from conftest import tie_points, tie_scene_and_states
+    from hip_helpers import hip_step, make_engine
+    from oracle import oracle as orc
+    scene, distn, st, tie_envs = tie_scene_and_states()
+    t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
+    n = st["pos"].shape[0]
+    got, want = {}, {}
+    for mode, name in ((0, "cpu_div"), (1, "cuda_rcp")):
+        for variant in (2, 1):
+            eng = make_engine(scene, distn, n, variant=variant)
+            eng.set_option("cell_index_mode", mode)
+            got[(mode, variant)] = hip_step(eng, st)
+            eng.close()
+        try:
+            orc.set_cell_index_mode(name)
+            want[mode] = orc.step(t, r, st, *distn)
+        finally:
+            orc.set_cell_index_mode("cpu_div")
+        for variant in (2, 1):
+            for key in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
+                np.testing.assert_array_equal(got[(mode, variant)][key], want[mode][key], err_msg=f"{name} v{variant} {key}")
+    differs = np.nonzero((got[(0, 2)]["ray_dist"] != got[(1, 2)]["ray_dist"]).any(axis=1))[0]
+    assert len(differs) >= 4 and set(differs) <= set(tie_envs)
+    # heightfield lookup (rover.py:588-608): unique value per cell -> the chosen cell is visible
+    n0 = 600
+    hm = torch.arange(n0, dtype=torch.float32)[:, None] * 1000.0 + torch.arange(n0, dtype=torch.float32)[None, :]
+    v, ia, ib = tie_points(0.025, n0)
+    xy = torch.from_numpy(np.stack((v, np.full_like(v, 0.26)), axis=1)).cuda()
+    eng = make_engine(scene, distn, n)
+    eng.set_heightfield(hm, 0.025, 1.0)
+    np.testing.assert_array_equal(eng.sample_height(xy).cpu().numpy(), ia * 1000.0 + 10.0)
+    eng.set_option("cell_index_mode", 1)
+    np.testing.assert_array_equal(eng.sample_height(xy).cpu().numpy(), ib * 1000.0 + 10.0)
+    with pytest.raises(Exception, match="cell_index_mode"):
+        eng.set_option("cell_index_mode", 2)
+    eng.close()
+
+
+def test_library_rng_is_keyed_by_global_env_id_and_seed():
+    """Shards of a multi-GPU run must not replay each other's reset randomisation: the Philox counter is the GLOBAL env id
+    (id + env_offset), the key is the caller's seed.  Two engines that differ only in env_offset draw different yaws and goal
+    angles for the same local envs; the same (seed, global id) reproduces the same draw on any shard."""
+    from isaac_rover_amd import _lib, synth
+    fx = load_golden("reset_path")
+    scene = scene_for(fx)
+    e = 32
+
+    def run(env_offset, seed):
+        eng = _lib.Engine(e, device=0, num_envs_global=4 * e, env_offset=env_offset)
+        eng.set_scene(scene, synth.ray_distribution("9"))
+        eng.set_stones(fx["stone_info"])
+        dev = eng.device
+        initial = torch.from_numpy(fx["goal_initial"]).to(dev)
+        pos = torch.zeros(e, 3, device=dev); quat = torch.zeros(e, 4, device=dev); tgt = torch.zeros(e, 3, device=dev)
+        reset = torch.ones(e, dtype=torch.int64, device=dev); progress = torch.ones(e, dtype=torch.int64, device=dev)
+        ids = torch.arange(env_offset, env_offset + e, device=dev)
+        n = torch.full((1,), e, dtype=torch.int32, device=dev)
+        eng.reset_envs(ids, initial, pos, quat, reset, progress, n_reset_dev=n, target3=tgt, seed=seed)
+        torch.cuda.synchronize()
+        out = quat.cpu().numpy().copy(), tgt.cpu().numpy().copy()
+        eng.close()
+        return out
+
+    q0, t0 = run(0, 99)
+    q1, t1 = run(e, 99)
+    q0b, t0b = run(0, 99)
+    q0c, t0c = run(0, 100)
+    np.testing.assert_array_equal(q0, q0b); np.testing.assert_array_equal(t0, t0b)          # deterministic
+    assert (q0 != q1).any(axis=1).mean() > 0.9 and (t0[1:, 0:2] != t1[1:, 0:2]).any(axis=1).mean() > 0.9      # other shard
+    assert (q0 != q0c).any(axis=1).mean() > 0.9 and (t0[1:, 0:2] != t0c[1:, 0:2]).any(axis=1).mean() > 0.9    # other seed
+
+
+def test_yaw_deg_length_is_validated():
+    """yaw_deg[i] is read for every i below the reset count; with the count on the device that can be any i < num_envs."""
+    from isaac_rover_amd import _lib, synth
+    fx = load_golden("reset_path")
+    scene = scene_for(fx)
+    e = 32
+    eng = _lib.Engine(e, device=0)
+    eng.set_scene(scene, synth.ray_distribution("9"))
+    dev = eng.device
+    z3 = torch.zeros(e, 3, device=dev); q = torch.zeros(e, 4, device=dev)
+    reset = torch.ones(e, dtype=torch.int64, device=dev); progress = torch.ones(e, dtype=torch.int64, device=dev)
+    ids = torch.arange(e, device=dev); n = torch.full((1,), 4, dtype=torch.int32, device=dev)
+    short = torch.zeros(4, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.RoverError, match="yaw_deg"):
+        eng.reset_envs(ids, z3, z3.clone(), q, reset, progress, n_reset_dev=n, yaw_deg=short)
+    with pytest.raises(_lib.RoverError, match="yaw_deg"):
+        eng.reset_envs(ids, z3, z3.clone(), q, reset, progress, n_reset_host=8, yaw_deg=short)
+    # the C ABI checks too (a caller that bypasses the Python binding)
+    import ctypes as C
+    io = _lib.ResetIO(ids.data_ptr(), n.data_ptr(), 0, z3.data_ptr(), z3.data_ptr(), q.data_ptr(), None, None, None,
+                      reset.data_ptr(), progress.data_ptr(), short.data_ptr(), None, 8.0, None, 0, 0, None, 4)
+    assert eng.lib.rover_reset_envs(eng._h, C.byref(io), None) == -1
+    assert b"yaw_deg" in eng.lib.rover_last_error(eng._h)
+    eng.reset_envs(ids, z3, z3.clone(), q, reset, progress, n_reset_host=4, yaw_deg=short)      # long enough: fine
+    torch.cuda.synchronize()
+    eng.close()
+
+
 def test_philox_goals_have_clearance():
     """Library RNG path: every accepted goal has clearance > 1.0 and sits `radius` from its spawn."""
     from isaac_rover_amd import _lib, synth

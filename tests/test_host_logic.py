@@ -159,8 +159,8 @@ for step in range(3):
         allids = torch.arange(E * world, dtype=torch.float32)
         assert torch.equal(O, allids[:, None] * 10 + torch.arange(W) + step)
         assert torch.equal(R, allids + 0.5 * step)
-        assert torch.equal(D, (torch.arange(E * world) + step) % 2)
-        assert D.dtype == torch.int64
+        assert torch.equal(D.long(), (torch.arange(E * world) + step) % 2)
+        assert D.dtype == torch.uint8                 # done travels as one byte per env
     else:
         assert out is None
 # overlapped mode: two buffer sets, the transfer of step i is only waited for when set i % 2 is needed again
@@ -172,7 +172,7 @@ for step in range(5):
         O, R, D = g2.global_views(d)
         allids = torch.arange(E * world, dtype=torch.float32)
         assert torch.equal(O, allids[:, None] * 10 + torch.arange(W) + (step - 2))
-        assert torch.equal(D, (torch.arange(E * world) + step - 2) % 2)
+        assert torch.equal(D.long(), (torch.arange(E * world) + step - 2) % 2)
     obs, rew, reset = g2.local_views(d)
     ids = torch.arange(lo, hi, dtype=torch.float32)
     obs.copy_(ids[:, None] * 10 + torch.arange(W) + step)
@@ -226,45 +226,100 @@ class FakeEngine:
         ids = torch.arange(self.off, self.off + self.n, dtype=torch.float32)
         sout["obs"].copy_(ids[:, None] + 0.001 * self.steps)
         sout["rew"].copy_(ids)
-        sout["reset"].copy_((torch.arange(self.off, self.off + self.n) + self.steps) % 2)
+        flags = (torch.arange(self.off, self.off + self.n) + self.steps) % 2
+        sout["reset"].copy_(flags)
+        sout["done_u8"].copy_(flags)
     def reset_envs(self, *a, **k): pass
-    def set_profiling(self, on): pass
-    def get_profile(self): return types.SimpleNamespace(raycast_ms=1.0 * self.steps, launches=self.steps, pairs_per_launch=self.n * 63 * 200)
+    def set_profiling(self, on): self.steps0 = self.steps
+    def get_profile(self):
+        n = self.steps - self.steps0
+        return types.SimpleNamespace(raycast_ms=1.0 * n, launches=n, pairs_per_launch=self.n * 63 * 200)
 
 bench._device = lambda local_rank: torch.device("cpu")
 bench._init_process_group = lambda dist, device: dist.init_process_group("gloo")
 bench._make_engine = lambda n, local_rank, n_global, off: FakeEngine(n, off)
 bench._sync = lambda: None
 bench.load_scene = lambda args, device: None
-sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "7", "--warmup", "3", "--envs-per-gpu", "64",
-            "--preroll-ms", "20"] + os.environ.get("BENCH_EXTRA", "").split()
-bench.main()
-print("rank", os.environ["RANK"], "done")
+rc = bench.main(sys.argv[1:])
+print("rank", os.environ["RANK"], "done", file=sys.stderr)
+sys.exit(rc)
 """
 
+_BENCH_ARGS = ["--steps", "7", "--warmup", "3", "--envs-per-gpu", "64", "--preroll-ms", "20"]
 
-@pytest.mark.parametrize("extra", ["", "--sync-gather"])
-def test_bench_distributed_control_flow_gloo(tmp_path, extra):
-    """bench.py's N > 1 path (rank bookkeeping, pre-roll without collectives, overlapped / blocking gather, barrier + max over
-    ranks, ONE JSON line on rank 0) driven on CPU: gloo, 2 processes, a stand-in engine.  Guards the multi-GPU run the driver
-    does at round end against Python-level mistakes; the kernels and RCCL are not involved."""
+
+def _check_bench_line(out, extra):
     import json
-    script = tmp_path / "bench_worker.py"
-    script.write_text(_BENCH_WORKER)
-    port = 31000 + (os.getpid() % 2000) + (7 if extra else 0)
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   ROVER_ROOT=ROOT, BENCH_EXTRA=extra)
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=180)[0] for p in procs]
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, o
-        assert f"rank {r} done" in o
-    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and not any(l.startswith("{") for l in outs[1].splitlines())
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 3 and d["scaling"] == "weak" and d["config"]["envs_total"] == 128
     assert d["value"] > 0 and abs(d["value"] - 128 * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
     assert ("overlapped" in d["config"]["workload"]) == (extra == "")
     assert "cpu_baseline" not in d and set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"          # the backend really saw both ranks
+    assert d["gather_check"] is True                                # root-side buffers == per-rank checksums
+    alt = d["alt_sync_gather" if extra == "" else "alt_overlapped"]
+    assert alt["gather_check"] is True and alt["value"] > 0
+    assert d["gather_bytes_per_rank_per_step"] == 64 * (4 * 41 + 4 + 1)
+    return d
+
+
+@pytest.mark.parametrize("extra", ["", "--sync-gather"])
+def test_bench_self_launch_gloo(tmp_path, extra):
+    """`python bench.py --gpus 2` with NO rank environment (how the driver calls it): the parent spawns two rank processes
+    itself, relays exactly one JSON line and returns 0.  CPU: gloo + a stand-in engine substituted through ROVER_BENCH_CHILD;
+    the real bench.main() runs in every rank (rank bookkeeping, pre-roll without collectives, overlapped / blocking gather of
+    (obs f32, rew f32, done u8), integer checksums of what the root received, barrier + max over ranks, both gather modes)."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ROVER_ROOT=ROOT, ROVER_BENCH_CHILD=str(script))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + _BENCH_ARGS + extra.split(),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "rank 0 done" in p.stderr and "rank 1 done" in p.stderr
+    _check_bench_line(p.stdout, extra)
+
+
+def test_bench_self_launch_reports_a_failed_rank(tmp_path):
+    """A rank that dies makes the parent exit non-zero without a JSON line (and without hanging on the survivors)."""
+    script = tmp_path / "bad_worker.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(2)\nprint('{}')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ROVER_BENCH_CHILD=str(script))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 7 and p.stdout.strip() == "" and "rank 1 exited with code 7" in p.stderr
+
+
+def test_bench_under_torchrun_env_does_not_spawn(tmp_path):
+    """With WORLD_SIZE / RANK already set (python -m torch.distributed.run ...) every process is one rank: nothing is spawned."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER)
+    port = 31000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ROVER_ROOT=ROOT, ROVER_BENCH_CHILD="/nonexistent/never-started")
+        procs.append(subprocess.Popen([sys.executable, str(script), "--gpus", "2"] + _BENCH_ARGS, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, e[-3000:]
+    _check_bench_line(outs[0][0], "")
+    assert not any(l.startswith("{") for l in outs[1][0].splitlines())
+
+
+def test_bench_parent_never_touches_the_gpu_runtime():
+    """The launcher half of bench.py imports nothing that could initialise HIP: no torch import at module level or in
+    launch_ranks()."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    names = {a.name.split(".")[0] for n in top if isinstance(n, ast.Import) for a in n.names} | \
+            {n.module.split(".")[0] for n in top if isinstance(n, ast.ImportFrom) and n.module}
+    assert "torch" not in names and "isaac_rover_amd" not in names and "numpy" not in names
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "launch_ranks")
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) for n in ast.walk(fn))

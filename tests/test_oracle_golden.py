@@ -52,6 +52,42 @@ def test_exact_ties_follow_the_reference(name, precision):
         assert (d0[on] == 0.75).all() and (d0[below] > 1.0).all()      # n == -fp16(0.1) accepted, one ulp less is not
 
 
+def test_cell_index_mode_cpu_div_vs_cuda_rcp():
+    """camera.py:241 / rock_detect.py:381 / rover.py:590 divide by a Python float.  ATen evaluates that as a division on CPU
+    (mode cpu_div: what every golden vector pins) and as a multiplication by the f32 reciprocal on CUDA (mode cuda_rcp: the
+    device the reference actually runs on).  The two pick different cells only for coordinates within an ulp of a .5 tie."""
+    from conftest import tie_points, tie_scene_and_states
+    # (1) heightfield lookup (rover.py:588-608) with a unique value per cell: the chosen cell is visible directly
+    n0 = 600
+    hm = (np.arange(n0, dtype=np.float32)[:, None] * 1000.0 + np.arange(n0, dtype=np.float32)[None, :])
+    v, ia, ib = tie_points(0.025, n0)
+    assert len(v) >= 32 and (ia != ib).all()
+    xy = np.stack((v, np.full_like(v, 0.26)), axis=1)            # y = 0.26 -> cell 10 in both modes
+    try:
+        orc.set_cell_index_mode("cpu_div")
+        h_div = orc.pos_height(hm, xy)
+        orc.set_cell_index_mode("cuda_rcp")
+        h_rcp = orc.pos_height(hm, xy)
+    finally:
+        orc.set_cell_index_mode("cpu_div")
+    np.testing.assert_array_equal(h_div, ia * 1000.0 + 10.0)
+    np.testing.assert_array_equal(h_rcp, ib * 1000.0 + 10.0)
+    # (2) ray cells: on a K = 2 map the ray result shows which cell was used; the modes differ on tie envs only
+    scene, distn, st, tie_envs = tie_scene_and_states()
+    t, r = _maps(scene)
+    try:
+        a = orc.step(t, r, st, *distn)
+        orc.set_cell_index_mode("cuda_rcp")
+        b = orc.step(t, r, st, *distn)
+    finally:
+        orc.set_cell_index_mode("cpu_div")
+    differs = np.nonzero((a["ray_dist"] != b["ray_dist"]).any(axis=1))[0]
+    assert len(differs) >= 4 and set(differs) <= set(tie_envs), differs
+    others = np.setdiff1d(np.arange(st["pos"].shape[0]), tie_envs)
+    for key in ("ray_dist", "wheel_dist", "body_dist", "obs_buf", "reset_buf"):
+        np.testing.assert_array_equal(a[key][others], b[key][others], err_msg=key)
+
+
 def test_edge_cases_are_exercised():
     fx = load_golden("step_e64_p37_fp32")
     assert fx["out_extras_pos_reward"][0] > 1.0            # goal reached: 1.03*(3000-progress)
