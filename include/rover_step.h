@@ -213,6 +213,18 @@ ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang
 ROVER_API int rover_build_knn_map(rover_ctx *ctx, const float *vertices, int32_t V, const int32_t *triangles, int32_t T,
                                   int32_t X, int32_t Y, float res, int32_t K, int32_t *map_idx_out);
 
+/* The same builder ranking EXACTLY like the reference does (rover_utils.py:71-102): triangle centroids and cell coordinates
+ * are fp16 tensors there, so per axis the difference is rounded to fp16, the norm is the f32 sqrt of the f32 sum of squares
+ * rounded to fp16, and torch.topk picks the K smallest of those fp16 distances (tie order unspecified; here: by triangle id).
+ * cell_x_f16 [X] / cell_y_f16 [Y] (IEEE half bits, host or device; NULL = fp16(float(i) * res), what ATen's CUDA arange yields)
+ * are the coordinate tables of the reference's torch.arange(0, X*res, res, dtype=float16) (:75-76) — ATen's CPU arange
+ * evaluates that in vector-width-dependent fp16 steps, so a map built by the reference on a CPU is reproduced by passing the
+ * table that host produced.  Result per cell: the same multiset of fp16 distances as the reference's list, the same triangles
+ * except among those tied with the K-th distance. */
+ROVER_API int rover_build_knn_map_ref(rover_ctx *ctx, const float *vertices, int32_t V, const int32_t *triangles, int32_t T,
+                                      int32_t X, int32_t Y, float res, int32_t K, const uint16_t *cell_x_f16,
+                                      const uint16_t *cell_y_f16, int32_t *map_idx_out);
+
 /* ---- policy-side consumer of the obs layout ("next" row f-4): learning/model.py:105-121 Layer = Linear + activation --- */
 #define ROVER_ACT_NONE      0
 #define ROVER_ACT_LEAKYRELU 1   /* nn.LeakyReLU(), slope 0.01 (cfg/trainSKRL/RoverPPOSKRL.yaml:5,9) */

@@ -99,6 +99,7 @@ SYMBOLS = {
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "rover_replay_raycast": (C.c_int, [_P, _P]),
     "rover_build_knn_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
+    "rover_build_knn_map_ref": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "rover_linear_forward": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "rover_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
@@ -330,15 +331,34 @@ class Engine:
         self._check(self.lib.rover_quat_to_euler(self._h, _ptr(quat), _ptr(out), n, _stream()), "rover_quat_to_euler")
         return out
 
-    def build_knn_map(self, vertices, triangles, n_x, n_y, res=0.1, k=200):
-        """rover_utils.py:48-123 on the GPU: -> map_indices [X, Y, K] int32 (device tensor), nearest first."""
+    def build_knn_map(self, vertices, triangles, n_x, n_y, res=0.1, k=200, ranking="exact_f32", cell_x_f16=None, cell_y_f16=None):
+        """rover_utils.py:48-123 on the GPU: -> map_indices [X, Y, K] int32 (device tensor), nearest first.
+        ``ranking``: "exact_f32" (exact f32 squared distance, ties by id) or "reference_fp16" (the reference's fp16 distances,
+        rover_utils.py:71-102; ``cell_*_f16`` = optional fp16 coordinate tables, see rover_build_knn_map_ref)."""
         v = _host(vertices, np.float32)
         t = _host(triangles, np.int32)
         if v.ndim != 2 or v.shape[1] != 3 or t.ndim != 2 or t.shape[1] != 3:
             raise RoverError("build_knn_map: expected vertices [V,3] and triangles [T,3]")
         out = torch.empty(int(n_x), int(n_y), int(k), dtype=torch.int32, device=self.device)
-        self._check(self.lib.rover_build_knn_map(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], int(n_x), int(n_y),
-                                                 float(res), int(k), _ptr(out)), "rover_build_knn_map")
+        if ranking == "exact_f32":
+            self._check(self.lib.rover_build_knn_map(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], int(n_x), int(n_y),
+                                                     float(res), int(k), _ptr(out)), "rover_build_knn_map")
+            return out
+        if ranking != "reference_fp16":
+            raise RoverError(f"build_knn_map: unknown ranking {ranking!r}")
+        tabs = []
+        for tab, n in ((cell_x_f16, n_x), (cell_y_f16, n_y)):
+            if tab is None:
+                tabs.append(None)
+                continue
+            a = np.ascontiguousarray(np.asarray(tab, dtype=np.float16)).view(np.uint16)
+            if a.shape != (int(n),):
+                raise RoverError(f"build_knn_map: fp16 cell table must have {n} entries")
+            tabs.append(a)
+        self._check(self.lib.rover_build_knn_map_ref(self._h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], int(n_x), int(n_y),
+                                                     float(res), int(k), None if tabs[0] is None else tabs[0].ctypes.data,
+                                                     None if tabs[1] is None else tabs[1].ctypes.data, _ptr(out)),
+                    "rover_build_knn_map_ref")
         return out
 
     ACTIVATIONS = {"none": 0, None: 0, "leakyrelu": 1, "tanh": 2, "relu": 3, "elu": 4}
@@ -350,11 +370,12 @@ class Engine:
         for t, name in ((x, "x"), (out, "out")):
             if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
                 raise RoverError(f"linear_forward: {name} must be a float32 GPU matrix with unit column stride")
-        self._chk(weight, (n, k), torch.float32, "weight")
+        if k > 0:
+            self._chk(weight, (n, k), torch.float32, "weight")
         self._chk(bias, (n,), torch.float32, "bias")
         if out.shape[0] != m or out.shape[1] != n:
             raise RoverError(f"linear_forward: out must be [{m},{n}]")
-        self._check(self.lib.rover_linear_forward(self._h, _ptr(x), x.stride(0), m, k, _ptr(weight), _ptr(bias), n,
+        self._check(self.lib.rover_linear_forward(self._h, _ptr(x), max(x.stride(0), k), m, k, _ptr(weight), _ptr(bias), n,
                                                   self.ACTIVATIONS[activation], _ptr(out), out.stride(0), _stream()),
                     "rover_linear_forward")
         return out

@@ -120,16 +120,21 @@ def load_ply(path: str):
         return verts, faces
 
 
-def build_knn_map(engine, vertices, triangles, n_cells: int = 600, res: float = 0.1, k: int = 200) -> KnnMap:
+def build_knn_map(engine, vertices, triangles, n_cells: int = 600, res: float = 0.1, k: int = 200, ranking: str = "exact_f32",
+                  cell_x_f16=None, cell_y_f16=None) -> KnnMap:
     """``_get_knn_triangles`` (rover_utils.py:52-123) on the GPU: K nearest triangle centroids per map cell, returned in
-    the in-memory form of one ``knn_*`` directory (vertices rounded to fp16 like :113)."""
-    idx = engine.build_knn_map(vertices, triangles, n_cells, n_cells, res, k)
+    the in-memory form of one ``knn_*`` directory (vertices rounded to fp16 like :113).  ``ranking="reference_fp16"`` ranks
+    like the reference (fp16 centroids, fp16 cell coordinates, fp16 distances, rover_utils.py:71-102) — pinned against maps
+    built by the reference's own code (tests/golden/knn_*.npz); the default ranks exact f32 distances."""
+    idx = engine.build_knn_map(vertices, triangles, n_cells, n_cells, res, k, ranking=ranking, cell_x_f16=cell_x_f16,
+                               cell_y_f16=cell_y_f16)
     return KnnMap(idx.cpu(), torch.as_tensor(np.asarray(triangles), dtype=torch.int32),
                   torch.as_tensor(np.asarray(vertices), dtype=torch.float32).to(torch.float16), res)
 
 
 def generate_knn_triangles(engine, terrain_dir: str, res_x: int = 600, res_y: int = 600, res: float = 0.1,
-                           n_triangles: int = 200, files=(("map.ply", "knn_terrain"), ("big_stones.ply", "knn_rocks"))):
+                           n_triangles: int = 200, files=(("map.ply", "knn_terrain"), ("big_stones.ply", "knn_rocks")),
+                           ranking: str = "exact_f32"):
     """``generate_knn_triangles`` of the reference (rover_utils.py:48-50): for ``map.ply`` and ``big_stones.ply`` in
     ``terrain_dir`` build the K-nearest-triangle map on the GPU and write ``map_indices.pt`` [K,X,Y] int32,
     ``vertices.pt`` fp16 and ``triangles.pt`` int32 into ``knn_terrain/`` and ``knn_rocks/`` (rover_utils.py:113-118) —
@@ -140,7 +145,7 @@ def generate_knn_triangles(engine, terrain_dir: str, res_x: int = 600, res_y: in
     out = {}
     for ply, sub in files:
         vertices, triangles = load_ply(os.path.join(terrain_dir, ply))
-        m = build_knn_map(engine, vertices, triangles, n_cells=res_x, res=res, k=n_triangles)
+        m = build_knn_map(engine, vertices, triangles, n_cells=res_x, res=res, k=n_triangles, ranking=ranking)
         d = os.path.join(terrain_dir, sub)
         os.makedirs(d, exist_ok=True)
         torch.save(m.map_indices.permute(2, 0, 1).contiguous().to(torch.int32), os.path.join(d, "map_indices.pt"))

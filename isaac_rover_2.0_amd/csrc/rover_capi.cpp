@@ -676,18 +676,65 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
     return ROVER_OK;
 }
 
+// IEEE binary16 <-> binary32 on the host (round to nearest even), for the reference-ranking coordinate tables
+static float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else { int e = -1; uint32_t m = man; do { ++e; m <<= 1; } while (!(m & 0x400u)); u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13); }
+    } else if (exp == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((exp + 112u) << 23) | (man << 13);
+    float f; memcpy(&f, &u, sizeof f); return f;
+}
+static uint16_t float_to_half_bits(float f) {
+    uint32_t u; memcpy(&u, &f, sizeof u);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (u > 0x7f800000u ? 0x200u : 0u));
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                        // rounds to infinity
+    if (u < 0x38800000u) {                                                         // subnormal half or zero
+        if (u < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(u >> 23);                                    // 14 .. 24
+        const uint32_t m = (u & 0x7fffffu) | 0x800000u;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (u - 0x38000000u) >> 13;
+    const uint32_t rem = u & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+static int build_knn_map_impl(rover_ctx* c, const float* vertices, int32_t V, const int32_t* triangles, int32_t T, int32_t X, int32_t Y,
+                              float res, int32_t K, int ref, const uint16_t* cell_x_f16, const uint16_t* cell_y_f16,
+                              int32_t* map_idx_out);
+
 int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const int32_t* triangles, int32_t T, int32_t X, int32_t Y,
                         float res, int32_t K, int32_t* map_idx_out) {
+    return build_knn_map_impl(c, vertices, V, triangles, T, X, Y, res, K, 0, nullptr, nullptr, map_idx_out);
+}
+
+int rover_build_knn_map_ref(rover_ctx* c, const float* vertices, int32_t V, const int32_t* triangles, int32_t T, int32_t X, int32_t Y,
+                            float res, int32_t K, const uint16_t* cell_x_f16, const uint16_t* cell_y_f16, int32_t* map_idx_out) {
+    return build_knn_map_impl(c, vertices, V, triangles, T, X, Y, res, K, 1, cell_x_f16, cell_y_f16, map_idx_out);
+}
+
+static int build_knn_map_impl(rover_ctx* c, const float* vertices, int32_t V, const int32_t* triangles, int32_t T, int32_t X, int32_t Y,
+                              float res, int32_t K, int ref, const uint16_t* cell_x_f16, const uint16_t* cell_y_f16,
+                              int32_t* map_idx_out) {
     if (!c) return ROVER_E_INVALID;
     if (!vertices || !triangles || !map_idx_out || V <= 0 || T <= 0 || X <= 0 || Y <= 0 || K <= 0 || !(res > 0.0f))
         return fail(c, ROVER_E_INVALID, "build_knn_map: bad arguments");
     if (T < K) return fail(c, ROVER_E_INVALID, "build_knn_map: the mesh has %d triangles, fewer than K=%d", T, K);
     if (K > 4096) return fail(c, ROVER_E_INVALID, "build_knn_map: K=%d exceeds the builder's limit of 4096", K);
     USE_DEVICE(c);
-    float *d_v = nullptr, *d_cx = nullptr, *d_cy = nullptr;
+    float *d_v = nullptr, *d_cx = nullptr, *d_cy = nullptr, *d_cell = nullptr;
     int32_t *d_t = nullptr, *d_over = nullptr;
     uint32_t *d_cur = nullptr, *d_items = nullptr, *d_bs = nullptr;
-    auto cleanup = [&]() { dfree(d_v); dfree(d_cx); dfree(d_cy); dfree(d_t); dfree(d_over); dfree(d_cur); dfree(d_items); dfree(d_bs); };
+    auto cleanup = [&]() { dfree(d_v); dfree(d_cx); dfree(d_cy); dfree(d_t); dfree(d_over); dfree(d_cur); dfree(d_items); dfree(d_bs); dfree(d_cell); };
 #define KNN_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e__ = (expr);                                                                          \
@@ -703,7 +750,19 @@ int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const in
     KNN_TRY(hipMemcpy(d_v, vertices, (size_t)V * 3 * sizeof(float), hipMemcpyDefault));
     KNN_TRY(hipMemcpy(d_t, triangles, (size_t)T * 3 * sizeof(int32_t), hipMemcpyDefault));
     KNN_TRY(hipMemset(d_over, 0, sizeof(int32_t)));
-    KNN_TRY(launch_knn_centroids(d_v, d_t, (uint32_t)T, (uint32_t)V, d_cx, d_cy, nullptr));
+    KNN_TRY(launch_knn_centroids(d_v, d_t, (uint32_t)T, (uint32_t)V, ref, d_cx, d_cy, nullptr));
+    if (ref) {
+        // cell coordinates as fp16 values: the caller's tables (what the reference's torch.arange(0, X res, res, dtype=float16)
+        // gave on the host that built the map), or fp16(float(i) * res) — ATen's CUDA arange kernel, the reference's own device
+        std::vector<float> cell((size_t)X + (size_t)Y);
+        std::vector<uint16_t> hx((size_t)X), hy((size_t)Y);
+        if (cell_x_f16) KNN_TRY(hipMemcpy(hx.data(), cell_x_f16, hx.size() * sizeof(uint16_t), hipMemcpyDefault));
+        if (cell_y_f16) KNN_TRY(hipMemcpy(hy.data(), cell_y_f16, hy.size() * sizeof(uint16_t), hipMemcpyDefault));
+        for (int32_t i = 0; i < X; ++i) cell[(size_t)i] = half_bits_to_float(cell_x_f16 ? hx[(size_t)i] : float_to_half_bits((float)i * res));
+        for (int32_t j = 0; j < Y; ++j) cell[(size_t)X + j] = half_bits_to_float(cell_y_f16 ? hy[(size_t)j] : float_to_half_bits((float)j * res));
+        KNN_TRY(hipMalloc((void**)&d_cell, cell.size() * sizeof(float)));
+        KNN_TRY(hipMemcpy(d_cell, cell.data(), cell.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     // bucket grid over the centroids' bounding box; bucket edge ~ the radius that holds K/4 centroids at mean density
     std::vector<float> hx((size_t)T), hy((size_t)T);
     KNN_TRY(hipMemcpy(hx.data(), d_cx, (size_t)T * sizeof(float), hipMemcpyDeviceToHost));
@@ -729,7 +788,7 @@ int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const in
     hipError_t e2 = hipMemcpy(d_start, d_cur, ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice);
     if (e2 == hipSuccess) e2 = launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 0, nullptr);
     if (e2 == hipSuccess) e2 = launch_knn_select(d_cx, d_cy, d_start, d_items, x0, y0, g, nbx, nby, (uint32_t)X, (uint32_t)Y, res,
-                                                 (uint32_t)K, map_idx_out, d_over, nullptr);
+                                                 (uint32_t)K, d_cell, d_cell ? d_cell + X : nullptr, map_idx_out, d_over, nullptr);
     if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
     int32_t over = 0;
     if (e2 == hipSuccess) e2 = hipMemcpy(&over, d_over, sizeof over, hipMemcpyDeviceToHost);
@@ -744,7 +803,8 @@ int rover_build_knn_map(rover_ctx* c, const float* vertices, int32_t V, const in
 int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t M, int32_t K, const float* weight, const float* bias,
                          int32_t N, int32_t activation, float* y, int64_t y_stride, void* stream) {
     if (!c) return ROVER_E_INVALID;
-    if (!x || !weight || !y || M < 0 || K <= 0 || N <= 0 || N > 256 || x_stride < K || y_stride < N || activation < 0 || activation > 4)
+    // K = 0: a layer over an empty obs slice (model.py builds Encoder(0, ...) when a heightmap part is absent) = act(bias)
+    if ((K > 0 && (!x || !weight)) || !y || M < 0 || K < 0 || N <= 0 || N > 256 || x_stride < K || y_stride < N || activation < 0 || activation > 4)
         return fail(c, ROVER_E_INVALID, "linear_forward: bad arguments (M=%d K=%d N=%d act=%d)", M, K, N, activation);
     if (M == 0) return ROVER_OK;
     USE_DEVICE(c);

@@ -1209,12 +1209,21 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
 // ---------------------------------------------------------------------------------------------------
 #define KNN_CAP 8192
 
+// ref = 1: the reference's own arithmetic — numpy float64 centroid of the (float64) open3d vertices (rover_utils.py:68-70),
+// then torch.tensor(..., dtype=float16) (:72), which converts double -> float -> half; kept here as the half's float value.
 __global__ void __launch_bounds__(256) knn_centroid_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tris,
-                                                           uint32_t T, uint32_t V, float* __restrict__ cx, float* __restrict__ cy) {
+                                                           uint32_t T, uint32_t V, int ref, float* __restrict__ cx, float* __restrict__ cy) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     uint32_t a = (uint32_t)tris[3ull * t], b = (uint32_t)tris[3ull * t + 1], c = (uint32_t)tris[3ull * t + 2];
     a = a < V ? a : 0u; b = b < V ? b : 0u; c = c < V ? c : 0u;
+    if (ref) {
+        double x = (((double)verts[3ull * a] + (double)verts[3ull * b]) + (double)verts[3ull * c]) / 3.0;
+        double y = (((double)verts[3ull * a + 1] + (double)verts[3ull * b + 1]) + (double)verts[3ull * c + 1]) / 3.0;
+        cx[t] = (float)(_Float16)(float)x;
+        cy[t] = (float)(_Float16)(float)y;
+        return;
+    }
     cx[t] = (verts[3ull * a] + verts[3ull * b] + verts[3ull * c]) / 3.0f;             // rover_utils.py:68-70
     cy[t] = (verts[3ull * a + 1] + verts[3ull * b + 1] + verts[3ull * c + 1]) / 3.0f;
 }
@@ -1240,12 +1249,17 @@ __global__ void __launch_bounds__(256) knn_bucket_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict__ cx, const float* __restrict__ cy,
                                                          const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ items,
                                                          float ox, float oy, float g, uint32_t nbx, uint32_t nby, uint32_t X,
-                                                         uint32_t Y, float res, uint32_t K, int32_t* __restrict__ out,
+                                                         uint32_t Y, float res, uint32_t K, const float* __restrict__ cell_x,
+                                                         const float* __restrict__ cell_y, int32_t* __restrict__ out,
                                                          int32_t* __restrict__ overflow) {
     __shared__ unsigned long long keys[KNN_CAP];
     __shared__ uint32_t count;
     const uint32_t cell = blockIdx.x, x = cell / Y, y = cell % Y, tid = threadIdx.x;
-    const float px = (float)x * res, py = (float)y * res;                   // rover_utils.py:75-81: cell (x, y) sits at (x res, y res)
+    // rover_utils.py:75-81: cell (x, y) sits at (x res, y res).  Reference ranking (cell_x != NULL): the fp16 coordinate tables
+    // of its torch.arange(..., dtype=float16), and distances as its fp16 tensors give them (:99-102): fp16(c - p) per axis,
+    // norm = sqrt of the f32 sum of squares, rounded to fp16; the key is that fp16 value, ties by triangle id.
+    const bool ref = cell_x != nullptr;
+    const float px = ref ? cell_x[x] : (float)x * res, py = ref ? cell_y[y] : (float)y * res;
     const float inv_g = 1.0f / g;
     const int bx = (int)knn_bucket(px, ox, inv_g, nbx), by = (int)knn_bucket(py, oy, inv_g, nby);
     const int rmax = (int)max(nbx, nby);
@@ -1268,9 +1282,11 @@ __global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict
             for (uint32_t k = s0; k < s1; ++k, ++base) {
                 if (base >= KNN_CAP) break;
                 const uint32_t t = items[k];
-                const float dx = cx[t] - px, dy = cy[t] - py;
+                float dx = cx[t] - px, dy = cy[t] - py;
+                if (ref) { dx = (float)(_Float16)dx; dy = (float)(_Float16)dy; }
                 const float d2 = dx * dx + dy * dy;
-                keys[base] = ((unsigned long long)__float_as_uint(d2) << 32) | t;
+                const float key = ref ? (float)(_Float16)sqrtf(d2) : d2;        // non-negative floats order like their bits
+                keys[base] = ((unsigned long long)__float_as_uint(key) << 32) | t;
             }
         }
         __syncthreads();
@@ -1294,9 +1310,11 @@ __global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict
                 }
             }
             // every triangle not gathered yet is at least r*g away (its bucket is > r rings out)
+            // (reference ranking: an ungathered triangle is >= reach away in the fp16-rounded coordinates and its fp16 distance is
+            //  at most a factor 1 - 2^-9.9 below that, so a K-th key strictly below reach (1 - 2^-9) cannot be undercut or tied)
             const float reach = (float)r * g;
             const float kth = n >= K ? __uint_as_float((uint32_t)(keys[K - 1] >> 32)) : __builtin_inff();
-            if (covers_all || kth <= reach * reach) {
+            if (covers_all || (ref ? kth < reach * (1.0f - 1.0f / 512.0f) : kth <= reach * reach)) {
                 for (uint32_t k = tid; k < K; k += 256) out[(uint64_t)cell * K + k] = k < n ? (int32_t)(uint32_t)keys[k] : 0;
                 return;
             }
@@ -1489,8 +1507,9 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
     return hipGetLastError();
 }
 
-hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, float* cx, float* cy, hipStream_t s) {
-    hipLaunchKernelGGL(knn_centroid_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, verts, tris, T, V, cx, cy);
+hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(knn_centroid_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, verts, tris, T, V, ref, cx, cy);
     return hipGetLastError();
 }
 
@@ -1511,10 +1530,10 @@ hipError_t launch_scan_exclusive(uint32_t* data, uint32_t n, uint32_t* block_sum
 }
 
 hipError_t launch_knn_select(const float* cx, const float* cy, const uint32_t* bucket_start, const uint32_t* items, float ox, float oy,
-                             float g, uint32_t nbx, uint32_t nby, uint32_t X, uint32_t Y, float res, uint32_t K, int32_t* out,
-                             int32_t* overflow, hipStream_t s) {
+                             float g, uint32_t nbx, uint32_t nby, uint32_t X, uint32_t Y, float res, uint32_t K, const float* cell_x,
+                             const float* cell_y, int32_t* out, int32_t* overflow, hipStream_t s) {
     hipLaunchKernelGGL(knn_select_kernel, dim3(X * Y), dim3(256), 0, s, cx, cy, bucket_start, items, ox, oy, g, nbx, nby, X, Y, res, K,
-                       out, overflow);
+                       cell_x, cell_y, out, overflow);
     return hipGetLastError();
 }
 

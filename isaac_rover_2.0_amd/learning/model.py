@@ -20,7 +20,7 @@ import torch
 
 class Layer:
     def __init__(self, in_channels, out_channels, activation_function="elu", device="cuda:0", generator=None):
-        bound = 1.0 / math.sqrt(in_channels)                     # nn.Linear.reset_parameters
+        bound = 1.0 / math.sqrt(in_channels) if in_channels > 0 else 0.0      # nn.Linear.reset_parameters (fan_in 0: zeros)
         self.weight = (torch.rand(out_channels, in_channels, generator=generator) * 2 - 1).mul_(bound).to(device)
         self.bias = (torch.rand(out_channels, generator=generator) * 2 - 1).mul_(bound).to(device)
         self.activation = activation_function
@@ -48,7 +48,8 @@ class HeightmapNet:
         for f in mlp_features:
             self.network.append(mk(i, f, activation_function)); i = f
         self.network.append(mk(i, num_outputs, head_activation))                          # :181-182 / :226
-        self.log_std_parameter = torch.zeros(num_outputs, device=device)                  # :183
+        # :183 — only the stochastic actor owns a log-std parameter (DeterministicHeightmap has none, :197-241)
+        self.log_std_parameter = torch.zeros(num_outputs, device=device) if head_activation == "tanh" else None
         self._bufs = {}
 
     def _buf(self, key, rows, cols):
@@ -77,7 +78,7 @@ class HeightmapNet:
 
     # ---- interop with the reference's nn.Module parameter names --------------------------------------------
     def state_dict(self):
-        sd = {"log_std_parameter": self.log_std_parameter}
+        sd = {} if self.log_std_parameter is None else {"log_std_parameter": self.log_std_parameter}
         for name, enc in (("encoder0", self.encoder0), ("encoder1", self.encoder1)):
             for i, l in enumerate(enc):
                 sd[f"{name}.encoder.{i}.layer.0.weight"] = l.weight

@@ -401,3 +401,19 @@ def ray_distribution(name: str):
         raise ValueError(name)
     return (np.asarray(pts, dtype=np.float64), np.asarray(sparse, dtype=np.int64),
             np.asarray(dense, dtype=np.int64))
+
+
+def knn_test_mesh(kind: str):
+    """Meshes of the KNN-builder parity fixtures (tests/golden/knn_*.npz were captured from the reference's own
+    ``_get_knn_triangles`` on exactly these): -> (vertices [V,3] f32, triangles [T,3] i32, builder arguments)."""
+    if kind == "grid10m":                # regular 0.1 m grid mesh over 10 m x 10 m, the terrain generator's triangulation
+        verts, tris, _ = grid_mesh(101, seed=1)
+        return verts.astype(np.float32), tris.astype(np.int32), dict(res_x=100, res_y=100, res=0.1, n_triangles=16)
+    if kind == "soup50m":                # irregular triangle soup over 50 m: coordinates where fp16 spacing is 0.03 m
+        rng = np.random.default_rng(77)
+        n = 6000
+        centers = rng.uniform(-1.0, 50.0, (n, 1, 2))
+        verts = np.concatenate([centers + rng.normal(0, 0.3, (n, 3, 2)), rng.normal(0, 0.2, (n, 3, 1))], axis=2)
+        return verts.reshape(-1, 3).astype(np.float32), np.arange(3 * n, dtype=np.int32).reshape(n, 3), \
+            dict(res_x=100, res_y=100, res=0.5, n_triangles=12)
+    raise ValueError(kind)

@@ -198,19 +198,7 @@ def main():
     next_rows(ref2, g)
 
 
-def knn_mesh(kind):
-    """Meshes of the KNN-builder fixtures, rebuilt bit-identically by the tests (only parameters + a digest are stored)."""
-    if kind == "grid10m":                # regular 0.1 m grid mesh over 10 m x 10 m, the terrain generator's triangulation
-        verts, tris, _ = synth.grid_mesh(101, seed=1)
-        return verts.astype(np.float32), tris.astype(np.int32), dict(res_x=100, res_y=100, res=0.1, n_triangles=16)
-    if kind == "soup50m":                # irregular triangle soup over 50 m: coordinates where fp16 spacing is 0.03 m
-        rng = np.random.default_rng(77)
-        n = 6000
-        centers = rng.uniform(-1.0, 50.0, (n, 1, 2))
-        verts = np.concatenate([centers + rng.normal(0, 0.3, (n, 3, 2)), rng.normal(0, 0.2, (n, 3, 1))], axis=2)
-        return verts.reshape(-1, 3).astype(np.float32), np.arange(3 * n, dtype=np.int32).reshape(n, 3), \
-            dict(res_x=100, res_y=100, res=0.5, n_triangles=12)
-    raise ValueError(kind)
+knn_mesh = synth.knn_test_mesh      # the meshes are rebuilt bit-identically by the tests (parameters + a digest are stored)
 
 
 def mesh_digest(verts, tris):

@@ -18,8 +18,9 @@ def make_engine(scene, distribution, num_envs, variant=2, run=None, **kw):
     return eng
 
 
-def hip_step(eng, st, compact=True, fused=True):
-    """One post_physics_step on the GPU. Returns a dict of CPU numpy arrays named like the oracle's."""
+def hip_step(eng, st, compact=True, fused=True, stone_margin=None):
+    """One post_physics_step on the GPU. Returns a dict of CPU numpy arrays named like the oracle's.
+    ``stone_margin``: also request the stone_info occupancy mask (BASELINE configs[2]) -> out["stone_collision"]."""
     dev = eng.device
     e = eng.num_envs
     d = {k: v.to(dev).contiguous() for k, v in st.items()}
@@ -34,7 +35,9 @@ def hip_step(eng, st, compact=True, fused=True):
                 ray_dist=torch.zeros(e, eng.P, device=dev), wheel_dist=torch.zeros(e, 24, device=dev),
                 body_dist=torch.zeros(e, 2, device=dev))
     extras = {k: torch.zeros(e, dtype=EXTRA_DT[k], device=dev) for k in _lib.EXTRAS}
-    sout = eng.make_out(obs, extras=extras, **bufs)
+    done_u8 = torch.full((e,), 7, dtype=torch.uint8, device=dev)
+    stone = None if stone_margin is None else torch.full((e,), -1, dtype=i64, device=dev)
+    sout = eng.make_out(obs, extras=extras, done_u8=done_u8, stone_collision=stone, stone_margin=stone_margin or 0.0, **bufs)
     if fused:
         eng.step(sin, sout, increment_progress=True, compact=compact)
     else:   # the reference's method split, rl_task.py:250-257
@@ -50,6 +53,10 @@ def hip_step(eng, st, compact=True, fused=True):
                obs_buf=obs, rew_buf=bufs["rew"], reset_buf=bufs["reset"], progress_buf=progress)
     for k in _lib.EXTRAS:
         out["extras_" + k] = extras[k]
+    if fused or True:
+        out["done_u8"] = done_u8
+    if stone is not None:
+        out["stone_collision"] = stone
     out = {k: v.cpu().numpy() for k, v in out.items()}
     n = int(bufs["n_reset"].item())
     out["reset_ids"] = bufs["reset_ids"][:n].cpu().numpy()

@@ -36,8 +36,9 @@ def test_full_size_invariants(full):
     b = _run(scene, distn, st, variant=1)
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    # (2) compaction = nonzero(reset_buf), ascending
+    # (2) compaction = nonzero(reset_buf), ascending; the one-byte done flags that travel in the multi-GPU gather agree
     np.testing.assert_array_equal(a["reset_ids"], np.nonzero(a["reset_buf"])[0])
+    np.testing.assert_array_equal(a["done_u8"], a["reset_buf"].astype(np.uint8))
     # (3) obs layout: [dist/9, heading/pi, lin, ang | ray distances / 2]; misses are exactly 11/2, hits bounded
     assert a["obs_buf"].shape == (E, 41)
     np.testing.assert_array_equal(a["obs_buf"][:, 4:], a["ray_dist"] / 2.0)
@@ -84,3 +85,111 @@ def test_full_size_step_is_repeatable(full):
     b = _run(scene, distn, st)
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_full_size_stone_mask_equals_clearance(full):
+    """BASELINE configs[2] "stone_info collision mask" on ALL 65 536 envs over 1 024 stones: the mask the step emits through
+    the stone-occupancy grid equals (rover_clearance(pos_xy) <= margin) — the exact clearance min over every stone
+    (rover.py:536-539) — for the margins 0, 1.0 (:539) and 1.4 (:660); envs whose clearance is within 1e-4 of the margin are
+    exempt.  A 512-env sample of the clearance itself is checked against the oracle."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    from oracle import oracle as orc
+    scene, distn, st = full
+    eng = make_engine(scene, distn, E)
+    xy = st["pos"][:, 0:2].contiguous().cuda()
+    clear = eng.clearance(xy).cpu().numpy()
+    info = synth.read_stone_info_array(scene.stone_info_raw)
+    idx = np.random.default_rng(5).choice(E, 512, replace=False)
+    np.testing.assert_allclose(clear[idx], orc.clearance(info, st["pos"][idx, 0:2]), rtol=0, atol=2e-5)
+    base = None
+    for margin in (0.0, 1.0, 1.4):
+        out = hip_step(eng, st, stone_margin=margin)
+        want = clear <= margin
+        sure = np.abs(clear - margin) > 1e-4
+        np.testing.assert_array_equal(out["stone_collision"][sure] == 1, want[sure], err_msg=f"margin {margin}")
+        assert set(np.unique(out["stone_collision"])) <= {0, 1}
+        assert 0.02 < want.mean() < 0.98, "the case must have both outcomes"
+        if base is None:
+            base = out
+        for k in ("obs_buf", "rew_buf", "reset_buf", "rock_collision"):      # the mask never feeds reward or done
+            np.testing.assert_array_equal(out[k], base[k], err_msg=k)
+    eng.close()
+
+
+def test_full_size_config4_dense_rays_and_goal_validation():
+    """BASELINE configs[4]: 65 536 envs, 120-point dense heightmap, then the device-side reset + spawn-goal validation of the
+    envs the step flagged (rover_reset_envs over 1 024 stones, count read on the device).  Properties: the two ray-cast
+    algorithms agree bit for bit on all 9.6 M rays; every re-drawn goal has clearance > 1.0 (rover.py:539) and sits at radius
+    8 (:578) from its spawn; reset / progress are zeroed exactly for the compacted ids; a 256-entry list with caller-supplied
+    draws equals the sequential oracle."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    from oracle import oracle as orc
+    scene = synth.make_scene(n_cells=CELLS, k=K, n_stones=1024, device="cuda")
+    distn = synth.ray_distribution("120")
+    st = synth.make_states(E, CELLS * 0.1, seed=9)
+    outs = {}
+    for variant in (2, 1):
+        eng = make_engine(scene, distn, E, variant=variant)
+        outs[variant] = hip_step(eng, st)
+        if variant == 1:
+            eng.close()
+        else:
+            eng2 = eng
+    a = outs[2]
+    for k in a:
+        np.testing.assert_array_equal(a[k], outs[1][k], err_msg=k)
+    assert a["obs_buf"].shape == (E, 124)
+    np.testing.assert_array_equal(a["obs_buf"][:, 4:], a["ray_dist"] / 2.0)
+    idx = np.random.default_rng(2).choice(E, 128, replace=False)
+    t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
+    want = orc.step(t, r, {k: v[idx] for k, v in st.items()}, *distn, num_envs_global=E)
+    got = {k: v[idx] for k, v in a.items() if k != "reset_ids"}
+    assert_step_close(got, {"out_" + k: v for k, v in want.items()}, "cfg4 sample")
+
+    # ---- reset + goal validation for the flagged envs, all on the device ----
+    eng = eng2
+    dev = eng.device
+    n = len(a["reset_ids"])
+    assert 1000 < n < E
+    ids = torch.zeros(E, dtype=torch.int64, device=dev)
+    ids[:n] = torch.from_numpy(a["reset_ids"]).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    initial = st["pos"].clone().cuda()
+    pos = torch.zeros(E, 3, device=dev); quat = torch.zeros(E, 4, device=dev)
+    target_before = st["target"].clone()
+    target = st["target"].clone().cuda()
+    reset = torch.from_numpy(a["reset_buf"]).to(dev); progress = torch.from_numpy(a["progress_buf"]).to(dev)
+    used = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng.reset_envs(ids, initial, pos, quat, reset, progress, n_reset_dev=n_dev, target3=target, radius=8.0, seed=4242,
+                   max_draws=256, n_draws_used=used)
+    torch.cuda.synchronize()
+    assert int(used.item()) >= 1, "every listed env found a clear goal within 256 draws"
+    rid = a["reset_ids"]
+    touched = np.union1d(rid, [0])                                    # env 0: the env_ids = mask*env_ids quirk (rover.py:540)
+    tgt = target.cpu().numpy()
+    c = eng.clearance(target[torch.from_numpy(touched).to(dev)][:, 0:2].contiguous()).cpu().numpy()
+    assert (c > 1.0).all(), f"{(c <= 1.0).sum()} accepted goals violate the clearance"
+    rad = np.linalg.norm(tgt[touched, 0:2] - st["pos"].numpy()[touched, 0:2], axis=1)
+    np.testing.assert_allclose(rad, 8.0, atol=1e-4)
+    np.testing.assert_array_equal(tgt[touched, 2], eng.sample_height(target[torch.from_numpy(touched).to(dev)][:, 0:2].contiguous()).cpu().numpy())
+    others = np.setdiff1d(np.arange(E), touched)
+    np.testing.assert_array_equal(tgt[others], target_before.numpy()[others])
+    np.testing.assert_array_equal(pos.cpu().numpy()[rid], st["pos"].numpy()[rid])
+    np.testing.assert_allclose(np.linalg.norm(quat.cpu().numpy()[rid], axis=1), 1.0, atol=1e-6)
+    assert (reset.cpu().numpy()[rid] == 0).all() and (progress.cpu().numpy()[rid] == 0).all()
+    np.testing.assert_array_equal(reset.cpu().numpy()[others], a["reset_buf"][others])
+    np.testing.assert_array_equal(progress.cpu().numpy()[others], a["progress_buf"][others])
+    # ---- 256 entries with supplied draws vs the sequential oracle (1 024 stones) ----
+    info = synth.read_stone_info_array(scene.stone_info_raw)
+    sub = rid[:: max(1, n // 256)][:256].astype(np.int64)
+    draws = np.random.default_rng(8).random((128, len(sub))).astype(np.float32)
+    want_t, want_used = orc.generate_goals(info, sub, st["pos"].numpy(), draws, radius=8.0)
+    t2 = torch.zeros(E, 3, device=dev)
+    used2 = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng.generate_goals(torch.from_numpy(sub).to(dev), initial, t2, radius=8.0, draws=torch.from_numpy(draws).to(dev), n_draws_used=used2)
+    assert int(used2.item()) == want_used
+    np.testing.assert_allclose(t2[:, 0:2].cpu().numpy(), want_t[:, 0:2], rtol=1e-6, atol=1e-5)
+    eng.close()

@@ -430,8 +430,14 @@ def test_cell_index_mode_cuda_rcp_matches_oracle_and_differs_on_ties():
         finally:
             orc.set_cell_index_mode("cpu_div")
         for variant in (2, 1):
-            for key in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
-                np.testing.assert_array_equal(got[(mode, variant)][key], want[mode][key], err_msg=f"{name} v{variant} {key}")
+            g = got[(mode, variant)]
+            # tie envs: identity orientation -> no trig ulps between OCML and glibc -> the terrain ray must agree bit for bit
+            np.testing.assert_array_equal(g["ray_dist"][tie_envs], want[mode]["ray_dist"][tie_envs], err_msg=f"{name} v{variant}")
+            for key in ("ray_dist", "wheel_dist", "body_dist"):
+                np.testing.assert_allclose(g[key], want[mode][key], rtol=1e-5, atol=1e-5, err_msg=f"{name} v{variant} {key}")
+            for key in ("rock_collision", "reset_buf"):
+                np.testing.assert_array_equal(g[key], want[mode][key], err_msg=f"{name} v{variant} {key}")
+        np.testing.assert_array_equal(got[(mode, 2)]["ray_dist"], got[(mode, 1)]["ray_dist"])
     differs = np.nonzero((got[(0, 2)]["ray_dist"] != got[(1, 2)]["ray_dist"]).any(axis=1))[0]
     assert len(differs) >= 4 and set(differs) <= set(tie_envs)
     # heightfield lookup (rover.py:588-608): unique value per cell -> the chosen cell is visible

@@ -1,0 +1,198 @@
+"""GPU (-m gpu): the "next" rows f-2 / f-3 / f-4 against golden vectors captured from the reference's OWN code
+(oracle/gen_golden.py: RoverTask.reset_idx, rover_utils._get_knn_triangles, learning/model.py's networks) — not against
+restatements written for the test."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_QUAT = 1e-6          # reset orientation: f32 sin/cos of d/2 vs scipy's float64 quaternion cast to f32
+TOL_NET_ABS, TOL_NET_REL = 2e-5, 2e-4      # f32 MFMA accumulation order vs the reference's nn.Linear on CPU (MKL sgemm)
+
+
+# --------------------------------------------------------------------------------------------------------------- f-2
+def _reset_state(fx, dev):
+    e = fx["initial_pos"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    return dict(initial=torch.from_numpy(fx["initial_pos"]).to(dev), pos=torch.randn(e, 3, generator=g).to(dev),
+                quat=torch.randn(e, 4, generator=g).to(dev), jp=torch.randn(e, 13, generator=g).to(dev),
+                jv=torch.randn(e, 13, generator=g).to(dev), base=torch.from_numpy(fx["base_pos_in"]).to(dev),
+                reset=torch.from_numpy(fx["reset_buf_in"]).to(dev), progress=torch.from_numpy(fx["progress_buf_in"]).to(dev))
+
+
+def _check_reset(fx, st, before):
+    ids = fx["env_ids"]
+    others = np.setdiff1d(np.arange(fx["initial_pos"].shape[0]), ids)
+    got = {k: v.cpu().numpy() for k, v in st.items()}
+    # what reset_idx handed to set_world_poses (rover.py:449): base_pos[ids] and the scipy (x,y,z,w) quaternion read as (w,x,y,z)
+    np.testing.assert_array_equal(got["pos"][ids], fx["out_pose_pos"])
+    np.testing.assert_allclose(got["quat"][ids], fx["out_pose_quat"], atol=TOL_QUAT, rtol=0)
+    np.testing.assert_array_equal(fx["out_pose_indices"], ids)
+    # set_joint_positions / set_joint_velocities (:439-440): zeros for the listed envs
+    np.testing.assert_array_equal(got["jp"][ids], fx["out_joint_pos"])
+    np.testing.assert_array_equal(got["jv"][ids], fx["out_joint_vel"])
+    # self.base_pos (:442), reset_buf / progress_buf (:452-453): whole arrays, untouched envs included
+    np.testing.assert_array_equal(got["base"], fx["out_base_pos"])
+    np.testing.assert_array_equal(got["reset"], fx["out_reset_buf"])
+    np.testing.assert_array_equal(got["progress"], fx["out_progress_buf"])
+    assert got["reset"][3] == 1                                    # flagged but not listed: stays flagged
+    for k in ("pos", "quat", "jp", "jv"):
+        np.testing.assert_array_equal(got[k][others], before[k][others], err_msg=k)
+
+
+@pytest.mark.parametrize("count_on_device", [False, True])
+def test_reset_envs_matches_reference_reset_idx(count_on_device):
+    """rover_reset_envs (reset_envs_kernel) vs RoverTask.reset_idx of the reference (rover.py:416-453) run unbound with
+    random.randint fed the same degrees: poses, the scipy-order yaw quirk (:429-431,:449), joint zeroing, bookkeeping."""
+    from isaac_rover_amd import _lib
+    fx = load_golden("reset_idx")
+    e = fx["initial_pos"].shape[0]
+    eng = _lib.Engine(e, device=0)
+    dev = eng.device
+    st = _reset_state(fx, dev)
+    before = {k: v.cpu().numpy().copy() for k, v in st.items()}
+    n = len(fx["env_ids"])
+    ids = torch.zeros(e, dtype=torch.int64, device=dev)
+    ids[:n] = torch.from_numpy(fx["env_ids"]).to(dev)
+    yaw = torch.zeros(e, dtype=torch.int32, device=dev)
+    yaw[:n] = torch.from_numpy(fx["degrees"]).to(dev)
+    kw = dict(n_reset_dev=torch.tensor([n], dtype=torch.int32, device=dev)) if count_on_device else dict(n_reset_host=n)
+    eng.reset_envs(ids, st["initial"], st["pos"], st["quat"], st["reset"], st["progress"], joint_pos13=st["jp"],
+                   joint_vel13=st["jv"], base_pos3=st["base"], yaw_deg=yaw, **kw)
+    torch.cuda.synchronize()
+    _check_reset(fx, st, before)
+    eng.close()
+
+
+def test_task_reset_idx_matches_reference():
+    """The host-side RoverTask.reset_idx of this package (the reference-shaped control flow, device_reset=False) against the
+    same fixture."""
+    from isaac_rover_amd import synth
+    from isaac_rover_amd.config import SimConfig
+    from isaac_rover_amd.tasks.rover import RoverTask
+    from isaac_rover_amd.vec_env import VecEnv
+    fx = load_golden("reset_idx")
+    e = fx["initial_pos"].shape[0]
+    scene = synth.make_scene(n_cells=128, k=16, n_stones=10)
+    env = VecEnv(headless=True)
+    task = RoverTask("Rover", SimConfig(num_envs=e, device="cuda:0"), env, scene=scene, distribution=synth.ray_distribution("9"),
+                     device_reset=False)
+    env.set_task(task, sim_params={"dt": 0.05})
+    dev = "cuda:0"
+    st = _reset_state(fx, dev)
+    rv = task._rover
+    rv._pos.copy_(st["pos"]); rv._quat.copy_(st["quat"]); rv._joint_pos.copy_(st["jp"]); rv._joint_vel.copy_(st["jv"])
+    task.initial_pos = st["initial"]
+    task.base_pos = st["base"]
+    task.reset_buf.copy_(st["reset"]); task.progress_buf.copy_(st["progress"])
+    before = {k: v.cpu().numpy().copy() for k, v in st.items()}
+    task.reset_idx(torch.from_numpy(fx["env_ids"]).to(dev), yaw_deg=torch.from_numpy(fx["degrees"]).to(dev))
+    torch.cuda.synchronize()
+    got = dict(pos=rv._pos, quat=rv._quat, jp=rv._joint_pos, jv=rv._joint_vel, base=task.base_pos, reset=task.reset_buf,
+               progress=task.progress_buf, initial=st["initial"])
+    _check_reset(fx, got, before)
+    env.close()
+
+
+# --------------------------------------------------------------------------------------------------------------- f-3
+def _fp16_distances(verts, tris, cell_x, cell_y, i):
+    """The reference's distances for map row i (rover_utils.py:68-72,99-100): fp16 centroids (float64 mean -> float -> half),
+    fp16(c - p) per axis, norm in f32 rounded to fp16.  Returns [Y, T] fp16."""
+    v = verts.astype(np.float64)
+    cx = ((v[tris[:, 0], 0] + v[tris[:, 1], 0] + v[tris[:, 2], 0]) / 3).astype(np.float32).astype(np.float16).astype(np.float32)
+    cy = ((v[tris[:, 0], 1] + v[tris[:, 1], 1] + v[tris[:, 2], 1]) / 3).astype(np.float32).astype(np.float16).astype(np.float32)
+    dx = (cx - np.float32(cell_x[i])).astype(np.float16).astype(np.float32)
+    dy = (cy[None, :] - cell_y.astype(np.float32)[:, None]).astype(np.float16).astype(np.float32)
+    return np.sqrt(dx[None, :] * dx[None, :] + dy * dy).astype(np.float16)
+
+
+@pytest.mark.parametrize("kind", ["grid10m", "soup50m"])
+def test_knn_builder_matches_the_reference_builder(kind):
+    """rover_build_knn_map_ref vs maps built by the reference's own _get_knn_triangles (tasks/utils/rover_utils.py:52-118;
+    only o3d.io.read_triangle_mesh replaced).  Per cell: the multiset of fp16 distances of the K chosen triangles is identical,
+    every triangle strictly nearer than the K-th distance is in both lists, nothing farther is in either — i.e. the lists may
+    differ only by swaps among triangles tied with the K-th fp16 distance (torch.topk leaves that order unspecified).  The
+    on-disk vertices / triangles tensors (:113-118) are byte-identical."""
+    from isaac_rover_amd import _lib, assets, synth
+    fx = load_golden("knn_" + kind)
+    verts, tris, kw = synth.knn_test_mesh(kind)
+    h = hashlib.sha256(); h.update(np.ascontiguousarray(verts).tobytes()); h.update(np.ascontiguousarray(tris).tobytes())
+    assert h.hexdigest() == str(fx["mesh_digest"]), "test mesh drifted from the one the reference built its map on"
+    x, y, res, k = int(fx["res_x"]), int(fx["res_y"]), float(fx["res"]), int(fx["n_triangles"])
+    eng = _lib.Engine(8, device=0)
+    m = assets.build_knn_map(eng, verts, tris, n_cells=x, res=res, k=k, ranking="reference_fp16", cell_x_f16=fx["cell_x_f16"],
+                             cell_y_f16=fx["cell_y_f16"])
+    got = m.map_indices.numpy().astype(np.int64)                          # [X, Y, K]
+    ref = np.transpose(fx["map_indices_kxy"].astype(np.int64), (1, 2, 0))  # saved as [K, X, Y] (rover_utils.py:108-113)
+    assert hashlib.sha256(m.vertices.numpy().tobytes()).hexdigest() == str(fx["vertices_f16_digest"])
+    assert hashlib.sha256(m.triangles.numpy().tobytes()).hexdigest() == str(fx["triangles_digest"])
+    n_swapped = 0
+    ids = np.arange(tris.shape[0])
+    for i in range(x):
+        d = _fp16_distances(verts, tris, fx["cell_x_f16"], fx["cell_y_f16"], i)      # [Y, T]
+        dg = np.take_along_axis(d, got[i], axis=1).astype(np.float32)                 # [Y, K]
+        dr = np.take_along_axis(d, ref[i], axis=1).astype(np.float32)
+        np.testing.assert_array_equal(np.sort(dg, axis=1), np.sort(dr, axis=1), err_msg=f"row {i}: fp16 distance multisets")
+        assert (np.diff(dg, axis=1) >= 0).all(), f"row {i}: list not ascending"
+        kth = dg[:, -1:]
+        nearer = d.astype(np.float32) < kth                                           # must be in both lists
+        for lst in (got[i], ref[i]):
+            member = np.zeros_like(nearer)
+            np.put_along_axis(member, lst, True, axis=1)
+            assert not (nearer & ~member).any(), f"row {i}: a strictly nearer triangle is missing"
+            assert (member.sum(axis=1) == k).all(), f"row {i}: duplicate triangle ids"
+        # own tie rule: among equal fp16 distances ascending triangle id
+        tie = np.diff(dg, axis=1) == 0
+        assert (np.diff(got[i], axis=1)[tie] > 0).all()
+        n_swapped += int((np.sort(got[i], axis=1) != np.sort(ref[i], axis=1)).any(axis=1).sum())
+    print(f"{kind}: {n_swapped} of {x * y} cells differ from the reference by swaps inside the K-th tie class")
+    # default coordinate tables = ATen's CUDA arange, fp16(float(i) * res): same call without tables must equal explicit ones
+    tab = (np.arange(x, dtype=np.float32) * np.float32(res)).astype(np.float16)
+    a = eng.build_knn_map(verts, tris, x, y, res, k, ranking="reference_fp16").cpu().numpy()
+    b = eng.build_knn_map(verts, tris, x, y, res, k, ranking="reference_fp16", cell_x_f16=tab, cell_y_f16=tab).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    eng.close()
+
+
+# --------------------------------------------------------------------------------------------------------------- f-4
+def _load(net, fx, tag):
+    sd = {k[len(tag) + 1:]: torch.from_numpy(v.astype(np.float32)) for k, v in fx.items() if k.startswith(tag + ".")}
+    assert set(sd) == set(net.state_dict()), "parameter names must be the reference's (state_dict interop)"
+    net.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("name", ["policy_native", "policy_p37"])
+def test_policy_forward_matches_reference_modules(name):
+    """HeightmapNet (rover_linear_forward, f32 MFMA) with a state_dict saved from the reference's StochasticActorHeightmap /
+    DeterministicHeightmap (learning/model.py:152-241, built by the reference's constructors with skrl's base class stubbed)
+    against the outputs those modules computed: both encoders (:122-150), the actor mean (Tanh head, :185-195) and the
+    critic value (:231-241).  policy_p37 has an EMPTY dense slice: Encoder(0, ...) = activation(bias)."""
+    from isaac_rover_amd import _lib
+    from isaac_rover_amd.learning.model import HeightmapNet
+    fx = load_golden(name)
+    nobs, ns, nd = int(fx["num_observations"]), int(fx["num_sparse"]), int(fx["num_dense"])
+    eng = _lib.Engine(8, device=0)
+    x = torch.from_numpy(fx["states"].astype(np.float32)).cuda()
+    actor = HeightmapNet(eng, nobs, ns, nd, 2, "tanh")
+    _load(actor, fx, "actor")
+    out = actor.compute(x)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), fx["out_actor"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    cat = actor._bufs["cat"].cpu().numpy()
+    p = nobs - ns - nd
+    np.testing.assert_array_equal(cat[:, :p], fx["states"].astype(np.float32)[:, :p])
+    np.testing.assert_allclose(cat[:, p:p + 60], fx["out_actor_encoder0"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    np.testing.assert_allclose(cat[:, p + 60:p + 120], fx["out_actor_encoder1"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    np.testing.assert_array_equal(actor.log_std_parameter.cpu().numpy(), fx["out_log_std"])
+    if "out_critic" in fx:
+        critic = HeightmapNet(eng, nobs, ns, nd, 1, None)
+        _load(critic, fx, "critic")
+        v = critic.compute(x)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(v.cpu().numpy(), fx["out_critic"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    eng.close()

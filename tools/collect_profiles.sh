@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 benc
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $P/pmc1.err
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/pmc2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $P/pmc2.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $P/pmc3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $P/pmc3.err
-python3 tools/profile_summary.py $P/stats $P/pmc1 $P/pmc2 $P/pmc3 --out "$OUT" --tag "$TAG"
+python3 tools/profile_summary.py $P/stats $P/pmc1 $P/pmc2 $P/pmc3 --out "$OUT" --tag "$TAG" --workload-key E65536_P37_K200_C600
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> /dev/null
 python3 bench.py --envs-per-gpu 4096 --steps 1000 --warmup 100 > "$OUT/${TAG}_bench_4096envs.json" 2> /dev/null
 python3 bench.py --rays 120 --validate-goals > "$OUT/${TAG}_bench_cfg5_120rays_goalvalidation.json" 2> /dev/null

@@ -8,6 +8,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("dirs", nargs="+")
 ap.add_argument("--out", required=True)
 ap.add_argument("--tag", required=True)
+ap.add_argument("--workload-key", default="", help="e.g. E65536_P37_K200_C600: also write traffic.json / valu.json entries "
+                                                     "(read by bench.py's roofline object) for the ray-cast kernel")
 a = ap.parse_args()
 os.makedirs(a.out, exist_ok=True)
 pmc = {}
@@ -38,4 +40,25 @@ for d in a.dirs:
             pmc.setdefault(k, {})[c] = {"n": len(v), "mean": sum(v) / len(v)}
 if pmc:
     json.dump(pmc, open(os.path.join(a.out, f"{a.tag}_pmc_rover_kernels.json"), "w"), indent=1)
+if pmc and a.workload_key:
+    # the dominant kernel = the ray cast that ran in these passes (binned f32 / binned fp16 / env-order)
+    cands = [k for k in pmc if "raycast" in k and "SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k]]
+    if cands:
+        k = max(cands, key=lambda n: pmc[n]["SQ_INSTS_VALU"]["mean"])
+        c = pmc[k]
+        src = f"profiles/{a.tag}_pmc_rover_kernels.json"
+        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a 128-B read request as 64 B (MI355X_MICROARCH.md, HBM): x2
+        traffic = 2.0 * c["FETCH_SIZE"]["mean"] * 1024.0 + c["WRITE_SIZE"]["mean"] * 1024.0
+        t = {a.workload_key: {"hbm_bytes_per_launch": traffic, "kernel": k.split("(")[0],
+                              "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes); bytes = "
+                                        "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction); cross-check TCC_MISS_sum*128 B = "
+                                        f"{c['TCC_MISS_sum']['mean'] * 128.0:.4g}", "source": src}}
+        v = {a.workload_key: {"valu_insts_per_launch": c["SQ_INSTS_VALU"]["mean"],
+                              "valu_active_quadcycles_per_launch": c["SQ_ACTIVE_INST_VALU"]["mean"],
+                              "wave_quadcycles_per_launch": c["SQ_WAVE_CYCLES"]["mean"], "salu_insts_per_launch": c["SQ_INSTS_SALU"]["mean"],
+                              "kernel": k.split("(")[0], "source": src,
+                              "method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES "
+                                        "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY, mean over the launches of the pass"}}
+        json.dump(t, open(os.path.join(a.out, "traffic_entry.json"), "w"), indent=1)
+        json.dump(v, open(os.path.join(a.out, "valu_entry.json"), "w"), indent=1)
 print("wrote", os.listdir(a.out))
