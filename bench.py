@@ -253,7 +253,7 @@ def roofline(args, E, n_rays, prof, info):
     hbm = None
     if traffic and t > 0:
         hbm = {"traffic": traffic, "GBps": traffic / t / 1e9, "frac_of_8TBps": traffic / t / 1e9 / HBM_PEAK_GBS}
-    return {"bound": "valu", "kernel": "raycast_binned_kernel" if info.raycast_variant == 2 else "raycast_kernel",
+    return {"bound": "valu", "kernel": {3: "raycast_culled_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
             "achieved": achieved, "peak": peak, "unit": "G VALU-issue cycles/s (1024 SIMDs x 2.4 GHz)", "frac": frac,
             "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches),
             "valu_insts_per_ray": insts_per_ray, "rays_per_launch": rays, "hbm": hbm,

@@ -241,14 +241,17 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers
- *        (needs K <= 256 on both maps).  Both give bit-identical results; auto picks 2 when it applies and a step casts
- *        more than 131 072 rays (below that the binning passes cost more than they save), or when ray_precision = 2.
+ *        (needs K <= 256 on both maps); 3 = culled: the sorted rays of 2, but a conservative bounding-sphere + normal test
+ *        (12 B per triangle, built at rover_set_knn_map) first proves for most (ray, triangle) pairs that ray_casting.py:59
+ *        rejects them, and only the remaining candidates get the exact arithmetic (csrc/rover_cull.hip; f32 arithmetic only).
+ *        All give bit-identical results; auto picks 3 (2 when ray_precision = 2) when a step casts more than 131 072 rays
+ *        (below that the binning passes cost more than they save: 1).
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
  *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
  *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.
  *        2 = AS SHIPPED: (1) plus every operation of ray_casting.py:31-59 rounded to fp16 the way ATen's Half kernels do,
  *        and fp16 collision thresholds (rover.py:667-668).  Bit-identical to the as-shipped reference on ray origins,
- *        distances, collision mask and done flags (needs ray-cast variant 2).
+ *        distances, collision mask and done flags (runs ray-cast variant 2).
  * name = "bin_low_bits": width of the low digit of the ray bucket sort, 8..12 (default 10).
  * name = "raycast_early_out": 1 (default) = the binned kernel drops a whole packed pair of triangles per lane (the far half
  *        of a cell's K-nearest list; on the rocks map also the near half) when a conservative test on the numerators shows that
@@ -258,16 +261,17 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
  *        vectors (captured from the reference on CPU) pin.  1 = cuda_rcp: multiplication by 1.0f / 0.1f = 10.0f, what ATen's
  *        CUDA kernel does ("a * reciprocal(b)" for a CPU-scalar divisor) — the device the reference actually runs on.  The
  *        two differ only for coordinates within an ulp of a .5 tie of the cell grid (tests/test_oracle_golden.py).
- * name = "raycast_run": sorted rays per wave for variant 2 (default 0 = auto: 32 on full batches, down to 4 on small ones). */
+ * name = "raycast_run": sorted rays per wave for variants 2 and 3 (default 0 = auto: 32 on full batches, down to 4 on small
+ *        ones; variant 3 caps it at 64). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
 
 /* ---- introspection (bench / roofline) ---------------------------------------------------------------- */
 typedef struct {
     int32_t P, Ns, Nd, rays_per_env_padded;
     int32_t K[2], K8[2], X[2], Y[2];
-    uint64_t table_bytes[2];       /* re-packed per-cell fp16 tables */
+    uint64_t table_bytes[2];       /* re-packed per-cell fp16 tables + cull tables */
     uint64_t workspace_bytes;
-    int32_t raycast_variant;       /* the variant the next step will run (1 or 2) */
+    int32_t raycast_variant;       /* the variant the next step will run (1, 2 or 3) */
 } rover_info;
 ROVER_API int rover_get_info(const rover_ctx *ctx, rover_info *info);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -21,6 +21,10 @@ struct rover_ctx {
     KnnDev map[2]{};
     uint64_t table_bytes[2]{0, 0};
     bool have_map[2]{false, false};
+    // cull tables of the culled ray cast (variant 3): per triangle a bounding-sphere centre + scaled unit normal, 12 B
+    uint4* cull[2]{nullptr, nullptr};
+    float4* cull_cen[2]{nullptr, nullptr};
+    uint64_t cull_bytes[2]{0, 0};
     // distribution
     double* d_dist = nullptr;       // [P][3]
     int32_t* d_obs_idx = nullptr;   // [Ns+Nd]
@@ -56,6 +60,7 @@ struct rover_ctx {
     int last_variant = 1;
     bool sorted_valid = false;
     uint32_t run = 0;                   // option "raycast_run": 0 = auto (effective_run)
+    uint32_t cull_waves = 0;            // option "cull_waves": kernel build of the culled ray cast (0, 6, 7, 8)
     uint32_t early_out = 1;             // option "raycast_early_out": conservative whole-pair rejection (bit-identical results)
     int32_t cell_rcp = 0;               // option "cell_index_mode": 0 cpu_div (x / 0.1), 1 cuda_rcp (x * (1 / 0.1))
     uint64_t workspace_bytes = 0;
@@ -137,7 +142,10 @@ static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
     if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
-    return 2;
+    // variant 3 (culled): f32 arithmetic only — the as-shipped fp16 mode keeps the binned kernel
+    const bool v3_ok = c->cull[0] && c->cull[1] && c->precision != 2;
+    if (c->variant == 2 || !v3_ok) return 2;
+    return 3;
 }
 
 // Sorted rays per wave.  Long runs amortise a cell's set-up (65 536 envs, ray cast only: run 12 -> 1.183 ms, 16 -> 1.171,
@@ -227,7 +235,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull[w]); dfree(c->cull_cen[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -273,10 +281,27 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         return fail(c, ROVER_E_HIP, "set_knn_map: %s", hipGetErrorString(e));
     }
     cleanup();
+    // cull table of the culled ray cast (64 lanes x 4 triangles, cell id + map bit in 32 bits)
+    uint4* d_cull = nullptr;
+    float4* d_cen = nullptr;
+    uint64_t cull_bytes = 0;
+    if (K8 <= 256 && n_cells < 0x80000000ull) {
+        cull_bytes = n_cells * (3ull * (K8 / 4) * sizeof(uint4) + sizeof(float4));
+        if ((e = hipMalloc((void**)&d_cull, n_cells * 3ull * (K8 / 4) * sizeof(uint4))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_cen, n_cells * sizeof(float4))) != hipSuccess ||
+            (e = launch_cull_build(d_table, n_cells, K8, (uint32_t)Y, cell, shift_x, shift_y, d_cen,
+                                   reinterpret_cast<uint16_t*>(d_cull), nullptr)) != hipSuccess ||
+            (e = hipDeviceSynchronize()) != hipSuccess) {
+            dfree(d_cull); dfree(d_cen); dfree(d_table);
+            return fail(c, ROVER_E_HIP, "set_knn_map: cull table (%llu B): %s", (unsigned long long)cull_bytes, hipGetErrorString(e));
+        }
+    }
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
+    dfree(c->cull[which]); dfree(c->cull_cen[which]);
+    c->cull[which] = d_cull; c->cull_cen[which] = d_cen; c->cull_bytes[which] = cull_bytes;
     c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, 1.0f / cell};
-    c->table_bytes[which] = bytes;
+    c->table_bytes[which] = bytes + cull_bytes;
     c->have_map[which] = true;
     c->rays_valid = false;
     return alloc_bins(c);
@@ -413,6 +438,18 @@ static int check_ready(rover_ctx* c) {
     return check_precision(c);
 }
 
+static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
+    CullArgs a{};
+    a.rays = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
+    a.tab0 = c->map[0].table; a.tab1 = c->map[1].table;
+    a.cull0 = c->cull[0]; a.cull1 = c->cull[1]; a.cen0 = c->cull_cen[0]; a.cen1 = c->cull_cen[1];
+    a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
+    a.run = effective_run(c);
+    a.waves = c->cull_waves;
+    a.out = c->d_dist_out;
+    return a;
+}
+
 static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, hipStream_t s) {
     if (!in->pos || !in->quat || !in->joints || !in->target || !in->lin_hist || !in->ang_hist)
         return fail(c, ROVER_E_INVALID, "get_observations: null input pointer");
@@ -428,18 +465,20 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     const int variant = effective_variant(c);
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
-    if (variant == 2) p.bin_out = c->d_bins;
+    if (variant >= 2) p.bin_out = c->d_bins;
     p.precision = c->precision;
     p.cell_rcp = c->cell_rcp;
     HIP_TRY(c, launch_prep(p, s));
-    if (variant == 2)
+    if (variant >= 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
                                    c->d_block_sums, c->d_sorted, s));
     if (c->profiling) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
     }
-    if (variant == 2)
+    if (variant == 3)
+        HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
+    else if (variant == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
                                          (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
     else
@@ -451,7 +490,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
         ++c->prof_launches;
     }
     c->last_variant = variant;
-    c->sorted_valid = variant == 2;
+    c->sorted_valid = variant >= 2;
     c->rays_valid = true;
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
@@ -816,7 +855,7 @@ int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t
 int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
     if (!strcmp(name, "raycast_variant")) {
-        if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 or 2");
+        if (value < 0 || value > 3) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned) or 3 (culled)");
         c->variant = (int)value;
         return ROVER_OK;
     }
@@ -841,6 +880,11 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->cell_rcp = (int32_t)value;
         c->hf.rcp = c->cell_rcp;
         c->rays_valid = false;
+        return ROVER_OK;
+    }
+    if (!strcmp(name, "cull_waves")) {
+        if (value != 0 && (value < 6 || value > 8)) return fail(c, ROVER_E_INVALID, "cull_waves must be 0, 6, 7 or 8");
+        c->cull_waves = (uint32_t)value;
         return ROVER_OK;
     }
     if (!strcmp(name, "raycast_run")) {
@@ -893,10 +937,12 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (!c->rays_valid) return fail(c, ROVER_E_STATE, "replay_raycast: no ray records yet (run a step first)");
     USE_DEVICE(c);
     int v = effective_variant(c);
-    if (v == 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
+    if (v >= 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
-    if (v == 2)
+    if (v == 3)
+        HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
+    else if (v == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
                                          (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
     else

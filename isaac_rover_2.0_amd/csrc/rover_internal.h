@@ -52,6 +52,19 @@ struct PrepArgs {
     int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
 };
 
+// raycast_culled_kernel (rover_cull.hip)
+struct CullArgs {
+    const RayRec* rays;
+    const uint32_t* sorted;      // ray slots sorted by (map, cell)
+    uint32_t n_sorted;
+    const uint16_t *tab0, *tab1; // re-packed blocks [cell][9][K8] (exact arithmetic, phase 2)
+    const uint4 *cull0, *cull1;  // cull tables [cell][3][K8/4] x 16 B (phase 1)
+    const float4 *cen0, *cen1;   // per-cell reference point of the cull table's fp16 offsets
+    uint32_t kp0, kp1, run, n_blocks, nb8;
+    uint32_t waves;              // option cull_waves: 0 or 6..8 (register budget of the kernel build, A/B)
+    float* out;
+};
+
 struct ObsArgs {
     uint32_t E, W, R8;
     int64_t obs_stride;
@@ -128,6 +141,9 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
                                  const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, uint32_t early_out, float* out,
                                  hipStream_t s);
+hipError_t launch_cull_build(const uint16_t* table, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell, float shift_x,
+                             float shift_y, float4* cen, uint16_t* cull, hipStream_t s);
+hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);
 hipError_t launch_knn_bucket(const float* cx, const float* cy, uint32_t T, float ox, float oy, float inv_g, uint32_t nbx, uint32_t nby,

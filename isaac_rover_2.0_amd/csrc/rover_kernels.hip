@@ -28,15 +28,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rover_internal.h"
+#include "rover_raymath.h"
 
 namespace rover {
 
 // ---------------------------------------------------------------------------------------------------
 // shared device maths (same operation order as oracle/rover_oracle.c, which cites the reference lines)
 // ---------------------------------------------------------------------------------------------------
-#define RAY_NEG_EPS (-0.0999755859375f)   // fp16(-0.1), ray_casting.py:25
-#define RAY_ONE_EPS (1.099609375f)        // fp16(1.1),  ray_casting.py:26
-#define RAY_MISS    (11.0f)               // fp16(1.1)*10, ray_casting.py:27
 
 __device__ __forceinline__ void quat_to_euler(const float* __restrict__ q, float& roll, float& pitch, float& yaw) {
     const float half_pi = 3.1415927410125732f / 2.0f;
@@ -1021,120 +1019,6 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
 // division expansion without its range scaling (den and quotients here are far from the f32 range ends),
 // so results stay bit-identical to n = N/det, m = M/det, k = K/det.
 // ---------------------------------------------------------------------------------------------------
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));       // two triangles side by side -> v_pk_{mul,add,fma}_f32
-
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-struct Quot3 { f2 n, m, k; };
-
-// n = nn/det, m = mn/det, k = kn/det for two triangles at once.  Per element this is the instruction sequence of
-// the IEEE-754 f32 division expansion (rcp, two Newton steps on the reciprocal, quotient, two residual
-// corrections) minus its range scaling / fix-up, which only act when |det| or a quotient is near the ends of
-// the f32 range — and every such case fails the barycentric test below either way.
-__device__ __forceinline__ Quot3 div3_ieee(f2 det, f2 nn, f2 mn, f2 kn) {
-    f2 r = {__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
-    const f2 one = {1.0f, 1.0f};
-    f2 e = fma2(-det, r, one);
-    r = fma2(e, r, r);
-    Quot3 q;
-#define ROVER_Q(num, dst)                 \
-    {                                     \
-        f2 t = (num) * r;                 \
-        f2 rem = fma2(-det, t, (num));    \
-        t = fma2(rem, r, t);              \
-        rem = fma2(-det, t, (num));       \
-        dst = fma2(rem, r, t);            \
-    }
-    ROVER_Q(nn, q.n) ROVER_Q(mn, q.m) ROVER_Q(kn, q.k)
-#undef ROVER_Q
-    return q;
-}
-
-// ray_casting.py:59 with the :46,:51,:56 substitutions folded in: det == fp16(-0.1) forces n = 11 and det == fp16(1.1)
-// forces m = k = 11, either of which fails n + m <= 1.1.
-__device__ __forceinline__ float accept1(float n, float m, float k, float det, float n_plus_m) {
-    bool ok = (n >= RAY_NEG_EPS) && (m >= RAY_NEG_EPS) && (n_plus_m <= RAY_ONE_EPS)
-              && (det != RAY_NEG_EPS) && (det != RAY_ONE_EPS);
-    return ok ? k : RAY_MISS;
-}
-__device__ __forceinline__ float accept1(float n, float m, float k, float det) { return accept1(n, m, k, det, n + m); }
-
-// min over the 64 lanes with DPP row operations (no LDS crossbar): result valid in lane 63.
-// One asm block so the DPP read-after-VALU-write wait states (2, "s_nop 1") are under our control.
-__device__ __forceinline__ float wave_min_to_lane63(float v) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return v;
-}
-
-// per-lane triangle pairs of one cell: a = v2, b = v1 - a, c = v0 - a, n = b x c (ray_casting.py:34-36,40)
-template <int NP>
-struct CellRegs {
-    f2 ax[NP], ay[NP], az[NP], bx[NP], by[NP], bz[NP], cx[NP], cy[NP], cz[NP], nx[NP], ny[NP], nz[NP];
-    __device__ __forceinline__ void poison() {       // lanes past K: NaN vertex -> every test fails
-        const float qnan = __builtin_nanf("");
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            ax[p] = ay[p] = az[p] = f2{qnan, qnan};
-            bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = f2{0.0f, 0.0f};
-        }
-    }
-};
-
-// the ray-dependent part of ray_casting.py:37-59 for the lane's NP pairs; returns the lane's min distance
-//
-// Whole-pair early out (bit p of pre_bits): before the divisions, every lane tests its two triangles of pair p with
-//     A = nn det, B = mn det, D = det^2:   A < -0.11 D - tiny   or   B < -0.11 D - tiny   or   A + B > 1.11 D + tiny
-// Any of these proves (with a margin of 0.01 against f32 rounding errors of ~1e-7, and tiny = 1e-30 against the
-// absolute errors of the denormal range) that n < -0.1, m < -0.1 or n + m > 1.1 holds for the exactly rounded quotients
-// too, i.e. that ray_casting.py:59 rejects the triangle; NaN / det = 0 never pass the test.  When ALL valid triangles
-// of the pair are rejected in every lane the wave skips the pair's k numerator, the three divisions and the accept
-// logic — the result is unchanged bit for bit, since a rejected triangle only contributes the 11.0 sentinel.
-// vmask[p][e]: wave mask of the lanes whose element e of pair p is a real triangle (not NaN padding).
-template <int NP>
-__device__ __forceinline__ float cast_pairs(const CellRegs<NP>& t, f2 sx, f2 sy, f2 sz, f2 dx, f2 dy, f2 dz,
-                                            const uint64_t (&vmask)[NP][2], uint32_t pre_bits) {
-    float best = RAY_MISS;            // every cell holds >= 1 real triangle, so the min is <= 11 (ray_casting.py:27)
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        f2 gx = sx - t.ax[p], gy = sy - t.ay[p], gz = sz - t.az[p];                                          // :37
-        f2 det = t.nx[p] * dx + t.ny[p] * dy + t.nz[p] * dz;                                                 // :41
-        f2 gcx = gy * t.cz[p] - gz * t.cy[p], gcy = gz * t.cx[p] - gx * t.cz[p], gcz = gx * t.cy[p] - gy * t.cx[p];
-        f2 nn = gcx * dx + gcy * dy + gcz * dz;                                                              // :44-45
-        f2 bgx = t.by[p] * gz - t.bz[p] * gy, bgy = t.bz[p] * gx - t.bx[p] * gz, bgz = t.bx[p] * gy - t.by[p] * gx;
-        f2 mn = bgx * dx + bgy * dy + bgz * dz;                                                              // :49-50
-        if (pre_bits & (1u << p)) {                                                                          // wave-uniform
-            const f2 D = det * det, A = nn * det, B = mn * det, S = A + B;
-            const f2 lo = fma2(f2{-0.11f, -0.11f}, D, f2{-1e-30f, -1e-30f});
-            const f2 hi = fma2(f2{1.11f, 1.11f}, D, f2{1e-30f, 1e-30f});
-            // one ballot per compare so that each stays a v_cmp writing an SGPR pair; the masks combine on the scalar unit
-            const uint64_t r0 = __builtin_amdgcn_ballot_w64(__builtin_fminf(A.x, B.x) < lo.x) | __builtin_amdgcn_ballot_w64(S.x > hi.x);
-            const uint64_t r1 = __builtin_amdgcn_ballot_w64(__builtin_fminf(A.y, B.y) < lo.y) | __builtin_amdgcn_ballot_w64(S.y > hi.y);
-            if (((~r0 & vmask[p][0]) | (~r1 & vmask[p][1])) == 0) continue;
-        }
-        f2 kn = t.nx[p] * gx + t.ny[p] * gy + t.nz[p] * gz;                                                  // :54-55
-        Quot3 q = div3_ieee(det, nn, mn, kn);
-        float r0 = accept1(q.n.x, q.m.x, q.k.x, det.x);
-        float r1 = accept1(q.n.y, q.m.y, q.k.y, det.y);
-        best = __builtin_fminf(best, __builtin_fminf(r0, r1));       // no NaN can reach here (accept1 filters)
-    }
-    return best;
-}
-
 __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
                                                              uint32_t n_sorted, const _Float16* __restrict__ tab0,
                                                              const _Float16* __restrict__ tab1, uint32_t kp0, uint32_t kp1,
@@ -1171,18 +1055,10 @@ __global__ void __launch_bounds__(256) raycast_binned_kernel(const RayRec* __res
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int t0 = 2 * p, t1 = 2 * p + 1;
-                    t.ax[p] = f2{(float)v[6][t0], (float)v[6][t1]};
-                    t.ay[p] = f2{(float)v[7][t0], (float)v[7][t1]};
-                    t.az[p] = f2{(float)v[8][t0], (float)v[8][t1]};
-                    t.bx[p] = f2{(float)v[3][t0], (float)v[3][t1]} - t.ax[p];
-                    t.by[p] = f2{(float)v[4][t0], (float)v[4][t1]} - t.ay[p];
-                    t.bz[p] = f2{(float)v[5][t0], (float)v[5][t1]} - t.az[p];
-                    t.cx[p] = f2{(float)v[0][t0], (float)v[0][t1]} - t.ax[p];
-                    t.cy[p] = f2{(float)v[1][t0], (float)v[1][t1]} - t.ay[p];
-                    t.cz[p] = f2{(float)v[2][t0], (float)v[2][t1]} - t.az[p];
-                    t.nx[p] = t.by[p] * t.cz[p] - t.bz[p] * t.cy[p];
-                    t.ny[p] = t.bz[p] * t.cx[p] - t.bx[p] * t.cz[p];
-                    t.nz[p] = t.bx[p] * t.cy[p] - t.by[p] * t.cx[p];
+                    f2 w[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) w[q] = f2{(float)v[q][t0], (float)v[q][t1]};
+                    set_pair(t, p, w);
                 }
             }
 #pragma unroll

@@ -6,9 +6,10 @@ from isaac_rover_amd import _lib
 EXTRA_DT = {k: (torch.int64 if k == "collision_penalty" else torch.float32) for k in _lib.EXTRAS}
 
 
-def make_engine(scene, distribution, num_envs, variant=2, run=None, **kw):
-    """``variant`` defaults to the binned ray cast (the kernel full batches run): at test sizes the library's auto choice
-    would be the env-order kernel.  None = leave the auto choice."""
+def make_engine(scene, distribution, num_envs, variant=3, run=None, **kw):
+    """``variant`` defaults to the culled ray cast (the kernel full batches run; the library itself falls back to the binned
+    kernel 2 for the as-shipped fp16 maths): at test sizes the library's auto choice would be the env-order kernel.
+    None = leave the auto choice."""
     eng = _lib.Engine(num_envs, device=0, **kw)
     eng.set_scene(scene, distribution)
     if variant is not None:

@@ -31,11 +31,13 @@ def _run(scene, distn, st, num_envs=None, **kw):
 
 def test_full_size_invariants(full):
     scene, distn, st = full
-    a = _run(scene, distn, st, variant=2)
-    # (1) two independent ray-cast algorithms (binned / register-resident vs env-order streaming) agree bit for bit
-    b = _run(scene, distn, st, variant=1)
-    for k in a:
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    a = _run(scene, distn, st, variant=3)
+    # (1) three independent ray-cast algorithms (culled: conservative sphere / normal test + exact candidates; binned:
+    #     register-resident cells, every triangle evaluated; env-order streaming) agree bit for bit
+    for other in (2, 1):
+        b = _run(scene, distn, st, variant=other)
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} vs variant {other}")
     # (2) compaction = nonzero(reset_buf), ascending; the one-byte done flags that travel in the multi-GPU gather agree
     np.testing.assert_array_equal(a["reset_ids"], np.nonzero(a["reset_buf"])[0])
     np.testing.assert_array_equal(a["done_u8"], a["reset_buf"].astype(np.uint8))
@@ -119,7 +121,7 @@ def test_full_size_stone_mask_equals_clearance(full):
 
 def test_full_size_config4_dense_rays_and_goal_validation():
     """BASELINE configs[4]: 65 536 envs, 120-point dense heightmap, then the device-side reset + spawn-goal validation of the
-    envs the step flagged (rover_reset_envs over 1 024 stones, count read on the device).  Properties: the two ray-cast
+    envs the step flagged (rover_reset_envs over 1 024 stones, count read on the device).  Properties: the three ray-cast
     algorithms agree bit for bit on all 9.6 M rays; every re-drawn goal has clearance > 1.0 (rover.py:539) and sits at radius
     8 (:578) from its spawn; reset / progress are zeroed exactly for the compacted ids; a 256-entry list with caller-supplied
     draws equals the sequential oracle."""
@@ -130,16 +132,17 @@ def test_full_size_config4_dense_rays_and_goal_validation():
     distn = synth.ray_distribution("120")
     st = synth.make_states(E, CELLS * 0.1, seed=9)
     outs = {}
-    for variant in (2, 1):
+    for variant in (3, 2, 1):
         eng = make_engine(scene, distn, E, variant=variant)
         outs[variant] = hip_step(eng, st)
-        if variant == 1:
+        if variant != 3:
             eng.close()
         else:
             eng2 = eng
-    a = outs[2]
+    a = outs[3]
     for k in a:
         np.testing.assert_array_equal(a[k], outs[1][k], err_msg=k)
+        np.testing.assert_array_equal(a[k], outs[2][k], err_msg=k)
     assert a["obs_buf"].shape == (E, 124)
     np.testing.assert_array_equal(a["obs_buf"][:, 4:], a["ray_dist"] / 2.0)
     idx = np.random.default_rng(2).choice(E, 128, replace=False)

@@ -31,12 +31,12 @@ def test_step_matches_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("name,precision", [("step_lattice_fp32", "fp32"), ("step_lattice_fp16_as_shipped", "fp16_as_shipped")])
-@pytest.mark.parametrize("variant", [2, 1])
+@pytest.mark.parametrize("variant", [3, 2, 1])
 def test_exact_ties_follow_the_reference(name, precision, variant):
     """The lattice fixture (exact threshold / det-guard / degenerate-triangle hits, see tests/test_oracle_golden.py):
     on its rounding-free envs the HIP ray casts equal the reference bit for bit, in both kernels."""
     from hip_helpers import hip_step, make_engine
-    if precision == "fp16_as_shipped" and variant == 1:
+    if precision == "fp16_as_shipped" and variant != 2:
         pytest.skip("the as-shipped fp16 maths exist in the binned kernel only")
     fx = load_golden(name)
     scene = scene_for(fx)
@@ -75,20 +75,23 @@ def test_step_matches_oracle(dist_name, num_envs, seed):
 @pytest.mark.parametrize("dist_name,num_envs,k", [("37", 4096, 24), ("120", 512, 200), ("9", 300, 7), ("37", 700, 100),
                                                   ("9", 200, 16)])
 def test_raycast_variants_bit_identical(dist_name, num_envs, k):
-    """Variant 1 (half-wave per ray, env order) and variant 2 (rays binned by cell, shared-reciprocal IEEE division,
-    any run length, early out on or off) must agree bit for bit, and with the oracle's ray maths given the same rays."""
+    """Variant 1 (half-wave per ray, env order), variant 2 (rays binned by cell, shared-reciprocal IEEE division,
+    any run length, early out on or off) and variant 3 (culled: bounding-sphere / normal test first, exact arithmetic on the
+    candidates only) must agree bit for bit, and with the oracle's ray maths given the same rays."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=k, n_stones=24)
     distn = synth.ray_distribution(dist_name)
     st = synth.make_states(num_envs, 6.4, seed=21)
     ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
-    for run, early_out in ((1, 1), (5, 0), (16, 1), (16, 0), (64, 1)):
-        eng = make_engine(scene, distn, num_envs, variant=2, run=run)
+    for variant, run, early_out in ((2, 1, 1), (2, 5, 0), (2, 16, 1), (2, 16, 0), (2, 64, 1),
+                                    (3, 1, 1), (3, 5, 1), (3, 32, 1), (3, 64, 1), (3, 200, 1)):
+        eng = make_engine(scene, distn, num_envs, variant=variant, run=run)
         eng.set_option("raycast_early_out", early_out)       # conservative whole-pair rejection: same bits on or off
+        assert eng.info().raycast_variant == variant
         got = hip_step(eng, st)
         for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run} early_out={early_out}")
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} run={run} early_out={early_out}")
         eng.close()
 
 
@@ -181,7 +184,7 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
     r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices, shift=shift[0:2])
     want = orc.step(t, r, st, *distn)
     results = []
-    for variant in (2, 1):
+    for variant in (3, 2, 1):
         eng = _lib.Engine(num_envs, device=0)
         eng.set_scene(scene, distn)
         eng.set_option("raycast_variant", variant)
@@ -190,8 +193,9 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
         np.testing.assert_array_equal(got["reset_ids"], np.nonzero(got["reset_buf"])[0])
         results.append(got)
         eng.close()
-    for k in results[0]:
-        np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+    for other in results[1:]:
+        for k in results[0]:
+            np.testing.assert_array_equal(results[0][k], other[k], err_msg=k)
 
 
 @pytest.mark.parametrize("precision", [0, 2])
@@ -207,7 +211,7 @@ def test_early_out_changes_no_bit(precision, k):
     st["quat"] = synth.quat_from_euler(0.5 * torch.randn(3000), 0.5 * torch.randn(3000), 3.0 * torch.randn(3000))   # steep tilts
     outs = []
     for early_out in (1, 0):
-        eng = make_engine(scene, distn, 3000)
+        eng = make_engine(scene, distn, 3000, variant=2)
         eng.set_option("ray_precision", precision)
         eng.set_option("raycast_early_out", early_out)
         outs.append(hip_step(eng, st))
@@ -217,9 +221,44 @@ def test_early_out_changes_no_bit(precision, k):
     assert (outs[0]["ray_dist"] < 11.0).mean() > 0.5
 
 
+@pytest.mark.parametrize("k,cells", [(200, 96), (40, 96), (255, 48)])
+def test_culled_raycast_changes_no_bit(k, cells):
+    """The culled kernel (variant 3) against the binned kernel with its early out off, on a batch with steep tilts, rays
+    parallel to facets (exact axis-aligned poses on the vertex lattice) and huge / NaN poses: every output identical, for
+    every register-budget build of the kernel."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 3000
+    scene = synth.make_scene(n_cells=cells, k=k, n_stones=40)
+    distn = synth.ray_distribution("120")
+    st = synth.make_states(n, cells * 0.1, seed=78)
+    g = torch.Generator().manual_seed(5)
+    st["quat"] = synth.quat_from_euler(0.5 * torch.randn(n, generator=g), 0.5 * torch.randn(n, generator=g), 3.0 * torch.randn(n, generator=g))
+    q = torch.randn(1000, 4, generator=g)
+    st["quat"][1000:2000] = q / q.norm(dim=1, keepdim=True)                      # arbitrary orientations
+    axis = torch.tensor([[1.0, 0, 0, 0], [0.70710678, 0.70710678, 0, 0], [0.70710678, 0, 0.70710678, 0], [0, 1.0, 0, 0]])
+    st["quat"][2000:2900] = axis[torch.randint(0, 4, (900,), generator=g)]       # rays in facet planes, through vertices
+    st["pos"][2000:2900, 0:2] = torch.round(st["pos"][2000:2900, 0:2] * 20) / 20
+    st["pos"][2900:2950] *= 1.0e4                                                 # far outside the map
+    st["pos"][2950:2960] = float("nan")
+    st["pos"][2960:2970, 2] += 500.0                                              # high above the terrain
+    eng = make_engine(scene, distn, n, variant=2)
+    eng.set_option("raycast_early_out", 0)
+    ref = hip_step(eng, st)
+    eng.close()
+    for waves in (0, 6, 7, 8):
+        eng = make_engine(scene, distn, n, variant=3)
+        eng.set_option("cull_waves", waves)
+        got = hip_step(eng, st)
+        eng.close()
+        for key in ref:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} waves={waves}")
+    assert (ref["ray_dist"] < 11.0).mean() > 0.3
+
+
 def test_auto_variant_and_run_selection():
-    """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the binned kernel above and whenever the
-    as-shipped fp16 maths are asked for; K8 > 256 always falls back to the env-order kernel."""
+    """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the culled kernel above (the binned one
+    whenever the as-shipped fp16 maths are asked for); K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=16, n_stones=8)
@@ -229,7 +268,10 @@ def test_auto_variant_and_run_selection():
     small.set_option("ray_precision", 2)
     assert small.info().raycast_variant == 2
     big = make_engine(scene, distn, 4096, variant=None)
+    assert big.info().raycast_variant == 3
+    big.set_option("ray_precision", 2)
     assert big.info().raycast_variant == 2
+    big.set_option("ray_precision", 0)
     st = synth.make_states(4096, 6.4, seed=3)
     a = hip_step(big, st)                                   # auto run length
     big.set_option("raycast_run", 16)
@@ -419,7 +461,7 @@ def test_cell_index_mode_cuda_rcp_matches_oracle_and_differs_on_ties():
     n = st["pos"].shape[0]
     got, want = {}, {}
     for mode, name in ((0, "cpu_div"), (1, "cuda_rcp")):
-        for variant in (2, 1):
+        for variant in (3, 2, 1):
             eng = make_engine(scene, distn, n, variant=variant)
             eng.set_option("cell_index_mode", mode)
             got[(mode, variant)] = hip_step(eng, st)
@@ -429,7 +471,7 @@ def test_cell_index_mode_cuda_rcp_matches_oracle_and_differs_on_ties():
             want[mode] = orc.step(t, r, st, *distn)
         finally:
             orc.set_cell_index_mode("cpu_div")
-        for variant in (2, 1):
+        for variant in (3, 2, 1):
             g = got[(mode, variant)]
             # tie envs: identity orientation -> no trig ulps between OCML and glibc -> the terrain ray must agree bit for bit
             np.testing.assert_array_equal(g["ray_dist"][tie_envs], want[mode]["ray_dist"][tie_envs], err_msg=f"{name} v{variant}")

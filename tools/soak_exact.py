@@ -1,5 +1,5 @@
-"""Bit-exactness soak (run on the GPU box): the binned ray cast with the conservative early out against the env-order
-kernel (no early out, different traversal) and against itself with the option off, over many seeds, arbitrary rover
+"""Bit-exactness soak (run on the GPU box): the culled ray cast (variant 3) and the binned ray cast with the conservative
+early out against the env-order kernel (no early out, different traversal) and against the binned kernel with the option off, over many seeds, arbitrary rover
 orientations (rays parallel to facets included), several K and both precisions.  Prints the number of compared rays.
 
     python tools/soak_exact.py [rounds]
@@ -16,7 +16,7 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
     scene = synth.make_scene(n_cells=cells, k=k, n_stones=max(8, cells * cells // 400), device="cuda")
     distn = synth.ray_distribution(dist_name)
     engs = {}
-    for name, (variant, early, prec) in {"binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
+    for name, (variant, early, prec) in {"culled": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
                                          "h": (2, 1, 2), "h_noearly": (2, 0, 2)}.items():
         e = _lib.Engine(E, device=0)
         e.set_scene(scene, distn)
@@ -42,7 +42,7 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
             e.step(sin, e.make_out(obs, **bufs), increment_progress=False)
             torch.cuda.synchronize()
             outs[name] = (bufs["ray_dist"], bufs["wheel_dist"], bufs["body_dist"], bufs["rock_collision"], bufs["reset"])
-        for a, b in (("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly")):
+        for a, b in (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly")):
             for x, y, what in zip(outs[a], outs[b], ("ray", "wheel", "body", "coll", "reset")):
                 same = torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all())
                 if not same:
@@ -53,4 +53,4 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
         print(f"K={k} round {r}: ok, terrain hit rate {hit:.3f}", flush=True)
     for e in engs.values():
         e.close()
-print(f"soak ok: {total / 1e6:.1f} M rays x 3 comparisons, all bit-identical")
+print(f"soak ok: {total / 1e6:.1f} M rays x 5 comparisons, all bit-identical")
