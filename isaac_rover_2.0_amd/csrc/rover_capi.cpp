@@ -154,7 +154,9 @@ static int effective_variant(const rover_ctx* c) {
 static uint32_t effective_run(const rover_ctx* c) {
     if (c->run) return c->run;
     const uint64_t r = valid_rays(c) / 65536u;
-    return (uint32_t)(r < 4 ? 4 : (r > 32 ? 32 : r));
+    // the culled kernel's set-up is lighter and its phase-2 batches fill better on long runs (65 536 envs: 32 -> 0.912 ms, 64 -> 0.882)
+    const uint64_t hi = effective_variant(c) == 3 ? 64 : 32;
+    return (uint32_t)(r < 4 ? 4 : (r > hi ? hi : r));
 }
 
 static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
