@@ -253,16 +253,25 @@ def roofline(args, E, n_rays, prof, info):
     hbm = None
     if traffic and t > 0:
         hbm = {"traffic": traffic, "GBps": traffic / t / 1e9, "frac_of_8TBps": traffic / t / 1e9 / HBM_PEAK_GBS}
-    return {"bound": "valu", "kernel": {3: "raycast_culled_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
-            "achieved": achieved, "peak": peak, "unit": "G VALU-issue cycles/s (1024 SIMDs x 2.4 GHz)", "frac": frac,
-            "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches),
-            "valu_insts_per_ray": insts_per_ray, "rays_per_launch": rays, "hbm": hbm,
-            "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
-            "reuse_factor": (algo / traffic) if traffic else None,
-            "note": "frac = SQ_INSTS_VALU per launch (profiles/valu.json) x 4 cycles / (1024 SIMDs x 2.4 GHz x live HIP-event "
-                    "time): the binned kernel serves most (ray, triangle) pairs from registers, so it is bound by f32 VALU issue, "
-                    "not by HBM; hbm.* = PMC-measured bytes per launch (profiles/traffic.json) at the live time; "
-                    "algorithmic_equiv_GBps = SURVEY 8(d)'s no-reuse byte model, kept for reference"}
+    valu_obj = {"achieved": achieved, "peak": peak, "unit": "G VALU-issue cycles/s (1024 SIMDs x 2.4 GHz)", "frac": frac,
+                "valu_insts_per_ray": insts_per_ray}
+    # The bound is whichever resource the kernel uses the larger fraction of (both from profiles/ counters at the live time):
+    # the binned kernel (variant 2) is VALU-issue bound, the culled kernel (variant 3) moves its cull table at HBM rate.
+    hbm_bound = hbm is not None and (frac is None or hbm["frac_of_8TBps"] >= frac)
+    if hbm_bound:
+        head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
+    else:
+        head = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": valu_obj["unit"], "frac": frac}
+    head.update({"kernel": {3: "raycast_culled_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
+                 "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "rays_per_launch": rays,
+                 "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
+                 "reuse_factor": (algo / traffic) if traffic else None,
+                 "note": "achieved (bound = hbm) = PMC-measured HBM bytes per launch (profiles/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, "
+                         "gfx950 correction) / live HIP-event time per launch; valu.frac = SQ_INSTS_VALU per launch (profiles/valu.json) "
+                         "x 4 cycles / (1024 SIMDs x 2.4 GHz x the same time); algorithmic_equiv_GBps = SURVEY 8(d)'s no-reuse byte "
+                         "model (18 B per (ray, triangle) pair), which the kernel beats by not touching provably rejected triangles: "
+                         "reuse_factor = model bytes / measured bytes; formulas in profiles/README.md"})
+    return head
 
 
 def _checksums(torch, obs, rew, done):

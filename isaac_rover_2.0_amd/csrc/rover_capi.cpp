@@ -21,9 +21,11 @@ struct rover_ctx {
     KnnDev map[2]{};
     uint64_t table_bytes[2]{0, 0};
     bool have_map[2]{false, false};
-    // cull tables of the culled ray cast (variant 3): per triangle a bounding-sphere centre + scaled unit normal, 12 B
-    uint4* cull[2]{nullptr, nullptr};
-    float4* cull_cen[2]{nullptr, nullptr};
+    // tables of the culled ray cast (variant 3): the cell's triangle ids, and per triangle a bounding-sphere centre + scaled
+    // unit normal (16 B) and the nine fp16 vertex components (20 B)
+    int32_t* cull_idx[2]{nullptr, nullptr};
+    uint4* cull_ctab[2]{nullptr, nullptr};
+    uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
     // distribution
     double* d_dist = nullptr;       // [P][3]
@@ -143,7 +145,7 @@ static int effective_variant(const rover_ctx* c) {
     if (c->variant == 1 || !v2_ok) return 1;
     if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
     // variant 3 (culled): f32 arithmetic only — the as-shipped fp16 mode keeps the binned kernel
-    const bool v3_ok = c->cull[0] && c->cull[1] && c->precision != 2;
+    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1] && c->precision != 2;
     if (c->variant == 2 || !v3_ok) return 2;
     return 3;
 }
@@ -237,7 +239,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull[w]); dfree(c->cull_cen[w]); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -282,26 +284,28 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         cleanup(); dfree(d_table);
         return fail(c, ROVER_E_HIP, "set_knn_map: %s", hipGetErrorString(e));
     }
-    cleanup();
-    // cull table of the culled ray cast (64 lanes x 4 triangles, cell id + map bit in 32 bits)
-    uint4* d_cull = nullptr;
-    float4* d_cen = nullptr;
+    // tables of the culled ray cast (64 lanes x 4 triangles; triangle ids and the map bit share 32 bits of a queue entry)
+    int32_t* d_cidx = nullptr;
+    uint4* d_ctab = nullptr;
+    uint16_t* d_rtab = nullptr;
     uint64_t cull_bytes = 0;
-    if (K8 <= 256 && n_cells < 0x80000000ull) {
-        cull_bytes = n_cells * (3ull * (K8 / 4) * sizeof(uint4) + sizeof(float4));
-        if ((e = hipMalloc((void**)&d_cull, n_cells * 3ull * (K8 / 4) * sizeof(uint4))) != hipSuccess ||
-            (e = hipMalloc((void**)&d_cen, n_cells * sizeof(float4))) != hipSuccess ||
-            (e = launch_cull_build(d_table, n_cells, K8, (uint32_t)Y, cell, shift_x, shift_y, d_cen,
-                                   reinterpret_cast<uint16_t*>(d_cull), nullptr)) != hipSuccess ||
+    if (K8 <= 256 && (uint32_t)T < 0x3ffffffu) {
+        const uint64_t b_idx = n_cells * K8 * sizeof(int32_t), b_ct = (uint64_t)T * sizeof(uint4), b_rt = (uint64_t)T * 20u;
+        cull_bytes = b_idx + b_ct + b_rt;
+        if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
+            (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess ||
+            (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, (uint32_t)V, d_cidx, d_ctab, d_rtab,
+                                   nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess) {
-            dfree(d_cull); dfree(d_cen); dfree(d_table);
-            return fail(c, ROVER_E_HIP, "set_knn_map: cull table (%llu B): %s", (unsigned long long)cull_bytes, hipGetErrorString(e));
+            cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_table);
+            return fail(c, ROVER_E_HIP, "set_knn_map: cull tables (%llu B): %s", (unsigned long long)cull_bytes, hipGetErrorString(e));
         }
     }
+    cleanup();
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
-    dfree(c->cull[which]); dfree(c->cull_cen[which]);
-    c->cull[which] = d_cull; c->cull_cen[which] = d_cen; c->cull_bytes[which] = cull_bytes;
+    dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]);
+    c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_bytes[which] = cull_bytes;
     c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, 1.0f / cell};
     c->table_bytes[which] = bytes + cull_bytes;
     c->have_map[which] = true;
@@ -443,8 +447,8 @@ static int check_ready(rover_ctx* c) {
 static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     CullArgs a{};
     a.rays = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
-    a.tab0 = c->map[0].table; a.tab1 = c->map[1].table;
-    a.cull0 = c->cull[0]; a.cull1 = c->cull[1]; a.cen0 = c->cull_cen[0]; a.cen1 = c->cull_cen[1];
+    a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1]; a.ctab0 = c->cull_ctab[0]; a.ctab1 = c->cull_ctab[1];
+    a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1];
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.waves = c->cull_waves;

@@ -28,6 +28,7 @@
 // NaN / inf anywhere makes (A) or (B) compare false, i.e. keeps the triangle a candidate.  DESIGN.md §4.3 has the long form.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rover_internal.h"
 #include "rover_raymath.h"
 
@@ -38,6 +39,7 @@ namespace rover {
 #define CULL_PAD    0.101            // barycentric padding of the proof (the reference's is fp16(0.1) = 0.09998)
 #define CULL_QCAP   320              // queue entries per wave: < 64 left after a flush + at most 128 new ones per ray, with slack
 #define CULL_RUNMAX 64               // sorted rays per wave (one result slot per lane)
+#define CULL_RING   4                // id rows (one bin each) in flight per wave: global -> LDS loads issued this many bins ahead
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
@@ -55,42 +57,46 @@ __device__ __forceinline__ float cull_r2(float nx, float ny, float nz) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// init: per-cell reference point (cell centre in xy, mean triangle height in z) — the fp16 offsets of the cull table
-// are relative to it
+// init (rover_set_knn_map): three tables per map, all indexed through the reference's own map_indices
+//   rtab [T]        20 B: the triangle's nine fp16 vertex components (v0 xyz, v1 xyz, v2 xyz, pad) — the exact arithmetic's
+//                         input, what camera.py:84 gathers through triangles -> vertices
+//   ctab [T]        16 B: {centre x, centre y (f32), half2(centre z, nx), half2(ny, nz)} — bounding-sphere centre of the padded
+//                         triangle and its unit normal scaled to length r / tau (r2 = tau^2 |n|^2 is the sphere test's radius)
+//   idx4 [cell][L][4] i32: the cell's K triangle ids (-1 = empty slot), L = K8 / 4 lanes x 4; ids sorted ascending and dealt
+//                         in quarters (slot j of lane l = sorted[j L + l]) so that one gather instruction of a wave touches
+//                         neighbouring ctab records (few L2 lines)
+// The per-triangle tables are small (26 B x T: 18 MB for 720 k triangles) and stay in L2 / MALL; HBM only streams idx4.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) cull_centre_kernel(const uint16_t* __restrict__ table, uint32_t n_cells, uint32_t K8,
-                                                          uint32_t Y, float cell, float shift_x, float shift_y,
-                                                          float4* __restrict__ cen) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells) return;
-    const _Float16* az = reinterpret_cast<const _Float16*>(table) + (size_t)c * 9u * K8 + 8u * (size_t)K8;
-    float sum = 0.0f; uint32_t n = 0;
-    for (uint32_t k = 0; k < K8; ++k) {
-        const float z = (float)az[k];
-        if (z == z && fabsf(z) < 6.0e4f) { sum += z; ++n; }
+__global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restrict__ tris, const uint16_t* __restrict__ verts,
+                                                         uint32_t T, uint32_t V, uint16_t* __restrict__ rtab) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint16_t v[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) v[q] = 0x7e00u;                        // fp16 NaN: every test fails
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t vi = (uint32_t)tris[3ull * t + a];
+        if (vi < V) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[3 * a + c] = verts[3ull * vi + c];
+        }
     }
-    const uint32_t ix = c / Y, iy = c % Y;
-    cen[c] = make_float4(shift_x + (float)ix * cell, shift_y + (float)iy * cell, n ? sum / (float)n : 0.0f, 0.0f);
+    v[9] = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) rtab[10ull * t + q] = v[q];
 }
 
-__device__ __forceinline__ uint16_t half_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
-
-// init: one thread per (cell, slot) of the re-packed table -> the slot's 6 halves of the cull table
-//   cull[cell][chunk 0..2][lane] = 16 B;  lane's 12 dwords D[p][q], p = pair, q = (ox, oy, oz, nx, ny, nz),
-//   dword = half2{triangle 2p, triangle 2p+1} of the lane (slot 4 lane + 2p + e of the re-packed block)
-__global__ void __launch_bounds__(256) cull_build_kernel(const uint16_t* __restrict__ table, uint64_t n_cells, uint32_t K8,
-                                                         const float4* __restrict__ cen, uint16_t* __restrict__ cull) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cells * K8) return;
-    const uint64_t cell = i / K8;
-    const uint32_t slot = (uint32_t)(i % K8), lane = slot >> 2, j = slot & 3u, p = j >> 1, e = j & 1u, L = K8 >> 2;
-    const _Float16* src = reinterpret_cast<const _Float16*>(table) + cell * 9ull * K8 + slot;
+__global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, uint4* __restrict__ ctab) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const _Float16* src = reinterpret_cast<const _Float16*>(rtab) + 10ull * t;
     float v[9];
     bool valid = true;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) { v[q] = (float)src[(size_t)q * K8]; valid = valid && (v[q] == v[q]) && fabsf(v[q]) < 6.0e4f; }
-    const float4 cc = cen[cell];
-    uint16_t out[6] = {0x7e00u, 0, 0, 0, 0, 0};                    // invalid slot: NaN offset (phase 1 masks it out)
+    for (int q = 0; q < 9; ++q) { v[q] = (float)src[q]; valid = valid && (v[q] == v[q]) && fabsf(v[q]) < 6.0e4f; }
+    float mk[3] = {0.0f, 0.0f, 0.0f};                                // the centre as phase 1 decodes it
+    uint16_t zh = 0, nh[3] = {0, 0, 0};                              // zero normal: guard (B) never holds = always a candidate
     if (valid) {
         // a, b, c exactly as ray_casting.py:34-36 / set_pair compute them (f32), widened
         const float af[3] = {v[6], v[7], v[8]};
@@ -120,18 +126,13 @@ __global__ void __launch_bounds__(256) cull_build_kernel(const uint16_t* __restr
             const double ws = w0 + w1 + w2;
             w0 /= ws; w1 /= ws; w2 /= ws;
         }
-        const float ccf[3] = {cc.x, cc.y, cc.z};
-        float mk[3];                                                 // the centre as phase 1 decodes it
-        bool ok = true;
+        double m[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double m = w0 * Q[0][k] + w1 * Q[1][k] + w2 * Q[2][k];
-            float off = (float)(m - (double)ccf[k]);
-            if (!(fabsf(off) < 6.0e4f)) { off = 0.0f; ok = false; }
-            const _Float16 oh = (_Float16)off;
-            out[k] = __builtin_bit_cast(uint16_t, oh);
-            mk[k] = ccf[k] + (float)oh;                              // = CullRegs::m in raycast_culled_kernel
-        }
+        for (int k = 0; k < 3; ++k) m[k] = w0 * Q[0][k] + w1 * Q[1][k] + w2 * Q[2][k];
+        mk[0] = (float)m[0]; mk[1] = (float)m[1];
+        const _Float16 zq = (_Float16)(float)m[2];                   // |z| < 6e4 (the vertices are fp16 values)
+        zh = __builtin_bit_cast(uint16_t, zq);
+        mk[2] = (float)zq;
         double rho2 = 0.0;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) cull_build_kernel(const uint16_t* __restr
         const double nN = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
         const double nb = sqrt((double)bf[0] * bf[0] + (double)bf[1] * bf[1] + (double)bf[2] * bf[2]);
         const double nc = sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]);
-        ok = ok && nN > 0.0 && nN >= 0.05 * nb * nc;                 // slivers stay candidates
+        bool ok = nN > 0.0 && nN >= 0.05 * nb * nc;                  // slivers stay candidates
         if (ok) {
             double scale = sqrt(need) * 1.002 / CULL_TAU / nN;       // |stored normal| = r / tau
             bool done = false;
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) cull_build_kernel(const uint16_t* __restr
                     const float f = (float)(N[k] * scale);
                     fin = fin && fabsf(f) < 6.0e4f;
                     const _Float16 hn = (_Float16)f;
-                    out[3 + k] = __builtin_bit_cast(uint16_t, hn);
+                    nh[k] = __builtin_bit_cast(uint16_t, hn);
                     dec[k] = (float)hn;
                 }
                 if (!fin) break;
@@ -165,13 +166,35 @@ __global__ void __launch_bounds__(256) cull_build_kernel(const uint16_t* __restr
             }
             ok = done;
         }
-        if (!ok) out[3] = out[4] = out[5] = 0;                       // zero normal: guard (B) never holds
+        if (!ok) nh[0] = nh[1] = nh[2] = 0;
     }
-    uint16_t* dst = cull + (cell * 3ull * L + lane) * 8ull;          // halves; chunk c of the lane at + c * L * 8
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const uint32_t h = (p * 6u + (uint32_t)q) * 2u + e;          // index among the lane's 24 halves
-        dst[(uint64_t)(h >> 3) * L * 8ull + (h & 7u)] = out[q];
+    ctab[t] = make_uint4(__float_as_uint(mk[0]), __float_as_uint(mk[1]), (uint32_t)zh | ((uint32_t)nh[0] << 16),
+                         (uint32_t)nh[1] | ((uint32_t)nh[2] << 16));
+}
+
+// one workgroup per cell: the cell's K ids sorted ascending (empty / out-of-range ids last), dealt to the lanes in quarters
+__global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restrict__ map_idx, uint32_t K, uint32_t K8, uint32_t T,
+                                                         int32_t* __restrict__ idx4) {
+    __shared__ uint32_t key[256];
+    const uint32_t cell = blockIdx.x, tid = threadIdx.x, L = K8 >> 2;
+    uint32_t k = 0xffffffffu;
+    if (tid < K) { const uint32_t t = (uint32_t)map_idx[(uint64_t)cell * K + tid]; if (t < T) k = t; }
+    key[tid] = k;
+    __syncthreads();
+    for (uint32_t len = 2; len <= 256u; len <<= 1) {
+        for (uint32_t stride = len >> 1; stride > 0; stride >>= 1) {
+            if (tid < 128u) {
+                const uint32_t lo = ((tid / stride) * stride << 1) + (tid % stride), hi = lo + stride;
+                const bool up = (lo & len) == 0;
+                const uint32_t a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < K8) {
+        const uint32_t lane = tid % L, j = tid / L;                   // sorted position tid -> slot j of lane `lane`
+        idx4[((uint64_t)cell * L + lane) * 4u + j] = (int32_t)key[tid];     // 0xffffffff -> -1
     }
 }
 
@@ -195,105 +218,164 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// PHASE 2: n <= 64 queue entries, one per lane: the exact arithmetic on the entry's pair of triangles, min into the ray's slot
-__device__ __forceinline__ void cull_flush(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
-                                           const _Float16* __restrict__ tab0, const _Float16* __restrict__ tab1, uint32_t kp0,
-                                           uint32_t kp1, const uint2* qe, uint32_t n, uint32_t lane, uint32_t i0, uint32_t* bk) {
-    if (lane < n) {
-        const uint2 en = qe[lane];
-        const uint32_t cell = en.x & 0x7fffffffu, map = en.x >> 31;
-        const uint32_t pos = en.y >> 8, el = (en.y >> 1) & 63u, p = en.y & 1u;
-        const uint32_t kp = map ? kp1 : kp0;
-        const _Float16* base = (map ? tab1 : tab0) + (size_t)cell * 9u * kp + el * 4u + p * 2u;        // el * 4 < kp
-        f2 v[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) v[q] = cvt2(*reinterpret_cast<const uint32_t*>(base + (size_t)q * kp));
-        CellRegs<1> t;
-        set_pair(t, 0, v);
-        const uint32_t gid = sorted[i0 + pos];
-        const float4* rp = reinterpret_cast<const float4*>(rays + gid);
-        const float4 ra = rp[0], rb = rp[1];
-        const uint64_t none[1][2] = {{0, 0}};
-        const float best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
-                                         f2{rb.z, rb.z}, none, 0u);
-        atomicMin(bk + pos, fkey(best));
-    }
+#define CULL_NOID 0x3ffffffu          // "no triangle" in a queue entry (ids are < 2^26 - 1)
+
+struct RawTri { uint32_t d[5]; };    // rtab record: v0 xyz, v1 xyz, v2 xyz, pad as ten fp16 values (4-byte aligned)
+
+// one f32 of another lane (the LDS crossbar, no memory access)
+__device__ __forceinline__ float lane_gather(float v, uint32_t src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
 }
+__device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-uniform */) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)src_lane));
+}
+
+// PHASE 2: n <= 64 queue entries, one per lane: the exact arithmetic on the entry's pair of triangles, min into the ray's slot.
+// ra / rb: the run's ray records, one per lane (lane = position in the run).
+__device__ __forceinline__ void cull_flush(const float4& ra, const float4& rb, const RawTri* __restrict__ rtab0,
+                                           const RawTri* __restrict__ rtab1, const uint2* qe, uint32_t n, uint32_t lane, uint32_t* bk) {
+    // every lane takes part in the cross-lane gathers; lanes past n compute on entry 0's data and drop the result
+    const uint2 en = qe[lane < n ? lane : 0u];
+    const uint32_t map = en.x >> 31, pos = en.y >> 26;
+    const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
+    const RawTri* rt = map ? rtab1 : rtab0;
+    const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
+    const float sx = lane_gather(ra.x, pos), sy = lane_gather(ra.y, pos), sz = lane_gather(ra.z, pos);
+    const float dx = lane_gather(rb.x, pos), dy = lane_gather(rb.y, pos), dz = lane_gather(rb.z, pos);
+    const float qnan = __builtin_nanf("");
+    f2 v[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
+        v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
+    }
+    // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
+    v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
+    CellRegs<1> t;
+    set_pair(t, 0, v);
+    const uint64_t none[1][2] = {{0, 0}};
+    const float best = cast_pairs<1>(t, f2{sx, sx}, f2{sy, sy}, f2{sz, sz}, f2{dx, dx}, f2{dy, dy}, f2{dz, dz}, none, 0u);
+    if (lane < n) atomicMin(bk + pos, fkey(best));
+}
+
+#define CULL_KERNEL_ARGS                                                                                                        \
+    const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
+        const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, uint32_t kp0, uint32_t kp1, uint32_t run,           \
+        uint32_t n_blocks, uint32_t nb8, float *__restrict__ out, uint32_t dbg
+#define CULL_KERNEL_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, rtab0, rtab1, kp0, kp1, run, n_blocks, nb8, out, dbg
 
 // WPE: waves per SIMD the register allocation aims at (0 = the compiler's own choice) — option "cull_waves", A/B only
 template <int WPE>
-__device__ __forceinline__ void raycast_culled_body(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
-                                                             uint32_t n_sorted, const _Float16* __restrict__ tab0,
-                                                             const _Float16* __restrict__ tab1, const uint4* __restrict__ cull0,
-                                                             const uint4* __restrict__ cull1, const float4* __restrict__ cen0,
-                                                             const float4* __restrict__ cen1, uint32_t kp0, uint32_t kp1,
-                                                             uint32_t run, uint32_t n_blocks, uint32_t nb8, float* __restrict__ out) {
+__device__ __forceinline__ void raycast_culled_body(CULL_KERNEL_ARGS) {
     __shared__ uint2 s_queue[4][CULL_QCAP];
     __shared__ uint32_t s_best[4][CULL_RUNMAX];
-    // XCD-aware order, as raycast_binned_kernel: each XCD walks one contiguous eighth of the sorted rays
+    // XCD-aware order, as raycast_binned_kernel: each XCD walks one contiguous eighth of the sorted rays — here that also
+    // keeps the ctab / rtab records an XCD touches (a band of the map) inside its own L2
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
     if (lb >= n_blocks) return;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
     const uint32_t i0 = wave * run;
     if (i0 >= n_sorted) return;
-    const uint32_t i_end = min(i0 + run, n_sorted);
+    const uint32_t n_run = min(run, n_sorted - i0);                  // <= 64
     uint2* q = s_queue[w];
     uint32_t* bk = s_best[w];
     bk[lane] = fkey(RAY_MISS);                 // a culled triangle contributes the 11.0 sentinel (ray_casting.py:27,59)
+    // The run's ray records, one per lane, in ONE round of loads (a per-ray scalar-load chain would cost a memory latency
+    // per ray, more than the ~75 instructions a ray takes); each ray's parameters then reach the SGPRs by v_readlane.
+    const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
+    const float4* rp = reinterpret_cast<const float4*>(rays + gid);
+    const float4 ra = rp[0], rb = rp[1];
+    const uint32_t key = __float_as_uint(ra.w) | (__float_as_uint(rb.w) << 31);        // cell | map << 31
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
+    // bit i: ray i starts a new (map, cell) bin
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(lane < n_run && (lane == 0u || key != prev));
+    // The id rows of the run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
+    // memory latency per run instead of one per bin; with 4-5 waves per SIMD nothing else hides it).
+    __shared__ int4 s_ids[4][CULL_RING][64];
+    uint64_t pf_heads = heads;                 // bins whose row is not requested yet
+    uint32_t pf_n = 0, use_n = 0;              // rows requested / consumed so far (slot = count % CULL_RING)
+    auto prefetch_row = [&]() {
+        const uint32_t j = (uint32_t)__builtin_ctzll(pf_heads);
+        pf_heads &= pf_heads - 1ull;
+        const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j);
+        const uint32_t c2 = k2 & 0x7fffffffu, m2 = k2 >> 31, L2 = (m2 ? kp1 : kp0) >> 2;
+        const int4* src = (m2 ? idx1 : idx0) + (size_t)c2 * L2 + (lane < L2 ? lane : L2 - 1u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
+        ++pf_n;
+    };
+#pragma unroll 1
+    for (int d = 0; d < CULL_RING; ++d)
+        if (pf_heads) prefetch_row();
     uint32_t qn = 0;
-    uint32_t cur_cell = 0xffffffffu, cur_map = 0xffffffffu, el = lane;
+    uint32_t qid[2][2] = {{CULL_NOID, CULL_NOID}, {CULL_NOID, CULL_NOID}};     // the lane's ids as queue-entry fields
     CullRegs t;
 #pragma unroll
     for (int p = 0; p < 2; ++p) t.mx[p] = t.my[p] = t.mz[p] = t.nx[p] = t.ny[p] = t.nz[p] = t.r2[p] = f2{0.0f, 0.0f};
-    for (uint32_t i = i0; i < i_end; ++i) {
-        const uint32_t gid = __builtin_amdgcn_readfirstlane(sorted[i]);
-        const float4* rp = reinterpret_cast<const float4*>(rays + gid);
-        const float4 ra = rp[0], rb = rp[1];
-        const uint32_t cell = __builtin_amdgcn_readfirstlane(__float_as_uint(ra.w));
-        const uint32_t map = __builtin_amdgcn_readfirstlane(__float_as_uint(rb.w)) & 1u;
-        bool change = cell != cur_cell || map != cur_map;
+    for (uint32_t i = 0; i < n_run; ++i) {
+        const bool head = (heads >> i) & 1ull;
+        bool change = head;
         // Flush full batches of 64 only where the cell registers are dead (before a set-up); mid-cell only when the queue
         // could overflow, and then the cell is set up again.
         if (qn > CULL_QCAP - 128u || (change && qn >= 64u)) {
             wave_lds_sync();
             do {
                 qn -= 64u;
-                cull_flush(rays, sorted, tab0, tab1, kp0, kp1, q + qn, 64u, lane, i0, bk);
+                if (!(dbg & 1u)) cull_flush(ra, rb, rtab0, rtab1, q + qn, 64u, lane, bk);
             } while (qn >= 64u);
             wave_lds_sync();
             change = true;
         }
         if (change) {
-            cur_cell = cell; cur_map = map;
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);
+            const uint32_t cell = k & 0x7fffffffu, map = k >> 31;
             const uint32_t L = (map ? kp1 : kp0) >> 2;
-            const float4 cc = (map ? cen1 : cen0)[cell];
             // lanes past K (K8 < 256) repeat the last lane's triangles: no divergent set-up (a divergent one keeps the old
             // cell's registers alive across the flush above), and a duplicate candidate cannot change a min
-            el = lane < L ? lane : L - 1u;
-            const uint4* cb = (map ? cull1 : cull0) + (size_t)cell * 3u * L + el;
-            const uint4 c0 = cb[0], c1 = cb[L], c2 = cb[2u * L];
-            const uint32_t D[2][6] = {{c0.x, c0.y, c0.z, c0.w, c1.x, c1.y}, {c1.z, c1.w, c2.x, c2.y, c2.z, c2.w}};
+            const uint32_t el = lane < L ? lane : L - 1u;
+            int4 id4;
+            if (head) {                        // the row requested CULL_RING bins ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the younger requests are at least a bin old)
+                wave_lds_sync();
+                id4 = s_ids[w][use_n % CULL_RING][lane];
+                ++use_n;
+            } else {                           // the same cell again after a mid-cell flush: its row may be overwritten
+                id4 = (map ? idx1 : idx0)[(size_t)cell * L + el];
+            }
+            const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
+            const uint4* ct = map ? ctab1 : ctab0;
+            uint4 rec[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rec[j] = (dbg & 4u) ? make_uint4(id[j], id[j], 0x3c003c00u, 0x3c003c00u) : ct[id[j] < 0 ? 0 : id[j]];
+            if (head && pf_heads) { wave_lds_sync(); prefetch_row(); }      // into the slot just read (ids are in registers)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                t.mx[p] = f2{cc.x, cc.x} + cvt2(D[p][0]);
-                t.my[p] = f2{cc.y, cc.y} + cvt2(D[p][1]);
-                t.mz[p] = f2{cc.z, cc.z} + cvt2(D[p][2]);
-                t.nx[p] = cvt2(D[p][3]); t.ny[p] = cvt2(D[p][4]); t.nz[p] = cvt2(D[p][5]);
+                const uint4 a = rec[2 * p], b = rec[2 * p + 1];
+                const f2 za = cvt2(a.z), zb = cvt2(b.z), wa = cvt2(a.w), wb = cvt2(b.w);
+                t.mx[p] = f2{__uint_as_float(a.x), __uint_as_float(b.x)};
+                t.my[p] = f2{__uint_as_float(a.y), __uint_as_float(b.y)};
+                t.mz[p] = f2{za.x, zb.x};
+                t.nx[p] = f2{za.y, zb.y}; t.ny[p] = f2{wa.x, wb.x}; t.nz[p] = f2{wa.y, wb.y};
                 f2 s = t.nx[p] * t.nx[p];
                 s = fma2(t.ny[p], t.ny[p], s);
                 s = fma2(t.nz[p], t.nz[p], s);
                 s = s * f2{CULL_TAU2, CULL_TAU2};                  // = cull_r2()
-                // an empty slot (NaN x offset, zero normal) is never a candidate: finite centre, r2 = -inf
-                const bool e0 = t.mx[p].x == t.mx[p].x, e1 = t.mx[p].y == t.mx[p].y;
-                t.mx[p] = f2{e0 ? t.mx[p].x : 0.0f, e1 ? t.mx[p].y : 0.0f};
+                // an empty slot is never a candidate: r2 = -inf (its centre / normal are triangle 0's, finite)
+                const bool e0 = id[2 * p] >= 0, e1 = id[2 * p + 1] >= 0;
                 t.r2[p] = f2{e0 ? s.x : -__builtin_inff(), e1 ? s.y : -__builtin_inff()};
+                qid[p][0] = (e0 ? (uint32_t)id[2 * p] : CULL_NOID) | (map << 31);
+                qid[p][1] = e1 ? (uint32_t)id[2 * p + 1] : CULL_NOID;
             }
         }
         // PHASE 1: lanes whose pair p holds a triangle that (A) and (B) do not both reject
-        const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
-        const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
+        const float rsx = lane_bcast(ra.x, i), rsy = lane_bcast(ra.y, i), rsz = lane_bcast(ra.z, i);
+        const float rdx = lane_bcast(rb.x, i), rdy = lane_bcast(rb.y, i), rdz = lane_bcast(rb.z, i);
+        const f2 sx = {rsx, rsx}, sy = {rsy, rsy}, sz = {rsz, rsz};
+        const f2 dx = {rdx, rdx}, dy = {rdy, rdy}, dz = {rdz, rdz};
         uint64_t any[2];
+        if (dbg & 2u) { any[0] = any[1] = (dbg & 8u) ? 0xffull : 0ull; } else
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
@@ -312,7 +394,7 @@ __device__ __forceinline__ void raycast_culled_body(const RayRec* __restrict__ r
             if (any[p]) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any[p], 0u));
                 if (__builtin_amdgcn_inverse_ballot_w64(any[p]))
-                    q[qn + rank] = make_uint2(cell | (map << 31), ((i - i0) << 8) | (el << 1) | (uint32_t)p);
+                    q[qn + rank] = make_uint2(qid[p][0], qid[p][1] | (i << 26));
                 qn += (uint32_t)__builtin_popcountll(any[p]);
             }
         }
@@ -321,18 +403,12 @@ __device__ __forceinline__ void raycast_culled_body(const RayRec* __restrict__ r
     while (qn) {
         const uint32_t n = qn < 64u ? qn : 64u;
         qn -= n;
-        cull_flush(rays, sorted, tab0, tab1, kp0, kp1, q + qn, n, lane, i0, bk);
+        if (!(dbg & 1u)) cull_flush(ra, rb, rtab0, rtab1, q + qn, n, lane, bk);
     }
     wave_lds_sync();
-    if (i0 + lane < i_end) out[sorted[i0 + lane]] = funkey(bk[lane]);
+    if (lane < n_run) out[gid] = funkey(bk[lane]);
 }
 
-#define CULL_KERNEL_ARGS                                                                                                       \
-    const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const _Float16 *__restrict__ tab0, \
-        const _Float16 *__restrict__ tab1, const uint4 *__restrict__ cull0, const uint4 *__restrict__ cull1,                   \
-        const float4 *__restrict__ cen0, const float4 *__restrict__ cen1, uint32_t kp0, uint32_t kp1, uint32_t run,            \
-        uint32_t n_blocks, uint32_t nb8, float *__restrict__ out
-#define CULL_KERNEL_PASS rays, sorted, n_sorted, tab0, tab1, cull0, cull1, cen0, cen1, kp0, kp1, run, n_blocks, nb8, out
 __global__ void __launch_bounds__(256) raycast_culled_kernel(CULL_KERNEL_ARGS) { raycast_culled_body<0>(CULL_KERNEL_PASS); }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) raycast_culled_w6_kernel(CULL_KERNEL_ARGS) {
     raycast_culled_body<6>(CULL_KERNEL_PASS);
@@ -349,11 +425,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) r
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
 
-hipError_t launch_cull_build(const uint16_t* table, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell, float shift_x,
-                             float shift_y, float4* cen, uint16_t* cull, hipStream_t s) {
-    hipLaunchKernelGGL(cull_centre_kernel, dim3(blocks_for(n_cells, 256)), dim3(256), 0, s, table, (uint32_t)n_cells, K8, Y, cell,
-                       shift_x, shift_y, cen);
-    hipLaunchKernelGGL(cull_build_kernel, dim3(blocks_for(n_cells * K8, 256)), dim3(256), 0, s, table, n_cells, K8, cen, cull);
+hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
+                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, hipStream_t s) {
+    hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, tris, verts, T, V, rtab);
+    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, rtab, T, ctab);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, idx4);
     return hipGetLastError();
 }
 
@@ -366,8 +442,9 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     auto kern = a.waves == 6 ? raycast_culled_w6_kernel : a.waves == 7 ? raycast_culled_w7_kernel
               : a.waves == 8 ? raycast_culled_w8_kernel : raycast_culled_kernel;
     hipLaunchKernelGGL(kern, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
-                       reinterpret_cast<const _Float16*>(a.tab0), reinterpret_cast<const _Float16*>(a.tab1), a.cull0, a.cull1,
-                       a.cen0, a.cen1, a.kp0, a.kp1, a.run, a.n_blocks, a.nb8, a.out);
+                       reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
+                       reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.kp0, a.kp1, a.run,
+                       a.n_blocks, a.nb8, a.out, getenv("ROVER_CULL_DBG") ? (uint32_t)atoi(getenv("ROVER_CULL_DBG")) : 0u);
     return hipGetLastError();
 }
 

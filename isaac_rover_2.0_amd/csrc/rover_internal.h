@@ -57,9 +57,9 @@ struct CullArgs {
     const RayRec* rays;
     const uint32_t* sorted;      // ray slots sorted by (map, cell)
     uint32_t n_sorted;
-    const uint16_t *tab0, *tab1; // re-packed blocks [cell][9][K8] (exact arithmetic, phase 2)
-    const uint4 *cull0, *cull1;  // cull tables [cell][3][K8/4] x 16 B (phase 1)
-    const float4 *cen0, *cen1;   // per-cell reference point of the cull table's fp16 offsets
+    const int32_t *idx0, *idx1;  // [cell][K8/4][4] triangle ids of the cell (-1 = empty slot)
+    const uint4 *ctab0, *ctab1;  // [T] 16 B: bounding-sphere centre + scaled unit normal per triangle (phase 1)
+    const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
     uint32_t kp0, kp1, run, n_blocks, nb8;
     uint32_t waves;              // option cull_waves: 0 or 6..8 (register budget of the kernel build, A/B)
     float* out;
@@ -141,8 +141,8 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
                                  const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, uint32_t early_out, float* out,
                                  hipStream_t s);
-hipError_t launch_cull_build(const uint16_t* table, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell, float shift_x,
-                             float shift_y, float4* cen, uint16_t* cull, hipStream_t s);
+hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
+                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, hipStream_t s);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);

@@ -10,11 +10,13 @@ from isaac_rover_amd import _lib, synth
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 # keys starting with ENV_ set / clear an environment variable the launcher reads (experiments only)
-ARMS = [dict(raycast_variant=2, raycast_early_out=1, raycast_run=0, cull_waves=0),
-        dict(raycast_variant=3, raycast_run=0, cull_waves=0), dict(raycast_variant=3, raycast_run=0, cull_waves=6),
-        dict(raycast_variant=3, raycast_run=0, cull_waves=7), dict(raycast_variant=3, raycast_run=0, cull_waves=8),
-        dict(raycast_variant=3, raycast_run=16, cull_waves=0), dict(raycast_variant=3, raycast_run=64, cull_waves=0),
-        dict(raycast_variant=3, raycast_run=64, cull_waves=7)]
+ARMS = [dict(raycast_variant=3, raycast_run=0, cull_waves=0, ENV_ROVER_CULL_DBG=None),
+        dict(raycast_variant=3, raycast_run=0, cull_waves=0, ENV_ROVER_CULL_DBG="1"),     # no phase 2
+        dict(raycast_variant=3, raycast_run=0, cull_waves=0, ENV_ROVER_CULL_DBG="3"),     # no phase 1 maths, no candidates
+        dict(raycast_variant=3, raycast_run=0, cull_waves=0, ENV_ROVER_CULL_DBG="7"),     # + no ctab gathers
+        dict(raycast_variant=3, raycast_run=0, cull_waves=0, ENV_ROVER_CULL_DBG="4"),     # only: no ctab gathers
+        dict(raycast_variant=3, raycast_run=0, cull_waves=0, ENV_ROVER_CULL_DBG="10"),    # no phase 1 maths, 8 entries per pair per ray
+        ]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
 distn = synth.ray_distribution("37")
