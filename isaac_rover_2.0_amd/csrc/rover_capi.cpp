@@ -27,6 +27,10 @@ struct rover_ctx {
     uint4* cull_ctab[2]{nullptr, nullptr};
     uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
+    uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast (worst case: 128 entries per ray)
+    uint32_t* d_cull_fill = nullptr;
+    uint64_t cull_entries = 0;
+    uint32_t cull_run = 0;              // run length the queue was sized for
     // distribution
     double* d_dist = nullptr;       // [P][3]
     int32_t* d_obs_idx = nullptr;   // [Ns+Nd]
@@ -156,9 +160,10 @@ static int effective_variant(const rover_ctx* c) {
 static uint32_t effective_run(const rover_ctx* c) {
     if (c->run) return c->run;
     const uint64_t r = valid_rays(c) / 65536u;
-    // the culled kernel's set-up is lighter and its phase-2 batches fill better on long runs (65 536 envs: 32 -> 0.912 ms, 64 -> 0.882)
-    const uint64_t hi = effective_variant(c) == 3 ? 64 : 32;
-    return (uint32_t)(r < 4 ? 4 : (r > hi ? hi : r));
+    // the culled ray cast: one workgroup of the exact kernel per run, so short runs only add launches
+    // (65 536 envs: 16 -> 0.874 ms, 32 -> 0.807, 64 -> 0.801; 4 096 envs: 4 -> 0.115, 16 -> 0.100, 32 -> 0.102)
+    if (effective_variant(c) == 3) return (uint32_t)(r < 16 ? 16 : (r > 64 ? 64 : r));
+    return (uint32_t)(r < 4 ? 4 : (r > 32 ? 32 : r));
 }
 
 static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
@@ -177,6 +182,21 @@ static int alloc_bins(rover_ctx* c) {
         HIP_TRY(c, hipMalloc((void**)&c->d_bkt_table, ((uint64_t)bucket_count(c) * n_blocks + 1) * sizeof(uint32_t)));
         c->bins_ok = true;
     }
+    return ROVER_OK;
+}
+
+// candidate queue of the culled ray cast, sized for the worst case of the run length in force
+static int alloc_cull_queue(rover_ctx* c) {
+    if (!c->ws_ok || !c->have_dist || !c->cull_idx[0] || !c->cull_idx[1]) return ROVER_OK;
+    const uint32_t run = effective_run(c);
+    uint64_t n_runs = 0;
+    const uint64_t entries = cull_queue_entries(valid_rays(c), run, &n_runs);
+    if (c->d_cull_queue && entries <= c->cull_entries && run == c->cull_run) return ROVER_OK;
+    dfree(c->d_cull_queue); dfree(c->d_cull_fill);
+    c->cull_entries = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_cull_queue, entries * sizeof(uint2)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_cull_fill, n_runs * sizeof(uint32_t)));
+    c->cull_entries = entries; c->cull_run = run;
     return ROVER_OK;
 }
 
@@ -248,6 +268,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
+    dfree(c->d_cull_queue); dfree(c->d_cull_fill);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -453,6 +474,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.run = effective_run(c);
     a.waves = c->cull_waves;
     a.out = c->d_dist_out;
+    a.queue = c->d_cull_queue; a.fill = c->d_cull_fill;
     return a;
 }
 
@@ -469,6 +491,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
     p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading; p.env_rec = c->d_env_rec;
     const int variant = effective_variant(c);
+    if (variant == 3) { if (int r = alloc_cull_queue(c)) return r; }
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
     if (variant >= 2) p.bin_out = c->d_bins;
@@ -501,10 +524,10 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
-    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2;
+    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2; o.dist_is_key = variant == 3;
     HIP_TRY(c, launch_assemble_obs(o, s));
     if (out->ray_dist || out->wheel_dist || out->body_dist)
-        HIP_TRY(c, launch_export_dist(c->d_dist_out, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
+        HIP_TRY(c, launch_export_dist(c->d_dist_out, variant == 3, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
     if (out->euler) HIP_TRY(c, hipMemcpyAsync(out->euler, c->d_euler, (uint64_t)E * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->heading_diff) HIP_TRY(c, hipMemcpyAsync(out->heading_diff, c->d_heading, (uint64_t)E * sizeof(float), hipMemcpyDeviceToDevice, s));
     return ROVER_OK;
@@ -533,7 +556,7 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.wheel_thr = c->precision == 2 ? 0.7998046875f : 0.8f;                // fp16(0.8), fp16(0.45): Python scalars compared
     m.body_thr = c->precision == 2 ? 0.449951171875f : 0.45f;              // against fp16 tensors (rover.py:667-668)
     m.pos = in->pos; m.target = in->target; m.joints = in->joints; m.lin_hist = in->lin_hist; m.ang_hist = in->ang_hist;
-    m.euler_pre = in->euler_pre; m.heading = c->d_heading; m.dist = c->d_dist_out;
+    m.euler_pre = in->euler_pre; m.heading = c->d_heading; m.dist = c->d_dist_out; m.dist_is_key = c->last_variant == 3;
     m.progress = in->progress; m.rock_collision = out->rock_collision; m.rew = out->rew; m.reset = out->reset;
     m.ex_pos_reward = out->ex_pos_reward; m.ex_collision = out->ex_collision_penalty; m.ex_upright = out->ex_uprightness_penalty;
     m.ex_heading = out->ex_heading_contraint_penalty; m.ex_motion = out->ex_motion_contraint_penalty;
@@ -946,9 +969,10 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (v >= 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
-    if (v == 3)
+    if (v == 3) {
+        if (int r = alloc_cull_queue(c)) return r;
         HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
-    else if (v == 2)
+    } else if (v == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
                                          (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
     else

@@ -37,7 +37,6 @@ namespace rover {
 #define CULL_TAU2   1.6e-5f          // (4e-3)^2: guard threshold on the unit normal, folded into r2 = TAU2 * |n_stored|^2
 #define CULL_TAU    4.0e-3
 #define CULL_PAD    0.101            // barycentric padding of the proof (the reference's is fp16(0.1) = 0.09998)
-#define CULL_QCAP   320              // queue entries per wave: < 64 left after a flush + at most 128 new ones per ray, with slack
 #define CULL_RUNMAX 64               // sorted rays per wave (one result slot per lane)
 #define CULL_RING   4                // id rows (one bin each) in flight per wave: global -> LDS loads issued this many bins ahead
 
@@ -203,13 +202,6 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
 // ---------------------------------------------------------------------------------------------------
 struct CullRegs { f2 mx[2], my[2], mz[2], nx[2], ny[2], nz[2], r2[2]; };     // per lane: 4 triangles as 2 packed pairs
 
-// order-preserving f32 -> u32 key with -0 < +0, the order v_min_f32 gives the other kernels' reductions
-__device__ __forceinline__ uint32_t fkey(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float funkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
-
 // LDS traffic between the lanes of ONE wave: the hardware keeps a wave's LDS operations in order; this only stops the
 // compiler from moving them across
 __device__ __forceinline__ void wave_lds_sync() {
@@ -222,56 +214,33 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 struct RawTri { uint32_t d[5]; };    // rtab record: v0 xyz, v1 xyz, v2 xyz, pad as ten fp16 values (4-byte aligned)
 
-// one f32 of another lane (the LDS crossbar, no memory access)
-__device__ __forceinline__ float lane_gather(float v, uint32_t src_lane) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
-}
 __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-uniform */) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)src_lane));
 }
 
-// PHASE 2: n <= 64 queue entries, one per lane: the exact arithmetic on the entry's pair of triangles, min into the ray's slot.
-// ra / rb: the run's ray records, one per lane (lane = position in the run).
-__device__ __forceinline__ void cull_flush(const float4& ra, const float4& rb, const RawTri* __restrict__ rtab0,
-                                           const RawTri* __restrict__ rtab1, const uint2* qe, uint32_t n, uint32_t lane, uint32_t* bk) {
-    // every lane takes part in the cross-lane gathers; lanes past n compute on entry 0's data and drop the result
-    const uint2 en = qe[lane < n ? lane : 0u];
-    const uint32_t map = en.x >> 31, pos = en.y >> 26;
-    const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
-    const RawTri* rt = map ? rtab1 : rtab0;
-    const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
-    const float sx = lane_gather(ra.x, pos), sy = lane_gather(ra.y, pos), sz = lane_gather(ra.z, pos);
-    const float dx = lane_gather(rb.x, pos), dy = lane_gather(rb.y, pos), dz = lane_gather(rb.z, pos);
-    const float qnan = __builtin_nanf("");
-    f2 v[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
-        v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
-    }
-    // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
-    v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
-    CellRegs<1> t;
-    set_pair(t, 0, v);
-    const uint64_t none[1][2] = {{0, 0}};
-    const float best = cast_pairs<1>(t, f2{sx, sx}, f2{sy, sy}, f2{sz, sz}, f2{dx, dx}, f2{dy, dy}, f2{dz, dz}, none, 0u);
-    if (lane < n) atomicMin(bk + pos, fkey(best));
-}
-
-#define CULL_KERNEL_ARGS                                                                                                        \
+// ---------------------------------------------------------------------------------------------------
+// PHASE 1 — cull_scan_kernel.  One wave walks a run of <= 64 sorted rays.  Per (map, cell) bin it gathers the bin's 200
+// bounding-sphere / normal records (4 per lane, as 2 packed pairs); per ray it runs tests (A), (B) on all of them and
+// appends one 8-byte entry per lane-pair that holds a candidate to the wave's own region of the global candidate queue:
+//     entry = { id0 | map << 31,  id1 | position in the run << 26 }          (CULL_NOID = empty slot next to a candidate)
+// Region w = [w * run * 128, ...): a ray adds at most 128 entries, so it cannot overflow and nothing is allocated on the
+// device (one returning atomic per wave on a shared counter cost 2.7 ms); fill[w] = entries written.  The kernel also
+// stores the 11.0 sentinel (as an ordered-u32 key) for every ray of the run: a culled triangle contributes exactly that
+// (ray_casting.py:27,59), and phase 2 only ever lowers it.
+// Nothing here is heavy in registers or LDS, so 7-8 waves per SIMD hide the latencies of the id rows (HBM, streamed
+// through LDS CULL_RING bins ahead) and of the record gathers (L2).
+// ---------------------------------------------------------------------------------------------------
+#define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
-        const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
-        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, uint32_t kp0, uint32_t kp1, uint32_t run,           \
-        uint32_t n_blocks, uint32_t nb8, float *__restrict__ out, uint32_t dbg
-#define CULL_KERNEL_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, rtab0, rtab1, kp0, kp1, run, n_blocks, nb8, out, dbg
+        const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1, uint32_t kp0,           \
+        uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint32_t *__restrict__ out_key,                            \
+        uint2 *__restrict__ queue, uint32_t *__restrict__ fill
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, kp0, kp1, run, n_blocks, nb8, out_key, queue, fill
 
-// WPE: waves per SIMD the register allocation aims at (0 = the compiler's own choice) — option "cull_waves", A/B only
 template <int WPE>
-__device__ __forceinline__ void raycast_culled_body(CULL_KERNEL_ARGS) {
-    __shared__ uint2 s_queue[4][CULL_QCAP];
-    __shared__ uint32_t s_best[4][CULL_RUNMAX];
+__device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
     // XCD-aware order, as raycast_binned_kernel: each XCD walks one contiguous eighth of the sorted rays — here that also
-    // keeps the ctab / rtab records an XCD touches (a band of the map) inside its own L2
+    // keeps the ctab records an XCD touches (a band of the map) inside its own L2
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
     if (lb >= n_blocks) return;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -279,20 +248,18 @@ __device__ __forceinline__ void raycast_culled_body(CULL_KERNEL_ARGS) {
     const uint32_t i0 = wave * run;
     if (i0 >= n_sorted) return;
     const uint32_t n_run = min(run, n_sorted - i0);                  // <= 64
-    uint2* q = s_queue[w];
-    uint32_t* bk = s_best[w];
-    bk[lane] = fkey(RAY_MISS);                 // a culled triangle contributes the 11.0 sentinel (ray_casting.py:27,59)
     // The run's ray records, one per lane, in ONE round of loads (a per-ray scalar-load chain would cost a memory latency
-    // per ray, more than the ~75 instructions a ray takes); each ray's parameters then reach the SGPRs by v_readlane.
+    // per ray, more than the ~50 instructions a ray takes here); each ray's parameters reach the SGPRs by v_readlane.
     const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
     const float4* rp = reinterpret_cast<const float4*>(rays + gid);
     const float4 ra = rp[0], rb = rp[1];
+    if (lane < n_run) out_key[gid] = fkey(RAY_MISS);
     const uint32_t key = __float_as_uint(ra.w) | (__float_as_uint(rb.w) << 31);        // cell | map << 31
     const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
     // bit i: ray i starts a new (map, cell) bin
     const uint64_t heads = __builtin_amdgcn_ballot_w64(lane < n_run && (lane == 0u || key != prev));
     // The id rows of the run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
-    // memory latency per run instead of one per bin; with 4-5 waves per SIMD nothing else hides it).
+    // exposed memory latency per run instead of one per bin).
     __shared__ int4 s_ids[4][CULL_RING][64];
     uint64_t pf_heads = heads;                 // bins whose row is not requested yet
     uint32_t pf_n = 0, use_n = 0;              // rows requested / consumed so far (slot = count % CULL_RING)
@@ -301,6 +268,7 @@ __device__ __forceinline__ void raycast_culled_body(CULL_KERNEL_ARGS) {
         pf_heads &= pf_heads - 1ull;
         const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j);
         const uint32_t c2 = k2 & 0x7fffffffu, m2 = k2 >> 31, L2 = (m2 ? kp1 : kp0) >> 2;
+        // lanes past K (K8 < 256) repeat the last lane's triangles: a duplicate candidate cannot change a min
         const int4* src = (m2 ? idx1 : idx0) + (size_t)c2 * L2 + (lane < L2 ? lane : L2 - 1u);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
@@ -309,115 +277,138 @@ __device__ __forceinline__ void raycast_culled_body(CULL_KERNEL_ARGS) {
 #pragma unroll 1
     for (int d = 0; d < CULL_RING; ++d)
         if (pf_heads) prefetch_row();
-    uint32_t qn = 0;
-    uint32_t qid[2][2] = {{CULL_NOID, CULL_NOID}, {CULL_NOID, CULL_NOID}};     // the lane's ids as queue-entry fields
-    CullRegs t;
+    uint2* const qw = queue + (size_t)wave * run * 128u;     // the wave's region of the candidate queue
+    uint32_t cused = 0;
+    uint64_t hm = heads;
+    while (hm) {                               // one (map, cell) bin of the run: rays [i, i_end)
+        const uint32_t i = (uint32_t)__builtin_ctzll(hm);
+        hm &= hm - 1ull;
+        const uint32_t i_end = hm ? (uint32_t)__builtin_ctzll(hm) : n_run;
+        const uint32_t map = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i) >> 31;
+        // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        const int4 id4 = s_ids[w][use_n % CULL_RING][lane];
+        ++use_n;
+        const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
+        const uint4* ct = map ? ctab1 : ctab0;
+        uint4 rec[4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) t.mx[p] = t.my[p] = t.mz[p] = t.nx[p] = t.ny[p] = t.nz[p] = t.r2[p] = f2{0.0f, 0.0f};
-    for (uint32_t i = 0; i < n_run; ++i) {
-        const bool head = (heads >> i) & 1ull;
-        bool change = head;
-        // Flush full batches of 64 only where the cell registers are dead (before a set-up); mid-cell only when the queue
-        // could overflow, and then the cell is set up again.
-        if (qn > CULL_QCAP - 128u || (change && qn >= 64u)) {
-            wave_lds_sync();
-            do {
-                qn -= 64u;
-                if (!(dbg & 1u)) cull_flush(ra, rb, rtab0, rtab1, q + qn, 64u, lane, bk);
-            } while (qn >= 64u);
-            wave_lds_sync();
-            change = true;
+        for (int j = 0; j < 4; ++j) rec[j] = ct[id[j] < 0 ? 0 : id[j]];
+        if (pf_heads) { wave_lds_sync(); prefetch_row(); }              // into the slot just read (the ids are in registers)
+        CullRegs t;
+        uint32_t qid[2][2];                    // the lane's ids as queue-entry fields
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint4 a = rec[2 * p], b = rec[2 * p + 1];
+            const f2 za = cvt2(a.z), zb = cvt2(b.z), wa = cvt2(a.w), wb = cvt2(b.w);
+            t.mx[p] = f2{__uint_as_float(a.x), __uint_as_float(b.x)};
+            t.my[p] = f2{__uint_as_float(a.y), __uint_as_float(b.y)};
+            t.mz[p] = f2{za.x, zb.x};
+            t.nx[p] = f2{za.y, zb.y}; t.ny[p] = f2{wa.x, wb.x}; t.nz[p] = f2{wa.y, wb.y};
+            f2 s = t.nx[p] * t.nx[p];
+            s = fma2(t.ny[p], t.ny[p], s);
+            s = fma2(t.nz[p], t.nz[p], s);
+            s = s * f2{CULL_TAU2, CULL_TAU2};                  // = cull_r2()
+            // an empty slot is never a candidate: r2 = -inf (its centre / normal are triangle 0's, finite)
+            const bool e0 = id[2 * p] >= 0, e1 = id[2 * p + 1] >= 0;
+            t.r2[p] = f2{e0 ? s.x : -__builtin_inff(), e1 ? s.y : -__builtin_inff()};
+            qid[p][0] = (e0 ? (uint32_t)id[2 * p] : CULL_NOID) | (map << 31);
+            qid[p][1] = e1 ? (uint32_t)id[2 * p + 1] : CULL_NOID;
         }
-        if (change) {
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);
-            const uint32_t cell = k & 0x7fffffffu, map = k >> 31;
-            const uint32_t L = (map ? kp1 : kp0) >> 2;
-            // lanes past K (K8 < 256) repeat the last lane's triangles: no divergent set-up (a divergent one keeps the old
-            // cell's registers alive across the flush above), and a duplicate candidate cannot change a min
-            const uint32_t el = lane < L ? lane : L - 1u;
-            int4 id4;
-            if (head) {                        // the row requested CULL_RING bins ago
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the younger requests are at least a bin old)
-                wave_lds_sync();
-                id4 = s_ids[w][use_n % CULL_RING][lane];
-                ++use_n;
-            } else {                           // the same cell again after a mid-cell flush: its row may be overwritten
-                id4 = (map ? idx1 : idx0)[(size_t)cell * L + el];
-            }
-            const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
-            const uint4* ct = map ? ctab1 : ctab0;
-            uint4 rec[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rec[j] = (dbg & 4u) ? make_uint4(id[j], id[j], 0x3c003c00u, 0x3c003c00u) : ct[id[j] < 0 ? 0 : id[j]];
-            if (head && pf_heads) { wave_lds_sync(); prefetch_row(); }      // into the slot just read (ids are in registers)
+        for (uint32_t r = i; r < i_end; ++r) {
+            // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
+            const float rsx = lane_bcast(ra.x, r), rsy = lane_bcast(ra.y, r), rsz = lane_bcast(ra.z, r);
+            const float rdx = lane_bcast(rb.x, r), rdy = lane_bcast(rb.y, r), rdz = lane_bcast(rb.z, r);
+            const f2 sx = {rsx, rsx}, sy = {rsy, rsy}, sz = {rsz, rsz};
+            const f2 dx = {rdx, rdx}, dy = {rdy, rdy}, dz = {rdz, rdz};
+            uint64_t any[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const uint4 a = rec[2 * p], b = rec[2 * p + 1];
-                const f2 za = cvt2(a.z), zb = cvt2(b.z), wa = cvt2(a.w), wb = cvt2(b.w);
-                t.mx[p] = f2{__uint_as_float(a.x), __uint_as_float(b.x)};
-                t.my[p] = f2{__uint_as_float(a.y), __uint_as_float(b.y)};
-                t.mz[p] = f2{za.x, zb.x};
-                t.nx[p] = f2{za.y, zb.y}; t.ny[p] = f2{wa.x, wb.x}; t.nz[p] = f2{wa.y, wb.y};
-                f2 s = t.nx[p] * t.nx[p];
-                s = fma2(t.ny[p], t.ny[p], s);
-                s = fma2(t.nz[p], t.nz[p], s);
-                s = s * f2{CULL_TAU2, CULL_TAU2};                  // = cull_r2()
-                // an empty slot is never a candidate: r2 = -inf (its centre / normal are triangle 0's, finite)
-                const bool e0 = id[2 * p] >= 0, e1 = id[2 * p + 1] >= 0;
-                t.r2[p] = f2{e0 ? s.x : -__builtin_inff(), e1 ? s.y : -__builtin_inff()};
-                qid[p][0] = (e0 ? (uint32_t)id[2 * p] : CULL_NOID) | (map << 31);
-                qid[p][1] = e1 ? (uint32_t)id[2 * p + 1] : CULL_NOID;
+                const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
+                f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
+                f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
+                const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));                 // (A): 0.995 |h|^2 - (h.d)^2 > r2
+                f2 Dn = t.nx[p] * dx; Dn = fma2(t.ny[p], dy, Dn); Dn = fma2(t.nz[p], dz, Dn);
+                const f2 B = Dn * Dn;                                                   // (B): (n.d)^2 > tau^2 |n|^2 = r2
+                // one ballot per compare (each stays a v_cmp writing an SGPR pair); NaN compares false = stays a candidate
+                const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > t.r2[p].x);
+                const uint64_t rej1 = __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y) & __builtin_amdgcn_ballot_w64(B.y > t.r2[p].y);
+                any[p] = ~(rej0 & rej1);                                                // (all 64 lanes are active here)
             }
-        }
-        // PHASE 1: lanes whose pair p holds a triangle that (A) and (B) do not both reject
-        const float rsx = lane_bcast(ra.x, i), rsy = lane_bcast(ra.y, i), rsz = lane_bcast(ra.z, i);
-        const float rdx = lane_bcast(rb.x, i), rdy = lane_bcast(rb.y, i), rdz = lane_bcast(rb.z, i);
-        const f2 sx = {rsx, rsx}, sy = {rsy, rsy}, sz = {rsz, rsz};
-        const f2 dx = {rdx, rdx}, dy = {rdy, rdy}, dz = {rdz, rdz};
-        uint64_t any[2];
-        if (dbg & 2u) { any[0] = any[1] = (dbg & 8u) ? 0xffull : 0ull; } else
+            {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
-            f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
-            f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
-            const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));                     // (A): 0.995 |h|^2 - (h.d)^2 > r2
-            f2 Dn = t.nx[p] * dx; Dn = fma2(t.ny[p], dy, Dn); Dn = fma2(t.nz[p], dz, Dn);
-            const f2 B = Dn * Dn;                                                       // (B): (n.d)^2 > tau^2 |n|^2 = r2
-            // one ballot per compare (each stays a v_cmp writing an SGPR pair); NaN compares false = stays a candidate
-            const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > t.r2[p].x);
-            const uint64_t rej1 = __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y) & __builtin_amdgcn_ballot_w64(B.y > t.r2[p].y);
-            any[p] = ~(rej0 & rej1);                                                    // (all 64 lanes are active here)
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (any[p]) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any[p], 0u));
-                if (__builtin_amdgcn_inverse_ballot_w64(any[p]))
-                    q[qn + rank] = make_uint2(qid[p][0], qid[p][1] | (i << 26));
-                qn += (uint32_t)__builtin_popcountll(any[p]);
+                for (int p = 0; p < 2; ++p) {
+                    if (any[p]) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any[p], 0u));
+                        if (__builtin_amdgcn_inverse_ballot_w64(any[p]))
+                            qw[cused + rank] = make_uint2(qid[p][0], qid[p][1] | (r << 26));
+                        cused += (uint32_t)__builtin_popcountll(any[p]);
+                    }
+                }
             }
         }
     }
-    wave_lds_sync();
-    while (qn) {
-        const uint32_t n = qn < 64u ? qn : 64u;
-        qn -= n;
-        if (!(dbg & 1u)) cull_flush(ra, rb, rtab0, rtab1, q + qn, n, lane, bk);
-    }
-    wave_lds_sync();
-    if (lane < n_run) out[gid] = funkey(bk[lane]);
+    if (lane == 0u) fill[wave] = cused;
 }
 
-__global__ void __launch_bounds__(256) raycast_culled_kernel(CULL_KERNEL_ARGS) { raycast_culled_body<0>(CULL_KERNEL_PASS); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) raycast_culled_w6_kernel(CULL_KERNEL_ARGS) {
-    raycast_culled_body<6>(CULL_KERNEL_PASS);
-}
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) raycast_culled_w7_kernel(CULL_KERNEL_ARGS) {
-    raycast_culled_body<7>(CULL_KERNEL_PASS);
-}
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) raycast_culled_w8_kernel(CULL_KERNEL_ARGS) {
-    raycast_culled_body<8>(CULL_KERNEL_PASS);
+__global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) { cull_scan_body<0>(CULL_SCAN_PASS); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) cull_scan_w6_kernel(CULL_SCAN_ARGS) { cull_scan_body<6>(CULL_SCAN_PASS); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) cull_scan_w7_kernel(CULL_SCAN_ARGS) { cull_scan_body<7>(CULL_SCAN_PASS); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) cull_scan_w8_kernel(CULL_SCAN_ARGS) { cull_scan_body<8>(CULL_SCAN_PASS); }
+
+// ---------------------------------------------------------------------------------------------------
+// PHASE 2 — cull_exact_kernel.  One workgroup per run, one thread per queue entry (64-entry slices dealt to its 4 waves):
+// the exact arithmetic of rover_raymath.h (the code every other ray-cast kernel runs) on the entry's pair of triangles,
+// then the min over the entries of a ray.  A ray's entries are contiguous, so a segmented wave reduction leaves one
+// atomicMin per (wave, ray) on the ordered-u32 distance key.  Every lane is independent: the dependent gathers (sorted id
+// -> ray record, triangle records) overlap across the whole grid.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cull_exact_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
+                                                         const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
+                                                         const uint2* __restrict__ queue, const uint32_t* __restrict__ fill,
+                                                         uint32_t run, uint32_t* __restrict__ out_key) {
+    const uint32_t wv = blockIdx.x;                                // the run (= phase-1 wave) this workgroup finishes
+    const uint32_t n = fill[wv];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint2* qw = queue + (size_t)wv * run * 128u;
+    const uint32_t i0 = wv * run;
+    for (uint32_t base = (threadIdx.x >> 6) * 64u; base < n; base += 256u) {        // wave-uniform
+        const uint32_t e = base + lane;
+        const bool live = e < n;
+        const uint2 en = qw[live ? e : base];
+        const uint32_t map = en.x >> 31, pos = en.y >> 26;
+        const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
+        const RawTri* rt = map ? rtab1 : rtab0;
+        const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
+        const uint32_t gid = sorted[i0 + pos];
+        const float4* rp = reinterpret_cast<const float4*>(rays + gid);
+        const float4 ra = rp[0], rb = rp[1];
+        const float qnan = __builtin_nanf("");
+        f2 v[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
+            v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
+        }
+        // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
+        v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
+        CellRegs<1> t;
+        set_pair(t, 0, v);
+        const uint64_t none[1][2] = {{0, 0}};
+        const float best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
+                                         f2{rb.z, rb.z}, none, 0u);
+        // segmented min over the lanes with the same ray (contiguous); dead lanes carry a position no live lane has
+        uint32_t k = live ? fkey(best) : 0xffffffffu;
+        const uint32_t seg = live ? pos : 64u + lane;
+#pragma unroll
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t ok = (uint32_t)__shfl_down((int)k, off, 64), os = (uint32_t)__shfl_down((int)seg, off, 64);
+            if (lane + off < 64u && os == seg) k = ok < k ? ok : k;
+        }
+        const uint32_t ps = (uint32_t)__shfl_up((int)seg, 1, 64);
+        if (live && (lane == 0u || ps != seg)) atomicMin(out_key + gid, k);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -439,13 +430,24 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const uint32_t n_waves = blocks_for(a.n_sorted, a.run);
     a.n_blocks = blocks_for(n_waves, 4);
     a.nb8 = blocks_for(a.n_blocks, 8);
-    auto kern = a.waves == 6 ? raycast_culled_w6_kernel : a.waves == 7 ? raycast_culled_w7_kernel
-              : a.waves == 8 ? raycast_culled_w8_kernel : raycast_culled_kernel;
+    auto kern = a.waves == 6 ? cull_scan_w6_kernel : a.waves == 7 ? cull_scan_w7_kernel : a.waves == 8 ? cull_scan_w8_kernel : cull_scan_kernel;
     hipLaunchKernelGGL(kern, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
-                       reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
-                       reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.kp0, a.kp1, a.run,
-                       a.n_blocks, a.nb8, a.out, getenv("ROVER_CULL_DBG") ? (uint32_t)atoi(getenv("ROVER_CULL_DBG")) : 0u);
+                       reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.kp0, a.kp1,
+                       a.run, a.n_blocks, a.nb8, reinterpret_cast<uint32_t*>(a.out), a.queue, a.fill);
+    if (!getenv("ROVER_CULL_SKIP_EXACT"))          // diagnostic: time phase 1 alone (wrong results)
+        hipLaunchKernelGGL(cull_exact_kernel, dim3(n_waves), dim3(256), 0, s, a.rays, a.sorted,
+                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.queue, a.fill, a.run,
+                           reinterpret_cast<uint32_t*>(a.out));
     return hipGetLastError();
+}
+
+// entries the candidate queue must hold for n_rays rays in runs of `run`: every run owns run x 128 (a ray adds at most 128)
+uint64_t cull_queue_entries(uint64_t n_rays, uint32_t run, uint64_t* n_runs) {
+    if (run > CULL_RUNMAX) run = CULL_RUNMAX;
+    if (run == 0) run = 1;
+    const uint64_t n_waves = (n_rays + run - 1) / run;
+    if (n_runs) *n_runs = n_waves;
+    return n_waves * run * 128u;
 }
 
 }  // namespace rover
