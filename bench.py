@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--preroll-ms", type=float, default=400.0,
                     help="untimed load before the warm-up steps so that the GPU clocks have ramped (DVFS: the first ~60 ms of "
                          "load run up to 30 %% slower, measured with --debug-timing); 0 disables")
+    ap.add_argument("--no-torch-ref", action="store_true", help="skip the PyTorch tensor-program CPU baseline (oracle/torch_ref.py)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--rays", default="37", choices=["9", "37", "120", "native"],
                     help="BASELINE ray sets; native = the reference's own 1634-point distribution (1750-float obs)")
@@ -189,13 +190,34 @@ def cpu_baseline(args, scene, distn, states):
                     phys.add((pid, cid))
     except OSError:
         pass
-    return {"value": n / best, "unit": "env-steps/s", "cores": threads, "kind": "port", "cpu_model": model,
+    # second CPU baseline: the reference's APPROACH — dense [E, p, K, 3, 3] gathers, batched
+    # ray_distance, min over K, as a PyTorch tensor program (oracle/torch_ref.py) — in fp32 mode and as shipped (fp16 tensors)
+    torch_ref = None
+    if not args.no_torch_ref:
+        import torch
+        from oracle import torch_ref as tr
+        import dataclasses
+        host = lambda m: dataclasses.replace(m, map_indices=m.map_indices.cpu(), triangles=m.triangles.cpu(), vertices=m.vertices.cpu())
+        scene_cpu = dataclasses.replace(scene, terrain=host(scene.terrain), rocks=host(scene.rocks))
+        torch_ref = {"torch_threads": torch.get_num_threads()}
+        for name, dt, m in (("fp32", torch.float32, min(n, 256)), ("fp16_as_shipped", torch.float16, min(n, 64))):
+            sub = {k: v[:m] for k, v in st.items()}
+            tr.step(scene_cpu, sub, *distn, dtype=dt)                # warm-up
+            tb, tr_reps, t_all = float("inf"), 0, time.perf_counter()
+            while tr_reps < 2 or (time.perf_counter() - t_all < 4.0 and tr_reps < 5):
+                t0 = time.perf_counter()
+                tr.step(scene_cpu, sub, *distn, dtype=dt)
+                tb = min(tb, time.perf_counter() - t0)
+                tr_reps += 1
+            torch_ref[name] = {"value": m / tb, "unit": "env-steps/s", "sample": f"{m} envs x {tr_reps} reps, best rep"}
+    return {"value": n / best, "unit": "env-steps/s", "cores": threads, "kind": "port", "cpu_model": model, "torch_ref": torch_ref,
             "host": {"sockets": len(sockets) or None, "physical_cores": len(phys) or None, "logical_cpus": logical,
                      "omp_threads": threads},
             "sample": f"{n} envs x {reps} reps of the same workload (P={distn[0].shape[0]}, K={args.k}, "
                       f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp on every logical CPU",
             "reference_pytorch": "the reference's own PyTorch path is not runnable on the GPU box (it cannot travel); measured in the "
-                                 "build container (8 threads): 303-1525 env-steps/s, BASELINE.md §2"}
+                                 "build container (8 threads): 303-1525 env-steps/s, BASELINE.md §2; torch_ref = the same op "
+                                 "sequence restated in oracle/torch_ref.py, timed here"}
 
 
 # The touch points with the GPU runtime, as functions so that tests/test_host_logic.py can drive the N > 1 control flow (rank

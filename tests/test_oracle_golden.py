@@ -199,3 +199,22 @@ def test_ackermann_matches_reference():
     steer, vel = orc.ackermann(fx["lin"], fx["ang"])
     np.testing.assert_allclose(steer, fx["steer"], rtol=1e-6, atol=1e-6, equal_nan=True)
     np.testing.assert_allclose(vel, fx["vel"], rtol=1e-6, atol=1e-5, equal_nan=True)
+
+
+def test_torch_ref_matches_the_c_oracle():
+    """oracle/torch_ref.py (the tensor-program CPU baseline: dense [E, p, K, 3, 3] gathers + batched ray_distance + min, as
+    the reference runs it) against the per-ray C oracle on the same seeded inputs, fp32 mode; plus a smoke of the fp16 mode."""
+    import torch
+    from isaac_rover_amd import synth
+    from oracle import torch_ref
+    scene = synth.make_scene(n_cells=64, k=16, n_stones=16)
+    distn = synth.ray_distribution("37")
+    st = synth.make_states(96, 6.4, seed=5)
+    t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
+    want = orc.step(t, r, st, *distn)
+    got = torch_ref.step(scene, st, *distn)
+    assert_step_close(got, {"out_" + k: v for k, v in want.items()}, "torch_ref")
+    half = torch_ref.step(scene, {k: v[:8] for k, v in st.items()}, *distn, dtype=torch.float16)
+    d = np.abs(half["ray_dist"] - want["ray_dist"][:8])
+    assert np.median(d) < 0.05            # the as-shipped fp16 arithmetic: close, never equal (BASELINE.md §2: mean 0.0044)
