@@ -168,6 +168,8 @@ static uint32_t effective_run(const rover_ctx* c) {
 
 static uint32_t bucket_count(const rover_ctx* c) { return (c->n_bins + (1u << c->low_bits) - 1u) >> c->low_bits; }
 
+static int alloc_cull_queue(rover_ctx* c);
+
 static int alloc_bins(rover_ctx* c) {
     c->bins_ok = false;
     if (!c->have_map[0] || !c->have_map[1]) return ROVER_OK;
@@ -182,12 +184,12 @@ static int alloc_bins(rover_ctx* c) {
         HIP_TRY(c, hipMalloc((void**)&c->d_bkt_table, ((uint64_t)bucket_count(c) * n_blocks + 1) * sizeof(uint32_t)));
         c->bins_ok = true;
     }
-    return ROVER_OK;
+    return alloc_cull_queue(c);       // sized here, not in the step: hipMalloc is not allowed while a stream is capturing
 }
 
 // candidate queue of the culled ray cast, sized for the worst case of the run length in force
 static int alloc_cull_queue(rover_ctx* c) {
-    if (!c->ws_ok || !c->have_dist || !c->cull_idx[0] || !c->cull_idx[1]) return ROVER_OK;
+    if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) != 3) return ROVER_OK;
     const uint32_t run = effective_run(c);
     uint64_t n_runs = 0;
     const uint64_t entries = cull_queue_entries(valid_rays(c), run, &n_runs);
@@ -883,16 +885,17 @@ int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t
 
 int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
+    USE_DEVICE(c);                                 // some options (re)allocate device workspace
     if (!strcmp(name, "raycast_variant")) {
         if (value < 0 || value > 3) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned) or 3 (culled)");
         c->variant = (int)value;
-        return ROVER_OK;
+        return alloc_cull_queue(c);
     }
     if (!strcmp(name, "ray_precision")) {
         if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "ray_precision must be 0 (fp32), 1 (fp16 sources) or 2 (as shipped)");
         c->precision = (int)value;
         c->rays_valid = false;
-        return ROVER_OK;
+        return alloc_cull_queue(c);
     }
     if (!strcmp(name, "bin_low_bits")) {
         if (value < 8 || value > 12) return fail(c, ROVER_E_INVALID, "bin_low_bits must be in [8, 12]");
@@ -919,7 +922,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "raycast_run")) {
         if (value < 0 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be 0 (auto) or in [1, 4096]");
         c->run = (uint32_t)value;
-        return ROVER_OK;
+        return alloc_cull_queue(c);
     }
     return fail(c, ROVER_E_INVALID, "unknown option '%s'", name);
 }
