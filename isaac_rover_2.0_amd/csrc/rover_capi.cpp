@@ -526,10 +526,10 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
-    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2; o.dist_is_key = variant == 3;
+    o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2;
     HIP_TRY(c, launch_assemble_obs(o, s));
     if (out->ray_dist || out->wheel_dist || out->body_dist)
-        HIP_TRY(c, launch_export_dist(c->d_dist_out, variant == 3, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
+        HIP_TRY(c, launch_export_dist(c->d_dist_out, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
     if (out->euler) HIP_TRY(c, hipMemcpyAsync(out->euler, c->d_euler, (uint64_t)E * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->heading_diff) HIP_TRY(c, hipMemcpyAsync(out->heading_diff, c->d_heading, (uint64_t)E * sizeof(float), hipMemcpyDeviceToDevice, s));
     return ROVER_OK;
@@ -558,7 +558,7 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.wheel_thr = c->precision == 2 ? 0.7998046875f : 0.8f;                // fp16(0.8), fp16(0.45): Python scalars compared
     m.body_thr = c->precision == 2 ? 0.449951171875f : 0.45f;              // against fp16 tensors (rover.py:667-668)
     m.pos = in->pos; m.target = in->target; m.joints = in->joints; m.lin_hist = in->lin_hist; m.ang_hist = in->ang_hist;
-    m.euler_pre = in->euler_pre; m.heading = c->d_heading; m.dist = c->d_dist_out; m.dist_is_key = c->last_variant == 3;
+    m.euler_pre = in->euler_pre; m.heading = c->d_heading; m.dist = c->d_dist_out;
     m.progress = in->progress; m.rock_collision = out->rock_collision; m.rew = out->rew; m.reset = out->reset;
     m.ex_pos_reward = out->ex_pos_reward; m.ex_collision = out->ex_collision_penalty; m.ex_upright = out->ex_uprightness_penalty;
     m.ex_heading = out->ex_heading_contraint_penalty; m.ex_motion = out->ex_motion_contraint_penalty;

@@ -224,18 +224,16 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 // appends one 8-byte entry per lane-pair that holds a candidate to the wave's own region of the global candidate queue:
 //     entry = { id0 | map << 31,  id1 | position in the run << 26 }          (CULL_NOID = empty slot next to a candidate)
 // Region w = [w * run * 128, ...): a ray adds at most 128 entries, so it cannot overflow and nothing is allocated on the
-// device (one returning atomic per wave on a shared counter cost 2.7 ms); fill[w] = entries written.  The kernel also
-// stores the 11.0 sentinel (as an ordered-u32 key) for every ray of the run: a culled triangle contributes exactly that
-// (ray_casting.py:27,59), and phase 2 only ever lowers it.
+// device (one returning atomic per wave on a shared counter cost 2.7 ms); fill[w] = entries written.
 // Nothing here is heavy in registers or LDS, so 7-8 waves per SIMD hide the latencies of the id rows (HBM, streamed
 // through LDS CULL_RING bins ahead) and of the record gathers (L2).
 // ---------------------------------------------------------------------------------------------------
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1, uint32_t kp0,           \
-        uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint32_t *__restrict__ out_key,                            \
-        uint2 *__restrict__ queue, uint32_t *__restrict__ fill
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, kp0, kp1, run, n_blocks, nb8, out_key, queue, fill
+        uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint2 *__restrict__ queue,                                      \
+        uint32_t *__restrict__ fill
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, kp0, kp1, run, n_blocks, nb8, queue, fill
 
 template <int WPE>
 __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
@@ -248,13 +246,11 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
     const uint32_t i0 = wave * run;
     if (i0 >= n_sorted) return;
     const uint32_t n_run = min(run, n_sorted - i0);                  // <= 64
-    // The run's ray records, one per lane, in ONE round of loads (a per-ray scalar-load chain would cost a memory latency
-    // per ray, more than the ~50 instructions a ray takes here); each ray's parameters reach the SGPRs by v_readlane.
+    // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
+    // id rows ahead.  The rays' parameters come by scalar loads (s_load_dwordx8 through the ray id of lane r), requested one
+    // ray ahead so that their latency passes under the previous ray's arithmetic.
     const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
-    const float4* rp = reinterpret_cast<const float4*>(rays + gid);
-    const float4 ra = rp[0], rb = rp[1];
-    if (lane < n_run) out_key[gid] = fkey(RAY_MISS);
-    const uint32_t key = __float_as_uint(ra.w) | (__float_as_uint(rb.w) << 31);        // cell | map << 31
+    const uint32_t key = rays[gid].cell | (rays[gid].flags << 31);                     // cell | map << 31
     const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
     // bit i: ray i starts a new (map, cell) bin
     const uint64_t heads = __builtin_amdgcn_ballot_w64(lane < n_run && (lane == 0u || key != prev));
@@ -279,6 +275,12 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
         if (pf_heads) prefetch_row();
     uint2* const qw = queue + (size_t)wave * run * 128u;     // the wave's region of the candidate queue
     uint32_t cused = 0;
+    auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
+        const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
+        a4 = rp[0]; b4 = rp[1];
+    };
+    float4 nxa, nxb;
+    load_ray(0u, nxa, nxb);
     uint64_t hm = heads;
     while (hm) {                               // one (map, cell) bin of the run: rays [i, i_end)
         const uint32_t i = (uint32_t)__builtin_ctzll(hm);
@@ -318,10 +320,10 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
         }
         for (uint32_t r = i; r < i_end; ++r) {
             // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
-            const float rsx = lane_bcast(ra.x, r), rsy = lane_bcast(ra.y, r), rsz = lane_bcast(ra.z, r);
-            const float rdx = lane_bcast(rb.x, r), rdy = lane_bcast(rb.y, r), rdz = lane_bcast(rb.z, r);
-            const f2 sx = {rsx, rsx}, sy = {rsy, rsy}, sz = {rsz, rsz};
-            const f2 dx = {rdx, rdx}, dy = {rdy, rdy}, dz = {rdz, rdz};
+            const float4 ra = nxa, rb = nxb;
+            load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
+            const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
+            const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
             uint64_t any[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -360,19 +362,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) c
 // ---------------------------------------------------------------------------------------------------
 // PHASE 2 — cull_exact_kernel.  One workgroup per run, one thread per queue entry (64-entry slices dealt to its 4 waves):
 // the exact arithmetic of rover_raymath.h (the code every other ray-cast kernel runs) on the entry's pair of triangles,
-// then the min over the entries of a ray.  A ray's entries are contiguous, so a segmented wave reduction leaves one
-// atomicMin per (wave, ray) on the ordered-u32 distance key.  Every lane is independent: the dependent gathers (sorted id
-// -> ray record, triangle records) overlap across the whole grid.
+// then the min over the entries of a ray: a segmented wave reduction (a ray's entries are contiguous), one LDS atomicMin per
+// (wave, ray) on an ordered-u32 key, and at the end one plain store per ray of the run — the 11.0 sentinel where a ray
+// had no candidate at all (a culled triangle contributes exactly that, ray_casting.py:27,59).  No global atomics, and the
+// output buffer holds plain floats like the other kernels'.  Every lane is independent: the dependent gathers (sorted id ->
+// ray record, triangle records) overlap across the whole grid.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cull_exact_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
                                                          const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
                                                          const uint2* __restrict__ queue, const uint32_t* __restrict__ fill,
-                                                         uint32_t run, uint32_t* __restrict__ out_key) {
+                                                         uint32_t run, uint32_t n_sorted, float* __restrict__ out) {
+    __shared__ uint32_t s_best[CULL_RUNMAX];
     const uint32_t wv = blockIdx.x;                                // the run (= phase-1 wave) this workgroup finishes
     const uint32_t n = fill[wv];
     const uint32_t lane = threadIdx.x & 63u;
     const uint2* qw = queue + (size_t)wv * run * 128u;
     const uint32_t i0 = wv * run;
+    if (threadIdx.x < CULL_RUNMAX) s_best[threadIdx.x] = fkey(RAY_MISS);
+    __syncthreads();
     for (uint32_t base = (threadIdx.x >> 6) * 64u; base < n; base += 256u) {        // wave-uniform
         const uint32_t e = base + lane;
         const bool live = e < n;
@@ -407,8 +414,10 @@ __global__ void __launch_bounds__(256) cull_exact_kernel(const RayRec* __restric
             if (lane + off < 64u && os == seg) k = ok < k ? ok : k;
         }
         const uint32_t ps = (uint32_t)__shfl_up((int)seg, 1, 64);
-        if (live && (lane == 0u || ps != seg)) atomicMin(out_key + gid, k);
+        if (live && (lane == 0u || ps != seg)) atomicMin(s_best + pos, k);
     }
+    __syncthreads();
+    if (threadIdx.x < run && i0 + threadIdx.x < n_sorted) out[sorted[i0 + threadIdx.x]] = funkey(s_best[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -433,11 +442,11 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     auto kern = a.waves == 6 ? cull_scan_w6_kernel : a.waves == 7 ? cull_scan_w7_kernel : a.waves == 8 ? cull_scan_w8_kernel : cull_scan_kernel;
     hipLaunchKernelGGL(kern, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.kp0, a.kp1,
-                       a.run, a.n_blocks, a.nb8, reinterpret_cast<uint32_t*>(a.out), a.queue, a.fill);
-    if (!getenv("ROVER_CULL_SKIP_EXACT"))          // diagnostic: time phase 1 alone (wrong results)
+                       a.run, a.n_blocks, a.nb8, a.queue, a.fill);
+    if (!getenv("ROVER_CULL_SKIP_EXACT"))          // diagnostic: time phase 1 alone (no results)
         hipLaunchKernelGGL(cull_exact_kernel, dim3(n_waves), dim3(256), 0, s, a.rays, a.sorted,
                            reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.queue, a.fill, a.run,
-                           reinterpret_cast<uint32_t*>(a.out));
+                           a.n_sorted, a.out);
     return hipGetLastError();
 }
 

@@ -62,7 +62,7 @@ struct CullArgs {
     const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
     uint32_t kp0, kp1, run, n_blocks, nb8;
     uint32_t waves;              // option cull_waves: 0 or 6..8 (register budget of the kernel build, A/B)
-    float* out;                  // [E*R8] distances as ordered-u32 keys (cull_key_to_float decodes)
+    float* out;                  // [E*R8] distances
     uint2* queue;                // candidate queue: one region of run x 128 8-byte entries per run
     uint32_t* fill;              // entries written per run
 };
@@ -73,7 +73,6 @@ struct ObsArgs {
     int64_t obs_stride;
     const float *pos, *target, *heading, *lin_hist, *ang_hist, *dist;
     int32_t fp16_div;            // as-shipped mode: round dist / 2 to fp16
-    int32_t dist_is_key;         // dist holds ordered-u32 keys (culled ray cast)
     const int32_t* obs_idx;      // [Ns+Nd] ray index per heightmap column
     float* obs;
 };
@@ -86,7 +85,6 @@ struct MetricsArgs {
     float pos_reward, heading_contraint_reward, motion_contraint_reward, goal_angle_reward, boogie_contraint_reward;
     float wheel_thr, body_thr;   // rover.py:667-668 thresholds (0.8 / 0.45; their fp16 roundings in the as-shipped mode)
     const float *pos, *target, *joints, *lin_hist, *ang_hist, *euler_pre, *heading, *dist;
-    int32_t dist_is_key;         // dist holds ordered-u32 keys (culled ray cast)
     int64_t* progress;
     int64_t* rock_collision;
     float* rew;
@@ -158,7 +156,7 @@ hipError_t launch_knn_select(const float* cx, const float* cy, const uint32_t* b
                              float g, uint32_t nbx, uint32_t nby, uint32_t X, uint32_t Y, float res, uint32_t K, const float* cell_x,
                              const float* cell_y, int32_t* out, int32_t* overflow, hipStream_t s);
 hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
-hipError_t launch_export_dist(const float* dist, int is_key, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
+hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
                               hipStream_t s);
 hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s);
 hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint32_t* block_cnt, bool counted, int64_t* ids,

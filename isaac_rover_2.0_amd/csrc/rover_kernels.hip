@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
     float v;
     if (col >= 4u) {
         int32_t p = a.obs_idx[col - 4u];                       // sparse then dense, heightmap_distribution.py:126-133
-        v = dist_load(a.dist, (uint64_t)e * a.R8 + 26u + (uint32_t)p, a.dist_is_key) / 2.0f;
+        v = a.dist[(uint64_t)e * a.R8 + 26u + (uint32_t)p] / 2.0f;
         if (a.fp16_div) v = (float)(_Float16)v;                // as shipped: `sparse / 2` is an fp16 division (rover.py:324-325)
     } else if (col == 0u) {
         float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
@@ -360,14 +360,14 @@ __global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
 }
 
 // optional intermediates for parity tests
-__global__ void __launch_bounds__(256) export_dist_kernel(const float* __restrict__ dist, int is_key, uint32_t E, uint32_t R8, uint32_t P,
+__global__ void __launch_bounds__(256) export_dist_kernel(const float* __restrict__ dist, uint32_t E, uint32_t R8, uint32_t P,
                                                           float* __restrict__ ray_dist, float* __restrict__ wheel,
                                                           float* __restrict__ body) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 26u + P;
     if (i >= (uint64_t)E * n) return;
     uint32_t e = (uint32_t)(i / n), s = (uint32_t)(i % n);
-    float v = dist_load(dist, (uint64_t)e * R8 + s, is_key);
+    float v = dist[(uint64_t)e * R8 + s];
     if (s < 24u) { if (wheel) wheel[24ull * e + s] = v; }
     else if (s < 26u) { if (body) body[2ull * e + (s - 24u)] = v; }
     else if (ray_dist) ray_dist[(uint64_t)e * P + (s - 26u)] = v;
@@ -393,12 +393,11 @@ __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t 
     if (a.do_collision) {                                                   // check_collision, rover.py:663-668
         coll = 0;
         if (a.curriculum_level >= 2) {
-            const uint64_t d0 = (uint64_t)e * a.R8;
-            float mw = dist_load(a.dist, d0, a.dist_is_key);
+            const float* d = a.dist + (uint64_t)e * a.R8;
+            float mw = d[0];
 #pragma unroll
-            for (int r = 1; r < 24; ++r) { const float dr = dist_load(a.dist, d0 + r, a.dist_is_key); mw = (dr < mw) ? dr : mw; }
-            const float b0 = dist_load(a.dist, d0 + 24, a.dist_is_key), b1 = dist_load(a.dist, d0 + 25, a.dist_is_key);
-            float mb = (b1 < b0) ? b1 : b0;
+            for (int r = 1; r < 24; ++r) mw = (d[r] < mw) ? d[r] : mw;
+            float mb = (d[25] < d[24]) ? d[25] : d[24];
             coll = (fabsf(mw) < a.wheel_thr) ? 1 : 0;            // 0.8 / 0.45, as fp16 values in the as-shipped mode
             if (fabsf(mb) < a.body_thr) coll = 1;
         }
@@ -1419,9 +1418,9 @@ hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_export_dist(const float* dist, int is_key, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
+hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
                               hipStream_t s) {
-    hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, is_key, E, R8, P,
+    hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, E, R8, P,
                        ray_dist, wheel, body);
     return hipGetLastError();
 }

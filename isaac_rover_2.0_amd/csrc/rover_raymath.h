@@ -84,19 +84,13 @@ struct CellRegs {
     }
 };
 
-// Distances as ordered-u32 keys (the culled ray cast reduces with integer atomicMin): order-preserving f32 -> u32 with
-// -0 < +0, the order v_min_f32 gives the other kernels' reductions.
+// Distances as ordered-u32 keys (the culled ray cast reduces with an integer LDS atomicMin): order-preserving f32 -> u32
+// with -0 < +0, the order v_min_f32 gives the other kernels' reductions.
 __device__ __forceinline__ uint32_t fkey(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float funkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
-// a distance as the step's consumers read it from the ray-cast output buffer
-__device__ __forceinline__ float dist_load(const float* __restrict__ dist, uint64_t i, int is_key) {
-    const float v = dist[i];
-    return is_key ? funkey(__float_as_uint(v)) : v;
-}
-
 // one packed pair from its nine vertex components (component q = 3 * vertex + coord, two triangles side by side)
 template <int NP>
 __device__ __forceinline__ void set_pair(CellRegs<NP>& t, int p, const f2 (&v)[9]) {
