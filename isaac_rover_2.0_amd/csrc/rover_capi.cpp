@@ -26,6 +26,7 @@ struct rover_ctx {
     int32_t* cull_idx[2]{nullptr, nullptr};
     uint4* cull_ctab[2]{nullptr, nullptr};
     uint16_t* cull_rtab[2]{nullptr, nullptr};
+    uint4* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast (worst case: 128 entries per ray)
     uint32_t* d_cull_fill = nullptr;
@@ -261,7 +262,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -311,24 +312,28 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     int32_t* d_cidx = nullptr;
     uint4* d_ctab = nullptr;
     uint16_t* d_rtab = nullptr;
+    uint4* d_qrow = nullptr;
+    float* d_nz = nullptr;
     uint64_t cull_bytes = 0;
     if (K8 <= 256 && (uint32_t)T < 0x3ffffffu) {
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t), b_ct = (uint64_t)T * sizeof(uint4), b_rt = (uint64_t)T * 20u;
-        cull_bytes = b_idx + b_ct + b_rt;
+        cull_bytes = b_idx + b_ct + b_rt + n_cells * sizeof(uint4);
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
-            (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess ||
+            (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint4))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_nz, (uint64_t)T * sizeof(float))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, (uint32_t)V, d_cidx, d_ctab, d_rtab,
-                                   nullptr)) != hipSuccess ||
+                                   d_qrow, d_nz, nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess) {
-            cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_table);
+            cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_qrow); dfree(d_nz); dfree(d_table);
             return fail(c, ROVER_E_HIP, "set_knn_map: cull tables (%llu B): %s", (unsigned long long)cull_bytes, hipGetErrorString(e));
         }
     }
     cleanup();
+    dfree(d_nz);
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
-    dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]);
-    c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_bytes[which] = cull_bytes;
+    dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
+    c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_qrow[which] = d_qrow; c->cull_bytes[which] = cull_bytes;
     c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, 1.0f / cell};
     c->table_bytes[which] = bytes + cull_bytes;
     c->have_map[which] = true;
@@ -471,7 +476,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     CullArgs a{};
     a.rays = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
     a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1]; a.ctab0 = c->cull_ctab[0]; a.ctab1 = c->cull_ctab[1];
-    a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1];
+    a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1]; a.qrow0 = c->cull_qrow[0]; a.qrow1 = c->cull_qrow[1];
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.waves = c->cull_waves;

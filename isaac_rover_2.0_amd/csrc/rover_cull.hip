@@ -26,6 +26,10 @@
 // so with (A):  |det*| <= 2e-6 |b||c| / 0.02 = 1e-4 |b||c|.  But (B) and the sliver bound give
 // |det*| = |N . d| >= (4e-3 - 1e-3) * 0.05 |b||c| = 1.5e-4 |b||c|  — a contradiction: the reference rejects.
 // NaN / inf anywhere makes (A) or (B) compare false, i.e. keeps the triangle a candidate.  DESIGN.md §4.3 has the long form.
+// (B) for a whole cell at once: with q = min over the cell's triangles of |N_z| / |N| (0 if any is a sliver) and beta the
+// ray's angle from the vertical, every triangle has |N . d| / |N| >= cos(acos q + beta), which exceeds 3.5e-3 iff
+// q > 3.5e-3 |d_z| + sqrt(1 - 3.5e-3^2) |d_xy|.  prep_rays_kernel stores the right-hand side (rounded up to 16 bits) in the
+// ray record, the id row carries q (rounded down): where q wins, phase 1 runs test (A) only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -86,7 +90,8 @@ __global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restri
     for (int q = 0; q < 10; ++q) rtab[10ull * t + q] = v[q];
 }
 
-__global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, uint4* __restrict__ ctab) {
+__global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, uint4* __restrict__ ctab,
+                                                         float* __restrict__ nz_abs) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const _Float16* src = reinterpret_cast<const _Float16*>(rtab) + 10ull * t;
@@ -95,6 +100,7 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
 #pragma unroll
     for (int q = 0; q < 9; ++q) { v[q] = (float)src[q]; valid = valid && (v[q] == v[q]) && fabsf(v[q]) < 6.0e4f; }
     float mk[3] = {0.0f, 0.0f, 0.0f};                                // the centre as phase 1 decodes it
+    float nzq = 0.0f;                                                // |N_z| / |N| of the exact normal; 0 = no cone shortcut for its cells
     uint16_t zh = 0, nh[3] = {0, 0, 0};                              // zero normal: guard (B) never holds = always a candidate
     if (valid) {
         // a, b, c exactly as ray_casting.py:34-36 / set_pair compute them (f32), widened
@@ -166,19 +172,25 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
             ok = done;
         }
         if (!ok) nh[0] = nh[1] = nh[2] = 0;
+        else nzq = (float)(fabs(N[2]) / nN * (1.0 - 1.0e-6));
     }
+    nz_abs[t] = nzq;
     ctab[t] = make_uint4(__float_as_uint(mk[0]), __float_as_uint(mk[1]), (uint32_t)zh | ((uint32_t)nh[0] << 16),
                          (uint32_t)nh[1] | ((uint32_t)nh[2] << 16));
 }
 
-// one workgroup per cell: the cell's K ids sorted ascending (empty / out-of-range ids last), dealt to the lanes in quarters
+// one workgroup per cell: the cell's K ids sorted ascending (empty / out-of-range ids last), dealt to the lanes in quarters;
+// qrow[cell] = {q16, 0, 0, 0}: q = min |N_z| / |N| over the cell's triangles as a 16-bit fraction rounded down (0 = none)
 __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restrict__ map_idx, uint32_t K, uint32_t K8, uint32_t T,
-                                                         int32_t* __restrict__ idx4) {
+                                                         const float* __restrict__ nz_abs, int32_t* __restrict__ idx4,
+                                                         uint4* __restrict__ qrow) {
     __shared__ uint32_t key[256];
+    __shared__ float qmin[256];
     const uint32_t cell = blockIdx.x, tid = threadIdx.x, L = K8 >> 2;
     uint32_t k = 0xffffffffu;
     if (tid < K) { const uint32_t t = (uint32_t)map_idx[(uint64_t)cell * K + tid]; if (t < T) k = t; }
     key[tid] = k;
+    qmin[tid] = k != 0xffffffffu ? nz_abs[k] : 2.0f;
     __syncthreads();
     for (uint32_t len = 2; len <= 256u; len <<= 1) {
         for (uint32_t stride = len >> 1; stride > 0; stride >>= 1) {
@@ -191,14 +203,24 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
             __syncthreads();
         }
     }
+    for (uint32_t sdt = 128u; sdt > 0; sdt >>= 1) {
+        if (tid < sdt) qmin[tid] = fminf(qmin[tid], qmin[tid + sdt]);
+        __syncthreads();
+    }
     if (tid < K8) {
         const uint32_t lane = tid % L, j = tid / L;                   // sorted position tid -> slot j of lane `lane`
         idx4[((uint64_t)cell * L + lane) * 4u + j] = (int32_t)key[tid];     // 0xffffffff -> -1
     }
+    if (tid == 0) {
+        const float q = qmin[0];
+        uint32_t q16 = 0;
+        if (q <= 1.0f && q > 0.0f) { q16 = (uint32_t)floorf(q * 65535.0f); q16 = q16 > 0xfffeu ? 0xfffeu : q16; }
+        qrow[cell] = make_uint4(q16, 0u, 0u, 0u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// the kernel
+// the kernels
 // ---------------------------------------------------------------------------------------------------
 struct CullRegs { f2 mx[2], my[2], mz[2], nx[2], ny[2], nz[2], r2[2]; };     // per lane: 4 triangles as 2 packed pairs
 
@@ -230,10 +252,10 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 // ---------------------------------------------------------------------------------------------------
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
-        const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1, uint32_t kp0,           \
-        uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint2 *__restrict__ queue,                                      \
+        const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
+        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint2 *__restrict__ queue,                                      \
         uint32_t *__restrict__ fill
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, kp0, kp1, run, n_blocks, nb8, queue, fill
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, nb8, queue, fill
 
 template <int WPE>
 __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
@@ -266,6 +288,7 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
         const uint32_t c2 = k2 & 0x7fffffffu, m2 = k2 >> 31, L2 = (m2 ? kp1 : kp0) >> 2;
         // lanes past K (K8 < 256) repeat the last lane's triangles: a duplicate candidate cannot change a min
         const int4* src = (m2 ? idx1 : idx0) + (size_t)c2 * L2 + (lane < L2 ? lane : L2 - 1u);
+        if (lane == 63u && L2 < 64u) src = reinterpret_cast<const int4*>((m2 ? qrow1 : qrow0) + c2);   // slot 63: the cell's q
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
         ++pf_n;
@@ -290,7 +313,10 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
         // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
-        const int4 id4 = s_ids[w][use_n % CULL_RING][lane];
+        const uint32_t L = (map ? kp1 : kp0) >> 2;
+        const int4 id4 = s_ids[w][use_n % CULL_RING][lane < L ? lane : L - 1u];
+        // the cell's normal cone as a 16-bit fraction (0: none; K8 = 256 leaves no slot for it)
+        const uint32_t q16 = L < 64u ? (uint32_t)__builtin_amdgcn_readfirstlane(s_ids[w][use_n % CULL_RING][63].x) : 0u;
         ++use_n;
         const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
         const uint4* ct = map ? ctab1 : ctab0;
@@ -325,18 +351,31 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
             const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
             const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
             uint64_t any[2];
+            // the ray's cone bound (prep_rays_kernel, flags bits 16..31) against the cell's: (B) holds for every triangle
+            const bool cone = q16 >= (__float_as_uint(rb.w) >> 16);
+            if (cone) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
-                f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
-                f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
-                const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));                 // (A): 0.995 |h|^2 - (h.d)^2 > r2
-                f2 Dn = t.nx[p] * dx; Dn = fma2(t.ny[p], dy, Dn); Dn = fma2(t.nz[p], dz, Dn);
-                const f2 B = Dn * Dn;                                                   // (B): (n.d)^2 > tau^2 |n|^2 = r2
-                // one ballot per compare (each stays a v_cmp writing an SGPR pair); NaN compares false = stays a candidate
-                const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > t.r2[p].x);
-                const uint64_t rej1 = __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y) & __builtin_amdgcn_ballot_w64(B.y > t.r2[p].y);
-                any[p] = ~(rej0 & rej1);                                                // (all 64 lanes are active here)
+                for (int p = 0; p < 2; ++p) {
+                    const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
+                    f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
+                    f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
+                    const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));             // (A): 0.995 |h|^2 - (h.d)^2 > r2
+                    any[p] = ~(__builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y));
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
+                    f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
+                    f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
+                    const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));             // (A): 0.995 |h|^2 - (h.d)^2 > r2
+                    f2 Dn = t.nx[p] * dx; Dn = fma2(t.ny[p], dy, Dn); Dn = fma2(t.nz[p], dz, Dn);
+                    const f2 B = Dn * Dn;                                               // (B): (n.d)^2 > tau^2 |n|^2 = r2
+                    // one ballot per compare (each stays a v_cmp writing an SGPR pair); NaN compares false = stays a candidate
+                    const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > t.r2[p].x);
+                    const uint64_t rej1 = __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y) & __builtin_amdgcn_ballot_w64(B.y > t.r2[p].y);
+                    any[p] = ~(rej0 & rej1);                                            // (all 64 lanes are active here)
+                }
             }
             {
 #pragma unroll
@@ -426,10 +465,11 @@ __global__ void __launch_bounds__(256) cull_exact_kernel(const RayRec* __restric
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
 
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
-                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, hipStream_t s) {
+                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow,
+                             float* nz_scratch, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, tris, verts, T, V, rtab);
-    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, rtab, T, ctab);
-    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, idx4);
+    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, rtab, T, ctab, nz_scratch);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, nz_scratch, idx4, qrow);
     return hipGetLastError();
 }
 
@@ -441,8 +481,8 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     a.nb8 = blocks_for(a.n_blocks, 8);
     auto kern = a.waves == 6 ? cull_scan_w6_kernel : a.waves == 7 ? cull_scan_w7_kernel : a.waves == 8 ? cull_scan_w8_kernel : cull_scan_kernel;
     hipLaunchKernelGGL(kern, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
-                       reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.kp0, a.kp1,
-                       a.run, a.n_blocks, a.nb8, a.queue, a.fill);
+                       reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
+                       a.kp0, a.kp1, a.run, a.n_blocks, a.nb8, a.queue, a.fill);
     if (!getenv("ROVER_CULL_SKIP_EXACT"))          // diagnostic: time phase 1 alone (no results)
         hipLaunchKernelGGL(cull_exact_kernel, dim3(n_waves), dim3(256), 0, s, a.rays, a.sorted,
                            reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.queue, a.fill, a.run,

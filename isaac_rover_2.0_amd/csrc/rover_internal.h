@@ -10,7 +10,7 @@ struct RayRec {
     float sx, sy, sz;    // origin
     uint32_t cell;       // ix * Y + iy into the map the flags select
     float dx, dy, dz;    // -normalize(direction), ray_casting.py:31
-    uint32_t flags;      // bit0: rocks map, bit1: valid
+    uint32_t flags;      // bit0: rocks map, bit1: valid; bits 16..31: the ray's normal-cone bound (rover_cull.hip), 0xffff = none
 };
 static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
 
@@ -59,6 +59,7 @@ struct CullArgs {
     uint32_t n_sorted;
     const int32_t *idx0, *idx1;  // [cell][K8/4][4] triangle ids of the cell (-1 = empty slot)
     const uint4 *ctab0, *ctab1;  // [T] 16 B: bounding-sphere centre + scaled unit normal per triangle (phase 1)
+    const uint4 *qrow0, *qrow1;  // [cell] {q16, 0, 0, 0}: the cell's normal cone (min |N_z| / |N| as a 16-bit fraction)
     const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
     uint32_t kp0, kp1, run, n_blocks, nb8;
     uint32_t waves;              // option cull_waves: 0 or 6..8 (register budget of the kernel build, A/B)
@@ -145,7 +146,8 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
                                  const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, uint32_t early_out, float* out,
                                  hipStream_t s);
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
-                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, hipStream_t s);
+                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow,
+                             float* nz_scratch, hipStream_t s);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);

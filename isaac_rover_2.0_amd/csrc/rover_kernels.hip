@@ -258,6 +258,12 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         } else {
             neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
         }
+        {   // the ray's normal-cone bound for the culled ray cast (rover_cull.hip): a cell whose triangles all have
+            // |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole; 16-bit fraction rounded up, 0xffff = none
+            const float qm = 3.5e-3f * fabsf(rec.dz) + sqrtf(rec.dx * rec.dx + rec.dy * rec.dy) + 2.0e-5f;
+            const uint32_t qq = (qm < 0.9999f) ? (uint32_t)ceilf(qm * 65535.0f) : 0xffffu;      // NaN -> 0xffff
+            rec.flags |= qq << 16;
+        }
         uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->inv_cell, a.cell_rcp, m->X);
         uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->inv_cell, a.cell_rcp, m->X);
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
