@@ -66,8 +66,8 @@ __device__ __forceinline__ float cull_r2(float nx, float ny, float nz) {
 //   ctab [T]        16 B: {centre x, centre y (f32), half2(centre z, nx), half2(ny, nz)} — bounding-sphere centre of the padded
 //                         triangle and its unit normal scaled to length r / tau (r2 = tau^2 |n|^2 is the sphere test's radius)
 //   idx4 [cell][L][4] i32: the cell's K triangle ids (-1 = empty slot), L = K8 / 4 lanes x 4; ids sorted ascending and dealt
-//                         in quarters (slot j of lane l = sorted[j L + l]) so that one gather instruction of a wave touches
-//                         neighbouring ctab records (few L2 lines)
+//                         as pairs of neighbours (pair m = sorted[2m], sorted[2m + 1] -> lane m % L, pair slot m / L) so
+//                         that one gather instruction of a wave touches neighbouring ctab records (few L2 lines)
 // The per-triangle tables are small (26 B x T: 18 MB for 720 k triangles) and stay in L2 / MALL; HBM only streams idx4.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restrict__ tris, const uint16_t* __restrict__ verts,
@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         __syncthreads();
     }
     if (tid < K8) {
-        const uint32_t lane = tid % L, j = tid / L;                   // sorted position tid -> slot j of lane `lane`
+        // sorted position tid -> slot j of lane `lane`: neighbours 2m, 2m + 1 (on a grid mesh the two triangles of one mesh
+        // cell) share a packed pair, so that a pair sent to the exact kernel tends to hold two candidates; pair m goes to
+        // lane m % L, which keeps one gather instruction of a wave on consecutive records
+        const uint32_t m = tid >> 1, lane = m % L, j = 2u * (m / L) + (tid & 1u);
         idx4[((uint64_t)cell * L + lane) * 4u + j] = (int32_t)key[tid];     // 0xffffffff -> -1
     }
     if (tid == 0) {
