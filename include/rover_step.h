@@ -238,6 +238,16 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
                                    const float *weight, const float *bias, int32_t N, int32_t activation, float *y,
                                    int64_t y_stride, void *stream);
 
+/* A chain of 2 or 4 such layers in ONE kernel: y = L_n(... L_1(x[:, 0:K0])), L_i(v) = act_i(W_i v + b_i) — an Encoder
+ * (learning/model.py:122-150: 634 -> 80 -> 60) or the MLP with its head (:176-195: 124 -> 256 -> 160 -> 128 -> 2).  Only x and the
+ * last layer's output touch HBM: the activations stay in the MFMA accumulator registers, which are the next layer's B operand as
+ * they are (csrc/rover_mlp.hip).  weights[i] is nn.Linear's [widths[i]][widths[i-1]] (K0 for i = 0), biases[i] may be NULL.
+ * Built tile shapes: 2 layers with widths <= 96, <= 64; 4 layers with widths <= 256, <= 160, <= 128, <= 32 (else ROVER_E_INVALID:
+ * use rover_linear_forward per layer).  Same numerics as rover_linear_forward up to the summation order inside a layer. */
+ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers,
+                                      const float *const *weights, const float *const *biases, const int32_t *widths,
+                                      const int32_t *activations, float *y, int64_t y_stride, void *stream);
+
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers

@@ -101,6 +101,7 @@ SYMBOLS = {
     "rover_build_knn_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "rover_build_knn_map_ref": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "rover_linear_forward": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    "rover_mlp_chain_forward": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "rover_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
     "rover_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
@@ -378,6 +379,35 @@ class Engine:
         self._check(self.lib.rover_linear_forward(self._h, _ptr(x), max(x.stride(0), k), m, k, _ptr(weight), _ptr(bias), n,
                                                   self.ACTIVATIONS[activation], _ptr(out), out.stride(0), _stream()),
                     "rover_linear_forward")
+        return out
+
+    CHAIN_SHAPES = {2: (96, 64), 4: (256, 160, 128, 32)}        # widths the fused chain kernel is built for
+
+    def chain_fits(self, layers):
+        """True if ``layers`` (objects with .weight [n, k]) can run as one rover_mlp_chain_forward launch."""
+        lim = self.CHAIN_SHAPES.get(len(layers))
+        return lim is not None and all(l.weight.shape[0] <= m for l, m in zip(layers, lim)) and layers[0].weight.shape[1] > 0
+
+    def chain_forward(self, x, layers, out):
+        """out = layers[-1](... layers[0](x)) in one kernel; ``layers``: objects with .weight [n, k], .bias [n], .activation."""
+        m, k0 = x.shape
+        for t, name in ((x, "x"), (out, "out")):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+                raise RoverError(f"chain_forward: {name} must be a float32 GPU matrix with unit column stride")
+        n = len(layers)
+        k = k0
+        for l in layers:
+            self._chk(l.weight, (l.weight.shape[0], k), torch.float32, "weight")
+            self._chk(l.bias, (l.weight.shape[0],), torch.float32, "bias")
+            k = l.weight.shape[0]
+        if out.shape[0] != m or out.shape[1] != k:
+            raise RoverError(f"chain_forward: out must be [{m},{k}]")
+        w = (C.c_void_p * n)(*[_ptr(l.weight) for l in layers])
+        b = (C.c_void_p * n)(*[_ptr(l.bias) for l in layers])
+        widths = (C.c_int32 * n)(*[l.weight.shape[0] for l in layers])
+        acts = (C.c_int32 * n)(*[self.ACTIVATIONS[l.activation] for l in layers])
+        self._check(self.lib.rover_mlp_chain_forward(self._h, _ptr(x), x.stride(0), m, k0, n, w, b, widths, acts, _ptr(out), out.stride(0),
+                                                     _stream()), "rover_mlp_chain_forward")
         return out
 
     def set_option(self, name, value):

@@ -888,6 +888,28 @@ int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t
     return ROVER_OK;
 }
 
+int rover_mlp_chain_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers,
+                            const float* const* weights, const float* const* biases, const int32_t* widths, const int32_t* activations,
+                            float* y, int64_t y_stride, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!x || !y || !weights || !biases || !widths || !activations || M < 0 || K0 <= 0 || x_stride < K0 || (n_layers != 2 && n_layers != 4))
+        return fail(c, ROVER_E_INVALID, "mlp_chain_forward: bad arguments (M=%d K0=%d layers=%d)", M, K0, n_layers);
+    ChainArgs a{};
+    a.x = x; a.x_stride = x_stride; a.M = M; a.K0 = K0; a.n_layers = n_layers; a.y = y; a.y_stride = y_stride;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!weights[i] || widths[i] <= 0 || widths[i] > 256 || activations[i] < 0 || activations[i] > 4)
+            return fail(c, ROVER_E_INVALID, "mlp_chain_forward: layer %d: width %d activation %d", i, widths[i], activations[i]);
+        a.w[i] = weights[i]; a.b[i] = biases[i]; a.n[i] = widths[i]; a.act[i] = activations[i];
+    }
+    if (y_stride < a.n[n_layers - 1]) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: y_stride %lld < width %d", (long long)y_stride, a.n[n_layers - 1]);
+    if (M == 0) return ROVER_OK;
+    USE_DEVICE(c);
+    hipError_t e = launch_chain(a, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: layer widths outside the built tile shapes (<= 96 -> <= 64, or <= 256 -> <= 160 -> <= 128 -> <= 32)");
+    HIP_TRY(c, e);
+    return ROVER_OK;
+}
+
 int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
     USE_DEVICE(c);                                 // some options (re)allocate device workspace

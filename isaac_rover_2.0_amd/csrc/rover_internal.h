@@ -135,6 +135,17 @@ struct LinearArgs {
 };
 hipError_t launch_linear_act(const LinearArgs& a, hipStream_t s);
 
+// a chain of 2 or 4 layers in one kernel (rover_mlp.hip): y = L_n(... L_1(x)), L_i(v) = act_i(W_i v + b_i)
+struct ChainArgs {
+    const float* x; int64_t x_stride;      // [M, K0] rows at x_stride floats
+    int32_t M, K0, n_layers;
+    int32_t n[4];                          // output widths
+    const float* w[4]; const float* b[4];  // nn.Linear: weight [n_i][n_{i-1}] (row-major, K0 for the first), bias [n_i] or NULL
+    int32_t act[4];
+    float* y; int64_t y_stride;            // [M, n_last] rows at y_stride floats
+};
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
+
 hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                          uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s);
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);

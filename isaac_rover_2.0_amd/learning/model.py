@@ -6,8 +6,9 @@ Mirrors ``omniisaacgymenvs/learning/model.py``: ``Layer`` (:84-121, Linear + act
 ``cfg/trainSKRL/RoverPPOSKRL.yaml:7-9``), the results are concatenated with the proprioceptive values and fed to the
 MLP (256 → 160 → 128, yaml :3-5) with a Tanh head of 2 (actor) or a linear head of 1 (critic).
 
-Every ``Layer`` is one ``rover_linear_forward`` launch (f32 MFMA); the slices are read in place from ``obs_buf`` and
-the encoder outputs are written straight into the concat buffer, so there is no ``torch.cat``.  Training (skrl PPO,
+Large batches run each encoder and the MLP + head as ONE fused kernel each (``rover_mlp_chain_forward``, f32 MFMA, activations
+kept in registers between the layers); otherwise every ``Layer`` is one ``rover_linear_forward`` launch.  The slices are read in
+place from ``obs_buf`` and the encoder outputs are written straight into the concat buffer, so there is no ``torch.cat``.  Training (skrl PPO,
 ``train.py``) stays out of scope: these classes hold plain tensors, initialised like ``nn.Linear``, and can load a
 ``state_dict`` saved from the reference's modules (same parameter names).
 """
@@ -58,19 +59,29 @@ class HeightmapNet:
             b = self._bufs[key] = torch.empty(rows, cols, device=self.device)
         return b
 
-    def compute(self, states):
-        """model.py:185-195 / :231-241.  ``states`` [E, num_observations] float32 (may be the task's obs_buf itself)."""
+    def compute(self, states, fused=None):
+        """model.py:185-195 / :231-241.  ``states`` [E, num_observations] float32 (may be the task's obs_buf itself).
+        ``fused``: run each encoder and the MLP + head as ONE kernel each (``rover_mlp_chain_forward``: activations stay in
+        registers) — default for batches of >= 16 384 rows when the layer widths fit the built tile shapes; otherwise one
+        ``rover_linear_forward`` launch per layer."""
         e = states.shape[0]
         p, ns, nd = self.num_proprioception, self.num_sparse, self.num_dense
         ef = self.encoder0[-1].weight.shape[0]
         cat = self._buf("cat", e, p + 2 * ef)
         cat[:, 0:p] = states[:, 0:p]
+        if fused is None:
+            fused = e >= 16384
         for enc, lo, n, col in ((self.encoder0, p, ns, p), (self.encoder1, p + ns, nd, p + ef)):
             x = states[:, lo:lo + n]
+            if fused and n > 0 and self.engine.chain_fits(enc):
+                self.engine.chain_forward(x, enc, cat[:, col:col + ef])
+                continue
             for li, layer in enumerate(enc):
                 last = li == len(enc) - 1
                 out = cat[:, col:col + ef] if last else self._buf(("enc", col, li), e, layer.weight.shape[0])
                 x = self.engine.linear_forward(x, layer.weight, layer.bias, layer.activation, out)
+        if fused and self.engine.chain_fits(self.network):
+            return self.engine.chain_forward(cat, self.network, self._buf(("mlp", len(self.network) - 1), e, self.network[-1].weight.shape[0]))
         x = cat
         for li, layer in enumerate(self.network):
             x = self.engine.linear_forward(x, layer.weight, layer.bias, layer.activation, self._buf(("mlp", li), e, layer.weight.shape[0]))

@@ -740,11 +740,12 @@ def test_policy_forward_matches_torch_fp32(num_envs, ns, nd):
     try:
         for outputs, head in ((2, "tanh"), (1, None)):
             net = HeightmapNet(eng, w, ns, nd, outputs, head, device="cuda:0", seed=outputs)
-            got = net.compute(states)
             want = _torch_net_reference(net, states)
-            torch.cuda.synchronize()
-            assert got.shape == (num_envs, outputs)
-            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-5)
+            for fused in (False, True):        # one launch per layer / one fused chain kernel per encoder and for MLP + head
+                got = net.compute(states, fused=fused)
+                torch.cuda.synchronize()
+                assert got.shape == (num_envs, outputs)
+                np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=f"fused={fused}")
     finally:
         torch.backends.cuda.matmul.allow_tf32 = prev
     sd = net.state_dict()

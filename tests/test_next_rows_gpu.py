@@ -180,7 +180,15 @@ def test_policy_forward_matches_reference_modules(name):
     x = torch.from_numpy(fx["states"].astype(np.float32)).cuda()
     actor = HeightmapNet(eng, nobs, ns, nd, 2, "tanh")
     _load(actor, fx, "actor")
-    out = actor.compute(x)
+    # the fused chain kernels (one launch per encoder, one for MLP + head) against the same reference outputs
+    fused = actor.compute(x, fused=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(fused.cpu().numpy(), fx["out_actor"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    p0 = nobs - ns - nd
+    cat_f = actor._bufs["cat"].cpu().numpy()
+    np.testing.assert_allclose(cat_f[:, p0:p0 + 60], fx["out_actor_encoder0"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    np.testing.assert_allclose(cat_f[:, p0 + 60:p0 + 120], fx["out_actor_encoder1"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    out = actor.compute(x, fused=False)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), fx["out_actor"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
     cat = actor._bufs["cat"].cpu().numpy()
@@ -192,7 +200,8 @@ def test_policy_forward_matches_reference_modules(name):
     if "out_critic" in fx:
         critic = HeightmapNet(eng, nobs, ns, nd, 1, None)
         _load(critic, fx, "critic")
-        v = critic.compute(x)
-        torch.cuda.synchronize()
-        np.testing.assert_allclose(v.cpu().numpy(), fx["out_critic"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+        for fused_mode in (True, False):
+            v = critic.compute(x, fused=fused_mode)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(v.cpu().numpy(), fx["out_critic"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
     eng.close()
