@@ -67,7 +67,6 @@ struct rover_ctx {
     int last_variant = 1;
     bool sorted_valid = false;
     uint32_t run = 0;                   // option "raycast_run": 0 = auto (effective_run)
-    uint32_t cull_waves = 0;            // option "cull_waves": kernel build of the culled ray cast (0, 6, 7, 8)
     uint32_t early_out = 1;             // option "raycast_early_out": conservative whole-pair rejection (bit-identical results)
     int32_t cell_rcp = 0;               // option "cell_index_mode": 0 cpu_div (x / 0.1), 1 cuda_rcp (x * (1 / 0.1))
     uint64_t workspace_bytes = 0;
@@ -479,7 +478,6 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1]; a.qrow0 = c->cull_qrow[0]; a.qrow1 = c->cull_qrow[1];
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
-    a.waves = c->cull_waves;
     a.out = c->d_dist_out;
     a.queue = c->d_cull_queue; a.fill = c->d_cull_fill;
     return a;
@@ -939,11 +937,6 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->cell_rcp = (int32_t)value;
         c->hf.rcp = c->cell_rcp;
         c->rays_valid = false;
-        return ROVER_OK;
-    }
-    if (!strcmp(name, "cull_waves")) {
-        if (value != 0 && (value < 6 || value > 8)) return fail(c, ROVER_E_INVALID, "cull_waves must be 0, 6, 7 or 8");
-        c->cull_waves = (uint32_t)value;
         return ROVER_OK;
     }
     if (!strcmp(name, "raycast_run")) {

@@ -260,8 +260,7 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
         uint32_t *__restrict__ fill
 #define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, nb8, queue, fill
 
-template <int WPE>
-__device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
+__global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     // XCD-aware order, as raycast_binned_kernel: each XCD walks one contiguous eighth of the sorted rays — here that also
     // keeps the ctab records an XCD touches (a band of the map) inside its own L2
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
@@ -396,11 +395,6 @@ __device__ __forceinline__ void cull_scan_body(CULL_SCAN_ARGS) {
     if (lane == 0u) fill[wave] = cused;
 }
 
-__global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) { cull_scan_body<0>(CULL_SCAN_PASS); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) cull_scan_w6_kernel(CULL_SCAN_ARGS) { cull_scan_body<6>(CULL_SCAN_PASS); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) cull_scan_w7_kernel(CULL_SCAN_ARGS) { cull_scan_body<7>(CULL_SCAN_PASS); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) cull_scan_w8_kernel(CULL_SCAN_ARGS) { cull_scan_body<8>(CULL_SCAN_PASS); }
-
 // ---------------------------------------------------------------------------------------------------
 // PHASE 2 — cull_exact_kernel.  One workgroup per run, one thread per queue entry (64-entry slices dealt to its 4 waves):
 // the exact arithmetic of rover_raymath.h (the code every other ray-cast kernel runs) on the entry's pair of triangles,
@@ -482,8 +476,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const uint32_t n_waves = blocks_for(a.n_sorted, a.run);
     a.n_blocks = blocks_for(n_waves, 4);
     a.nb8 = blocks_for(a.n_blocks, 8);
-    auto kern = a.waves == 6 ? cull_scan_w6_kernel : a.waves == 7 ? cull_scan_w7_kernel : a.waves == 8 ? cull_scan_w8_kernel : cull_scan_kernel;
-    hipLaunchKernelGGL(kern, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
+    hipLaunchKernelGGL(cull_scan_kernel, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
                        a.kp0, a.kp1, a.run, a.n_blocks, a.nb8, a.queue, a.fill);
     if (!getenv("ROVER_CULL_SKIP_EXACT"))          // diagnostic: time phase 1 alone (no results)

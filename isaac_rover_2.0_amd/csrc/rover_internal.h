@@ -62,7 +62,6 @@ struct CullArgs {
     const uint4 *qrow0, *qrow1;  // [cell] {q16, 0, 0, 0}: the cell's normal cone (min |N_z| / |N| as a 16-bit fraction)
     const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
     uint32_t kp0, kp1, run, n_blocks, nb8;
-    uint32_t waves;              // option cull_waves: 0 or 6..8 (register budget of the kernel build, A/B)
     float* out;                  // [E*R8] distances
     uint2* queue;                // candidate queue: one region of run x 128 8-byte entries per run
     uint32_t* fill;              // entries written per run

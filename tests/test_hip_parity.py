@@ -225,7 +225,7 @@ def test_early_out_changes_no_bit(precision, k):
 def test_culled_raycast_changes_no_bit(k, cells):
     """The culled kernel (variant 3) against the binned kernel with its early out off, on a batch with steep tilts, rays
     parallel to facets (exact axis-aligned poses on the vertex lattice) and huge / NaN poses: every output identical, for
-    every register-budget build of the kernel."""
+    several run lengths."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     n = 3000
@@ -246,13 +246,14 @@ def test_culled_raycast_changes_no_bit(k, cells):
     eng.set_option("raycast_early_out", 0)
     ref = hip_step(eng, st)
     eng.close()
-    for waves in (0, 6, 7, 8):
-        eng = make_engine(scene, distn, n, variant=3)
-        eng.set_option("cull_waves", waves)
+    for run in (0, 7, 64):                           # auto / odd / longest runs of sorted rays per wave
+        eng = make_engine(scene, distn, n, variant=3, run=run or None)
         got = hip_step(eng, st)
+        got2 = hip_step(eng, st)                     # and again on the same engine (queue regions are reused)
         eng.close()
         for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} waves={waves}")
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run}")
+            np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} run={run} (second step)")
     assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 

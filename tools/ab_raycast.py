@@ -14,10 +14,8 @@ ARMS = [dict(raycast_variant=2, raycast_early_out=1, raycast_run=0, ENV_ROVER_CU
         dict(raycast_variant=1, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT=None),
         dict(raycast_variant=3, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT=None),
         dict(raycast_variant=3, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT="1"),      # phase 1 alone (diagnostic, no results)
-        dict(raycast_variant=3, raycast_run=8, ENV_ROVER_CULL_SKIP_EXACT=None),
         dict(raycast_variant=3, raycast_run=16, ENV_ROVER_CULL_SKIP_EXACT=None),
         dict(raycast_variant=3, raycast_run=32, ENV_ROVER_CULL_SKIP_EXACT=None),
-        dict(raycast_variant=3, raycast_run=64, ENV_ROVER_CULL_SKIP_EXACT=None),
         ]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
