@@ -29,7 +29,6 @@ struct rover_ctx {
     uint4* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast (worst case: 128 entries per ray)
-    uint32_t* d_cull_fill = nullptr;
     uint64_t cull_entries = 0;
     uint32_t cull_run = 0;              // run length the queue was sized for
     // distribution
@@ -194,10 +193,9 @@ static int alloc_cull_queue(rover_ctx* c) {
     uint64_t n_runs = 0;
     const uint64_t entries = cull_queue_entries(valid_rays(c), run, &n_runs);
     if (c->d_cull_queue && entries <= c->cull_entries && run == c->cull_run) return ROVER_OK;
-    dfree(c->d_cull_queue); dfree(c->d_cull_fill);
+    dfree(c->d_cull_queue);
     c->cull_entries = 0;
     HIP_TRY(c, hipMalloc((void**)&c->d_cull_queue, entries * sizeof(uint2)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_cull_fill, n_runs * sizeof(uint32_t)));
     c->cull_entries = entries; c->cull_run = run;
     return ROVER_OK;
 }
@@ -270,7 +268,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
-    dfree(c->d_cull_queue); dfree(c->d_cull_fill);
+    dfree(c->d_cull_queue);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -479,7 +477,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.out = c->d_dist_out;
-    a.queue = c->d_cull_queue; a.fill = c->d_cull_fill;
+    a.queue = c->d_cull_queue;
     return a;
 }
 

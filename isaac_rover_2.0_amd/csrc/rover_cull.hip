@@ -5,10 +5,11 @@
 //
 // The reference evaluates all K = 200 triangles of a ray's cell and takes the min of k-or-11.0; a ray meets 1-3 of them.
 // raycast_binned_kernel (rover_kernels.hip) evaluates them all too (134 VALU instructions per ray).  This kernel splits the
-// work: PHASE 1 proves, per (ray, triangle), with 19 packed instructions per pair of triangles, that ray_casting.py:59
+// work: PHASE 1 proves, per (ray, triangle), with 11-15 packed instructions per pair of triangles, that ray_casting.py:59
 // rejects the triangle (it then contributes the 11.0 sentinel and nothing else); PHASE 2 runs the exact arithmetic of
 // rover_raymath.h — the same code the other kernels run — on the few (ray, lane-pair) candidates phase 1 could not
-// reject, 64 candidates of different rays side by side.  Results are bit-identical to raycast_binned_kernel /
+// reject, 64 candidates of different rays side by side.  One kernel (cull_scan_kernel): a wave scans its run of 64 sorted
+// rays, then finishes it.  Results are bit-identical to raycast_binned_kernel /
 // raycast_kernel (tests/test_hip_parity.py::test_raycast_variants_bit_identical, tools/soak_exact.py).
 //
 // ---- why a culled triangle is rejected by the reference (the proof behind phase 1) -----------------------------------
@@ -244,12 +245,63 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 }
 
 // ---------------------------------------------------------------------------------------------------
+// PHASE 2 — cull_exact: the wave that scanned a run finishes it.  One lane per queue entry, 64 entries at a time: the exact
+// arithmetic of rover_raymath.h (the code every other ray-cast kernel runs) on the entry's pair of triangles, then the min over
+// the entries of a ray: a segmented wave reduction (a ray's entries are contiguous), one LDS atomicMin per ray and slice on an
+// ordered-u32 key, and at the end one plain store per ray of the run — the 11.0 sentinel where a ray had no candidate at all
+// (a culled triangle contributes exactly that, ray_casting.py:27,59).  The phase is a chain of dependent gathers (entry ->
+// triangle records, ray record) that leaves the VALU idle; it runs AFTER the wave's scan loop, when the 28 cell registers are
+// dead (61 VGPRs, still 8 waves per SIMD), so on every SIMD the scan phases of some waves fill the gaps of the exact
+// phases of others — as a second kernel (or on a second stream) the two phases only ran one after the other.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
+                                           const uint2* qw, uint32_t n, uint32_t gid /* per lane: ray id of run position `lane` */,
+                                           uint32_t lane, uint32_t* bk) {
+    for (uint32_t base = 0; base < n; base += 64u) {                // wave-uniform
+        const uint32_t e = base + lane;
+        const bool live = e < n;
+        const uint2 en = qw[live ? e : base];
+        const uint32_t map = en.x >> 31, pos = en.y >> 26;
+        const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
+        const RawTri* rt = map ? rtab1 : rtab0;
+        const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
+        const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
+        const float4* rp = reinterpret_cast<const float4*>(rays + g);
+        const float4 ra = rp[0], rb = rp[1];
+        const float qnan = __builtin_nanf("");
+        f2 v[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
+            v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
+        }
+        // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
+        v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
+        CellRegs<1> t;
+        set_pair(t, 0, v);
+        const uint64_t none[1][2] = {{0, 0}};
+        const float best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
+                                         f2{rb.z, rb.z}, none, 0u);
+        // segmented min over the lanes with the same ray (contiguous); dead lanes carry a position no live lane has
+        uint32_t k = live ? fkey(best) : 0xffffffffu;
+        const uint32_t seg = live ? pos : 64u + lane;
+#pragma unroll
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t ok = (uint32_t)__shfl_down((int)k, off, 64), os = (uint32_t)__shfl_down((int)seg, off, 64);
+            if (lane + off < 64u && os == seg) k = ok < k ? ok : k;
+        }
+        const uint32_t ps = (uint32_t)__shfl_up((int)seg, 1, 64);
+        if (live && (lane == 0u || ps != seg)) atomicMin(bk + pos, k);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // PHASE 1 — cull_scan_kernel.  One wave walks a run of <= 64 sorted rays.  Per (map, cell) bin it gathers the bin's 200
 // bounding-sphere / normal records (4 per lane, as 2 packed pairs); per ray it runs tests (A), (B) on all of them and
 // appends one 8-byte entry per lane-pair that holds a candidate to the wave's own region of the global candidate queue:
 //     entry = { id0 | map << 31,  id1 | position in the run << 26 }          (CULL_NOID = empty slot next to a candidate)
 // Region w = [w * run * 128, ...): a ray adds at most 128 entries, so it cannot overflow and nothing is allocated on the
-// device (one returning atomic per wave on a shared counter cost 2.7 ms); fill[w] = entries written.
+// device (one returning atomic per wave on a shared counter cost 2.7 ms).
 // Nothing here is heavy in registers or LDS, so 7-8 waves per SIMD hide the latencies of the id rows (HBM, streamed
 // through LDS CULL_RING bins ahead) and of the record gathers (L2).
 // ---------------------------------------------------------------------------------------------------
@@ -257,8 +309,8 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
         const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint2 *__restrict__ queue,                                      \
-        uint32_t *__restrict__ fill
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, nb8, queue, fill
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, nb8, queue, rtab0, rtab1, out
 
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     // XCD-aware order, as raycast_binned_kernel: each XCD walks one contiguous eighth of the sorted rays — here that also
@@ -392,68 +444,18 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             }
         }
     }
-    if (lane == 0u) fill[wave] = cused;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// PHASE 2 — cull_exact_kernel.  One workgroup per run, one thread per queue entry (64-entry slices dealt to its 4 waves):
-// the exact arithmetic of rover_raymath.h (the code every other ray-cast kernel runs) on the entry's pair of triangles,
-// then the min over the entries of a ray: a segmented wave reduction (a ray's entries are contiguous), one LDS atomicMin per
-// (wave, ray) on an ordered-u32 key, and at the end one plain store per ray of the run — the 11.0 sentinel where a ray
-// had no candidate at all (a culled triangle contributes exactly that, ray_casting.py:27,59).  No global atomics, and the
-// output buffer holds plain floats like the other kernels'.  Every lane is independent: the dependent gathers (sorted id ->
-// ray record, triangle records) overlap across the whole grid.
-// ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) cull_exact_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
-                                                         const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
-                                                         const uint2* __restrict__ queue, const uint32_t* __restrict__ fill,
-                                                         uint32_t run, uint32_t n_sorted, float* __restrict__ out) {
-    __shared__ uint32_t s_best[CULL_RUNMAX];
-    const uint32_t wv = blockIdx.x;                                // the run (= phase-1 wave) this workgroup finishes
-    const uint32_t n = fill[wv];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint2* qw = queue + (size_t)wv * run * 128u;
-    const uint32_t i0 = wv * run;
-    if (threadIdx.x < CULL_RUNMAX) s_best[threadIdx.x] = fkey(RAY_MISS);
-    __syncthreads();
-    for (uint32_t base = (threadIdx.x >> 6) * 64u; base < n; base += 256u) {        // wave-uniform
-        const uint32_t e = base + lane;
-        const bool live = e < n;
-        const uint2 en = qw[live ? e : base];
-        const uint32_t map = en.x >> 31, pos = en.y >> 26;
-        const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
-        const RawTri* rt = map ? rtab1 : rtab0;
-        const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
-        const uint32_t gid = sorted[i0 + pos];
-        const float4* rp = reinterpret_cast<const float4*>(rays + gid);
-        const float4 ra = rp[0], rb = rp[1];
-        const float qnan = __builtin_nanf("");
-        f2 v[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
-            v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
-        }
-        // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
-        v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
-        CellRegs<1> t;
-        set_pair(t, 0, v);
-        const uint64_t none[1][2] = {{0, 0}};
-        const float best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
-                                         f2{rb.z, rb.z}, none, 0u);
-        // segmented min over the lanes with the same ray (contiguous); dead lanes carry a position no live lane has
-        uint32_t k = live ? fkey(best) : 0xffffffffu;
-        const uint32_t seg = live ? pos : 64u + lane;
-#pragma unroll
-        for (uint32_t off = 1; off < 64u; off <<= 1) {
-            const uint32_t ok = (uint32_t)__shfl_down((int)k, off, 64), os = (uint32_t)__shfl_down((int)seg, off, 64);
-            if (lane + off < 64u && os == seg) k = ok < k ? ok : k;
-        }
-        const uint32_t ps = (uint32_t)__shfl_up((int)seg, 1, 64);
-        if (live && (lane == 0u || ps != seg)) atomicMin(s_best + pos, k);
-    }
-    __syncthreads();
-    if (threadIdx.x < run && i0 + threadIdx.x < n_sorted) out[sorted[i0 + threadIdx.x]] = funkey(s_best[threadIdx.x]);
+    // PHASE 2 on the wave's own entries.  They were stored to global memory by this wave and are read back by this wave:
+    // waiting for the stores' acknowledgement (they write through to L2) is all the ordering that takes — no other wave
+    // touches this queue region, and the vector L1 cannot hold a stale line of it (regions are 128-byte aligned, nothing
+    // read them in this launch).  An agent-scope fence here writes back the whole L2 of the XCD: 3.7 ms instead of 0.6.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t* bk = reinterpret_cast<uint32_t*>(&s_ids[w][0][0]);   // the id ring is dead: 64 result slots of the run
+    wave_lds_sync();
+    bk[lane] = fkey(RAY_MISS);
+    wave_lds_sync();
+    cull_exact(rays, rtab0, rtab1, qw, cused, gid, lane, bk);
+    wave_lds_sync();
+    if (lane < n_run) out[gid] = funkey(bk[lane]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -478,11 +480,8 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     a.nb8 = blocks_for(a.n_blocks, 8);
     hipLaunchKernelGGL(cull_scan_kernel, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
-                       a.kp0, a.kp1, a.run, a.n_blocks, a.nb8, a.queue, a.fill);
-    if (!getenv("ROVER_CULL_SKIP_EXACT"))          // diagnostic: time phase 1 alone (no results)
-        hipLaunchKernelGGL(cull_exact_kernel, dim3(n_waves), dim3(256), 0, s, a.rays, a.sorted,
-                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.queue, a.fill, a.run,
-                           a.n_sorted, a.out);
+                       a.kp0, a.kp1, a.run, a.n_blocks, a.nb8, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
+                       reinterpret_cast<const RawTri*>(a.rtab1), a.out);
     return hipGetLastError();
 }
 

@@ -64,7 +64,6 @@ struct CullArgs {
     uint32_t kp0, kp1, run, n_blocks, nb8;
     float* out;                  // [E*R8] distances
     uint2* queue;                // candidate queue: one region of run x 128 8-byte entries per run
-    uint32_t* fill;              // entries written per run
 };
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t run, uint64_t* n_runs);
 

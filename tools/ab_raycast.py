@@ -10,12 +10,12 @@ from isaac_rover_amd import _lib, synth
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 # keys starting with ENV_ set / clear an environment variable the launcher reads (experiments only)
-ARMS = [dict(raycast_variant=2, raycast_early_out=1, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT=None),
-        dict(raycast_variant=1, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT=None),
-        dict(raycast_variant=3, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT=None),
-        dict(raycast_variant=3, raycast_run=0, ENV_ROVER_CULL_SKIP_EXACT="1"),      # phase 1 alone (diagnostic, no results)
-        dict(raycast_variant=3, raycast_run=16, ENV_ROVER_CULL_SKIP_EXACT=None),
-        dict(raycast_variant=3, raycast_run=32, ENV_ROVER_CULL_SKIP_EXACT=None),
+ARMS = [dict(raycast_variant=2, raycast_early_out=1, raycast_run=0),
+        dict(raycast_variant=1, raycast_run=0),
+        dict(raycast_variant=3, raycast_run=0),
+        dict(raycast_variant=3, raycast_run=16),
+        dict(raycast_variant=3, raycast_run=32),
+        dict(raycast_variant=3, raycast_run=64),
         ]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
