@@ -284,7 +284,7 @@ def roofline(args, E, n_rays, prof, info):
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     else:
         head = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": valu_obj["unit"], "frac": frac}
-    head.update({"kernel": {3: "cull_scan_kernel+cull_exact_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
+    head.update({"kernel": {3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
                  "reuse_factor": (algo / traffic) if traffic else None,

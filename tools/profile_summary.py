@@ -44,7 +44,7 @@ if pmc and a.workload_key:
     # the ray-cast stage that ran in these passes: the binned f32 / binned fp16 / env-order kernel, or the culled ray cast's
     # two kernels (cull_scan + cull_exact: counters summed per step, bench.py times the pair with one HIP-event bracket)
     cull = [k for k in pmc if "cull_scan" in k or "cull_exact" in k]
-    cands = [k for k in pmc if "raycast" in k and "SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k]]
+    cands = [k for k in pmc if ("raycast" in k or "cull_scan" in k) and "SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k]]
     if len(cull) == 2 and all("SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k] for k in cull):
         name = "+".join(sorted(k.split("(")[0].replace("rover::", "") for k in cull))
         pmc[name] = {cn: {"n": min(pmc[k][cn]["n"] for k in cull), "mean": sum(pmc[k][cn]["mean"] for k in cull)}
