@@ -94,3 +94,40 @@ def test_obs_row_stride_and_create_destroy_loop():
         e2, _ = _engine(64)
         e2.close()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_mlp_chain_forward_shapes_and_errors():
+    """rover_mlp_chain_forward: layer widths outside the built tile shapes, wrong depths and mismatched outputs are refused;
+    odd sizes inside them (K0 not a multiple of 32, M not a multiple of 128, narrow layers) match PyTorch."""
+    import torch.nn.functional as F
+    from isaac_rover_amd import _lib
+    from isaac_rover_amd.learning.model import Layer
+    eng = _lib.Engine(8, device=0)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(301, 45, generator=g) * 2 - 1).cuda()
+    ok2 = [Layer(45, 70, "leakyrelu", generator=g), Layer(70, 33, "tanh", generator=g)]
+    out = torch.empty(301, 33, device="cuda")
+    eng.chain_forward(x, ok2, out)
+    want = torch.tanh(F.linear(F.leaky_relu(F.linear(x, ok2[0].weight, ok2[0].bias)), ok2[1].weight, ok2[1].bias))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    ok4 = [Layer(45, 200, "elu", generator=g), Layer(200, 130, "relu", generator=g), Layer(130, 100, "leakyrelu", generator=g),
+           Layer(100, 3, None, generator=g)]
+    out4 = torch.empty(301, 3, device="cuda")
+    eng.chain_forward(x, ok4, out4)
+    h = F.elu(F.linear(x, ok4[0].weight, ok4[0].bias))
+    h = F.relu(F.linear(h, ok4[1].weight, ok4[1].bias))
+    h = F.leaky_relu(F.linear(h, ok4[2].weight, ok4[2].bias))
+    want4 = F.linear(h, ok4[3].weight, ok4[3].bias)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out4.cpu().numpy(), want4.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    assert eng.chain_fits(ok2) and eng.chain_fits(ok4)
+    wide = [Layer(45, 120, "relu", generator=g), Layer(120, 33, "relu", generator=g)]          # 120 > 96: no built shape
+    assert not eng.chain_fits(wide)
+    with pytest.raises(_lib.RoverError, match="tile shapes"):
+        eng.chain_forward(x, wide, out)
+    with pytest.raises(_lib.RoverError, match="layers"):
+        eng.chain_forward(x, ok4[:3], torch.empty(301, 100, device="cuda"))                   # 3 layers: not a built depth
+    with pytest.raises(_lib.RoverError, match="out must be"):
+        eng.chain_forward(x, ok2, torch.empty(301, 34, device="cuda"))
+    eng.close()
