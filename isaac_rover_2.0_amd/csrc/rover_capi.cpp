@@ -30,6 +30,7 @@ struct rover_ctx {
     uint64_t cull_bytes[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast (worst case: 128 entries per ray)
     uint64_t cull_entries = 0;
+    bool cull_queue_failed = false;     // the worst-case queue does not fit (huge E x rays): the binned kernel runs instead
     uint32_t cull_run = 0;              // run length the queue was sized for
     // distribution
     double* d_dist = nullptr;       // [P][3]
@@ -148,7 +149,7 @@ static int effective_variant(const rover_ctx* c) {
     if (c->variant == 1 || !v2_ok) return 1;
     if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
     // variant 3 (culled): f32 arithmetic only — the as-shipped fp16 mode keeps the binned kernel
-    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1] && c->precision != 2;
+    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1] && c->precision != 2 && !c->cull_queue_failed;
     if (c->variant == 2 || !v3_ok) return 2;
     return 3;
 }
@@ -188,6 +189,7 @@ static int alloc_bins(rover_ctx* c) {
 
 // candidate queue of the culled ray cast, sized for the worst case of the run length in force
 static int alloc_cull_queue(rover_ctx* c) {
+    c->cull_queue_failed = false;
     if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) != 3) return ROVER_OK;
     const uint32_t run = effective_run(c);
     uint64_t n_runs = 0;
@@ -195,7 +197,15 @@ static int alloc_cull_queue(rover_ctx* c) {
     if (c->d_cull_queue && entries <= c->cull_entries && run == c->cull_run) return ROVER_OK;
     dfree(c->d_cull_queue);
     c->cull_entries = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_cull_queue, entries * sizeof(uint2)));
+    // 1 KB per ray (a ray can add 128 entries): 4.2 GB at 65 536 envs x 63 rays.  Beyond 64 GB, or when the device cannot
+    // give it, the step runs the binned kernel (variant 2, same results) instead of failing.
+    const uint64_t bytes = entries * sizeof(uint2);
+    if (bytes > (64ull << 30) || hipMalloc((void**)&c->d_cull_queue, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        c->d_cull_queue = nullptr;
+        c->cull_queue_failed = true;
+        return ROVER_OK;
+    }
     c->cull_entries = entries; c->cull_run = run;
     return ROVER_OK;
 }
