@@ -295,6 +295,32 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
     }
 }
 
+// Packed f32 operations whose scalar operand is ONE float of an aligned SGPR pair, splat to both halves by op_sel.  The
+// ray record arrives by s_load_dwordx8 as four such pairs; left to the compiler every high-half splat (sy, dy) becomes two s_mov
+// building a new pair — 12 scalar instructions per ray in a loop that is bound by its total instruction issue.
+typedef unsigned long long sgpr2;        // two floats in an aligned SGPR pair
+__device__ __forceinline__ sgpr2 sgpr_pair(float lo, float hi) {
+    return (sgpr2)__float_as_uint(lo) | ((sgpr2)__float_as_uint(hi) << 32);
+}
+template <int HI> __device__ __forceinline__ f2 pk_rsub(sgpr2 s, f2 v) {        // {s, s} - v
+    f2 r;
+    if (HI) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(s), "v"(v));
+    else    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(s), "v"(v));
+    return r;
+}
+template <int HI> __device__ __forceinline__ f2 pk_mul_s(f2 v, sgpr2 s) {        // v * {s, s}
+    f2 r;
+    if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(v), "s"(s));
+    else    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "s"(s));
+    return r;
+}
+template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) {  // a * {s, s} + c
+    f2 r;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "s"(s), "v"(c));
+    else    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(s), "v"(c));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // PHASE 1 — cull_scan_kernel.  One wave walks a run of <= 64 sorted rays.  Per (map, cell) bin it gathers the bin's 200
 // bounding-sphere / normal records (4 per lane, as 2 packed pairs); per ray it runs tests (A), (B) on all of them and
@@ -402,16 +428,15 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
             const float4 ra = nxa, rb = nxb;
             load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
-            const f2 sx = {ra.x, ra.x}, sy = {ra.y, ra.y}, sz = {ra.z, ra.z};
-            const f2 dx = {rb.x, rb.x}, dy = {rb.y, rb.y}, dz = {rb.z, rb.z};
+            const sgpr2 sxy = sgpr_pair(ra.x, ra.y), szc = sgpr_pair(ra.z, ra.w), dxy = sgpr_pair(rb.x, rb.y), dzf = sgpr_pair(rb.z, rb.w);
             uint64_t any[2];
             // the ray's cone bound (prep_rays_kernel, flags bits 16..31) against the cell's: (B) holds for every triangle
             const bool cone = q16 >= (__float_as_uint(rb.w) >> 16);
             if (cone) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
-                    f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
+                    const f2 hx = pk_rsub<0>(sxy, t.mx[p]), hy = pk_rsub<1>(sxy, t.my[p]), hz = pk_rsub<0>(szc, t.mz[p]);
+                    const f2 hd = pk_fma_s<0>(hz, dzf, pk_fma_s<1>(hy, dxy, pk_mul_s<0>(hx, dxy)));
                     f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
                     const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));             // (A): 0.995 |h|^2 - (h.d)^2 > r2
                     any[p] = ~(__builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y));
@@ -419,11 +444,11 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             } else {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const f2 hx = sx - t.mx[p], hy = sy - t.my[p], hz = sz - t.mz[p];
-                    f2 hd = hx * dx; hd = fma2(hy, dy, hd); hd = fma2(hz, dz, hd);
+                    const f2 hx = pk_rsub<0>(sxy, t.mx[p]), hy = pk_rsub<1>(sxy, t.my[p]), hz = pk_rsub<0>(szc, t.mz[p]);
+                    const f2 hd = pk_fma_s<0>(hz, dzf, pk_fma_s<1>(hy, dxy, pk_mul_s<0>(hx, dxy)));
                     f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
                     const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));             // (A): 0.995 |h|^2 - (h.d)^2 > r2
-                    f2 Dn = t.nx[p] * dx; Dn = fma2(t.ny[p], dy, Dn); Dn = fma2(t.nz[p], dz, Dn);
+                    const f2 Dn = pk_fma_s<0>(t.nz[p], dzf, pk_fma_s<1>(t.ny[p], dxy, pk_mul_s<0>(t.nx[p], dxy)));
                     const f2 B = Dn * Dn;                                               // (B): (n.d)^2 > tau^2 |n|^2 = r2
                     // one ballot per compare (each stays a v_cmp writing an SGPR pair); NaN compares false = stays a candidate
                     const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > t.r2[p].x);
