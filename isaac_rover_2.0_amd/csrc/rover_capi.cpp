@@ -482,6 +482,7 @@ static int check_ready(rover_ctx* c) {
 static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     CullArgs a{};
     a.rays = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
+    a.n_terrain = (uint32_t)c->cfg.num_envs * (uint32_t)c->P;
     a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1]; a.ctab0 = c->cull_ctab[0]; a.ctab1 = c->cull_ctab[1];
     a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1]; a.qrow0 = c->cull_qrow[0]; a.qrow1 = c->cull_qrow[1];
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;

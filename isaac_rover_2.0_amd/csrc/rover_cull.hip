@@ -334,15 +334,19 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
-        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t nb8, uint2 *__restrict__ queue,                                      \
+        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint2 *__restrict__ queue,                                      \
         const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, nb8, queue, rtab0, rtab1, out
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, queue, rtab0, rtab1, out
 
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
-    // XCD-aware order, as raycast_binned_kernel: each XCD walks one contiguous eighth of the sorted rays — here that also
-    // keeps the ctab records an XCD touches (a band of the map) inside its own L2
-    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
-    if (lb >= n_blocks) return;
+    // XCD-aware order (blocks b, b + 8, ... run on one XCD): each XCD walks one contiguous eighth of the TERRAIN blocks
+    // [0, split) and then one contiguous eighth of the ROCKS blocks [split, n_blocks) — contiguous so that the ctab / rtab records
+    // it touches (a band of the map) stay in its own L2, an eighth of EACH map because a terrain ray costs about a third more
+    // than a rock ray (8 candidate pairs against 0.7): eighths of the whole sorted list left the rocks' XCDs idle at the end.
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    uint32_t lb;
+    if (j < t8) { lb = x * t8 + j; if (lb >= split) return; }
+    else { lb = split + x * r8 + (j - t8); if (lb >= n_blocks) return; }
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
     const uint32_t i0 = wave * run;
@@ -502,10 +506,13 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     if (a.run == 0) a.run = 1;
     const uint32_t n_waves = blocks_for(a.n_sorted, a.run);
     a.n_blocks = blocks_for(n_waves, 4);
-    a.nb8 = blocks_for(a.n_blocks, 8);
-    hipLaunchKernelGGL(cull_scan_kernel, dim3(a.nb8 * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
+    // the sorted list is all terrain rays, then all rock rays: blocks [0, split) are (all but one mixed block) terrain
+    uint32_t split = blocks_for(blocks_for(a.n_terrain, a.run), 4);
+    if (split > a.n_blocks) split = a.n_blocks;
+    const uint32_t t8 = blocks_for(split, 8), r8 = blocks_for(a.n_blocks - split, 8);
+    hipLaunchKernelGGL(cull_scan_kernel, dim3((t8 + r8) * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
-                       a.kp0, a.kp1, a.run, a.n_blocks, a.nb8, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
+                       a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
                        reinterpret_cast<const RawTri*>(a.rtab1), a.out);
     return hipGetLastError();
 }

@@ -57,11 +57,12 @@ struct CullArgs {
     const RayRec* rays;
     const uint32_t* sorted;      // ray slots sorted by (map, cell)
     uint32_t n_sorted;
+    uint32_t n_terrain;          // the first n_terrain sorted rays are terrain rays (bins are (map, cell): terrain first)
     const int32_t *idx0, *idx1;  // [cell][K8/4][4] triangle ids of the cell (-1 = empty slot)
     const uint4 *ctab0, *ctab1;  // [T] 16 B: bounding-sphere centre + scaled unit normal per triangle (phase 1)
     const uint4 *qrow0, *qrow1;  // [cell] {q16, 0, 0, 0}: the cell's normal cone (min |N_z| / |N| as a 16-bit fraction)
     const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
-    uint32_t kp0, kp1, run, n_blocks, nb8;
+    uint32_t kp0, kp1, run, n_blocks;
     float* out;                  // [E*R8] distances
     uint2* queue;                // candidate queue: one region of run x 128 8-byte entries per run
 };
