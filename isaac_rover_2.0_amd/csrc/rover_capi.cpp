@@ -51,7 +51,7 @@ struct rover_ctx {
     float* d_euler = nullptr;       // [E,3]
     float* d_heading = nullptr;     // [E]
     int64_t* d_ids_work = nullptr;  // [E]
-    float* d_env_rec = nullptr;     // [E][48]
+    float* d_env_rec = nullptr;     // [15][E] float4 chunks (ENV_CHUNKS, rover_kernels.hip)
     uint32_t* d_goal_work = nullptr;// [2][E] work lists of generate_goals
     uint32_t* d_block_cnt = nullptr;// [ceil(E/256)]
     // ray binning (raycast variant 2)
@@ -223,7 +223,7 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_euler, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_env_rec, E * 48 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_env_rec, E * 60 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_bins, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_pairs, n * sizeof(uint2)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
@@ -370,6 +370,7 @@ int rover_set_distribution(rover_ctx* c, const double* pts, int32_t P, const int
     HIP_TRY(c, hipMalloc((void**)&c->d_dist, hp.size() * sizeof(double)));
     HIP_TRY(c, hipMemcpy(c->d_dist, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void**)&c->d_obs_idx, (idx.size() + 1) * sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->d_obs_idx, 0, (idx.size() + 1) * sizeof(int32_t)));      // assemble_obs_kernel reads entry 0 from every lane
     if (!idx.empty()) HIP_TRY(c, hipMemcpy(c->d_obs_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     c->P = P; c->Ns = Ns; c->Nd = Nd;
     c->have_dist = true;

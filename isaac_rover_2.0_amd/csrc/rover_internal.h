@@ -45,7 +45,7 @@ struct PrepArgs {
     KnnDev terrain, rocks;
     RayRec* rays;                // [E*R8]
     float *euler, *heading;      // [E,3], [E]
-    float* env_rec;              // [E][48] per-env euler / heading / sin-cos record (prep_env_kernel)
+    float* env_rec;              // [15][E] float4: per-env euler / heading / sin-cos record (prep_env_kernel)
     uint32_t* bin_out;           // optional [E*R8]: bin = (map, cell) key of every slot for the bucket sort (binned ray cast)
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
@@ -68,8 +68,29 @@ struct CullArgs {
 };
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t run, uint64_t* n_runs);
 
+// n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own
+// expansion of a division by a run-time value is ~30 (32-bit) / ~110 (64-bit) dependent instructions per thread.
+struct FastDiv {
+    uint32_t m, s1, s2;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+#endif
+};
+inline FastDiv make_fastdiv(uint32_t d) {           // d >= 1
+    uint32_t L = 0;
+    while (L < 32 && (1ull << L) < d) ++L;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << L) - d) << 32) / d + 1ull);
+    f.s1 = L < 1 ? L : 1; f.s2 = L > 1 ? L - 1 : 0;
+    return f;
+}
+
 struct ObsArgs {
     uint32_t E, W, R8;
+    FastDiv w_div;               // by W (filled in by launch_assemble_obs)
     int64_t obs_stride;
     const float *pos, *target, *heading, *lin_hist, *ang_hist, *dist;
     int32_t fp16_div;            // as-shipped mode: round dist / 2 to fp16

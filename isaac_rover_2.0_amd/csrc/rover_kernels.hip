@@ -157,36 +157,47 @@ __constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0,
                                   {0, 0, 0.03}, {0, 0, 0.03}};
 __constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
 
-// per env: quaternion -> euler, heading, and every sin/cos the ray transforms need (46 floats per env)
-//   env_rec[e][0..2]  roll, pitch, yaw          [3] heading_diff
-//   env_rec[e][4..9]  sin/cos of -roll, -pitch, -yaw (Trig6)
-//   env_rec[e][10+6w .. 15+6w]  wheel w: sin/cos(-steer), sin/cos(susX), sin/cos(susY)   (rock_detect.py:248-272)
-#define ENV_REC 48
+// per env: quaternion -> euler, heading, and every sin/cos the ray transforms need — fifteen float4 chunks per env, stored
+// chunk-major ([ENV_CHUNKS][E] float4): a store instruction of prep_env_kernel then writes 1 KB in a row (env-major, each of its
+// 46 dword stores touched 64 cache lines: 3 M partial-line writes per launch, 13 us), and prep_rays_kernel reads four chunks.
+//   chunk 0        roll, pitch, yaw, heading_diff
+//   chunk 1, 2     sin/cos of -roll, -pitch | -yaw, 0, 0 (Trig6)
+//   chunk 3 + 2w   wheel w: sin/cos(-steer), sin/cos(susX)       chunk 4 + 2w: sin/cos(susY), 0, 0   (rock_detect.py:248-272)
+#define ENV_CHUNKS 15
+// One thread per env; loads first, stores last (the compiler may not move a load above a store it cannot prove disjoint).
 __global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.E) return;
-    const float* pos = a.pos + 3ull * e;
-    float roll, pitch, yaw;
-    quat_to_euler(a.quat + 4ull * e, roll, pitch, yaw);
-    a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
-    float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
-    float tx = a.target[3ull * e] - pos[0], ty = a.target[3ull * e + 1] - pos[1];
-    float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
-    a.heading[e] = hd;
-    float* r = a.env_rec + (size_t)ENV_REC * e;
-    r[0] = roll; r[1] = pitch; r[2] = yaw; r[3] = hd;
-    Trig6 t = euler_trig(roll, pitch, yaw);
-    r[4] = t.sx; r[5] = t.cx; r[6] = t.sy; r[7] = t.cy; r[8] = t.sz; r[9] = t.cz;
+    float4* r = reinterpret_cast<float4*>(a.env_rec) + e;      // chunk k of this env: r[k * E]
+    const size_t E = a.E;
+    const float q[4] = {a.quat[4ull * e], a.quat[4ull * e + 1], a.quat[4ull * e + 2], a.quat[4ull * e + 3]};
+    const float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
     const float* j = a.joints + 13ull * e;
+    const float j0 = j[0], j1 = j[1], j2 = j[2], j4 = j[4], j6 = j[6], j7 = j[7], j8 = j[8];
+    float roll, pitch, yaw;
+    quat_to_euler(q, roll, pitch, yaw);
+    float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
+    float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
+    Trig6 t = euler_trig(roll, pitch, yaw);
+    float o[36];
 #pragma unroll
     for (int w = 0; w < 6; ++w) {
-        float steer = (w == 0) ? j[4] : (w == 1) ? j[6] : (w == 4) ? -j[7] : (w == 5) ? j[8] : 0.0f;    // :248
-        float susY = (w == 0 || w == 2) ? -j[0] : (w == 1 || w == 3) ? j[1] : 0.0f;                      // :263
-        float susX = (w >= 4) ? -j[2] : 0.0f;                                                            // :264
-        float* q = r + 10 + 6 * w;
-        q[0] = sinf(-steer); q[1] = cosf(-steer);
-        q[2] = sinf(susX);   q[3] = cosf(susX);
-        q[4] = sinf(susY);   q[5] = cosf(susY);
+        float steer = (w == 0) ? j4 : (w == 1) ? j6 : (w == 4) ? -j7 : (w == 5) ? j8 : 0.0f;            // :248
+        float susY = (w == 0 || w == 2) ? -j0 : (w == 1 || w == 3) ? j1 : 0.0f;                          // :263
+        float susX = (w >= 4) ? -j2 : 0.0f;                                                              // :264
+        o[6 * w + 0] = sinf(-steer); o[6 * w + 1] = cosf(-steer);
+        o[6 * w + 2] = sinf(susX);   o[6 * w + 3] = cosf(susX);
+        o[6 * w + 4] = sinf(susY);   o[6 * w + 5] = cosf(susY);
+    }
+    a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
+    a.heading[e] = hd;
+    r[0] = make_float4(roll, pitch, yaw, hd);
+    r[1 * E] = make_float4(t.sx, t.cx, t.sy, t.cy);
+    r[2 * E] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        r[(3 + 2 * w) * E] = make_float4(o[6 * w], o[6 * w + 1], o[6 * w + 2], o[6 * w + 3]);
+        r[(4 + 2 * w) * E] = make_float4(o[6 * w + 4], o[6 * w + 5], 0.0f, 0.0f);
     }
 }
 
@@ -194,43 +205,51 @@ __global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
 __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t e = gid / a.R8, slot = gid % a.R8;
-    if (e >= a.E) return;
+    const bool live = e < a.E;              // lanes past the end stay for the transposed stores below
     RayRec rec;
     rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
     uint32_t bin = 0xffffffffu;
     const uint32_t n_real = 26u + a.P;
-    if (slot < n_real) {
-        const float* pos = a.pos + 3ull * e;
-        const float* er = a.env_rec + (size_t)ENV_REC * e;
+    // Every load of the three branches below is issued here, from clamped (always valid) addresses: the wave waits for memory
+    // once instead of once per branch it walks through (a wave of 64 slots meets all three).
+    const uint32_t ec = min(e, a.E - 1u);
+    const float4* er = reinterpret_cast<const float4*>(a.env_rec) + ec;                  // chunk k of the env: er[k * E]
+    const size_t EE = a.E;
+    const uint32_t wq = min(slot >> 2, 5u);                                              // wheel of slots 0..23
+    const uint32_t pq = (slot >= 26u) ? min(slot - 26u, a.P - 1u) : 0u;                  // distribution point of slots 26..
+    const float px = a.pos[3ull * ec], py = a.pos[3ull * ec + 1], pz = a.pos[3ull * ec + 2];
+    const float4 c1 = er[EE], c2 = er[2 * EE], cw = er[(3u + 2u * wq) * EE], cv = er[(4u + 2u * wq) * EE];
+    const float2 t01 = make_float2(c1.x, c1.y), t23 = make_float2(c1.z, c1.w), t45 = make_float2(c2.x, c2.y);
+    const float2 q01 = make_float2(cw.x, cw.y), q23 = make_float2(cw.z, cw.w), q45 = make_float2(cv.x, cv.y);
+    const double dpx = a.dist[3ull * pq], dpy = a.dist[3ull * pq + 1], dpz = a.dist[3ull * pq + 2];
+    if (live && slot < n_real) {
         Trig6 t;
-        t.sx = er[4]; t.cx = er[5]; t.sy = er[6]; t.cy = er[7]; t.sz = er[8]; t.cz = er[9];
+        t.sx = t01.x; t.cx = t01.y; t.sy = t23.x; t.cy = t23.y; t.sz = t45.x; t.cz = t45.y;
         float sx, sy, sz, ux, uy, uz;      // origin, un-normalised direction
         const KnnDev* m;
         if (slot < 24u) {                   // rock_detect.py:160-319
             uint32_t w = slot >> 2, r = slot & 3u;
-            const float* q = er + 10 + 6 * w;
-            const float sst = q[0], cst = q[1], ssx = q[2], csx = q[3], ssy = q[4], csy = q[5];
+            const float sst = q01.x, cst = q01.y, ssx = q23.x, csx = q23.y, ssy = q45.x, csy = q45.y;
             const float zero3[3] = {0.0f, 0.0f, 0.0f};
             wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[w], c_wp1[w], sst, cst, ssx, csx,
-                        ssy, csy, t, pos[0], pos[1], pos[2], sx, sy, sz);
+                        ssy, csy, t, px, py, pz, sx, sy, sz);
             wheel_chain(c_wheel_ray[4][0], c_wheel_ray[4][1], c_wheel_ray[4][2], zero3, zero3, sst, cst, ssx, csx,
                         ssy, csy, t, 0.0f, 0.0f, 0.0f, ux, uy, uz);
             m = &a.rocks;
             rec.flags = 3u;
         } else if (slot < 26u) {            // rock_detect.py:321-371
             uint32_t r = slot - 24u;
-            body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, pos[0], pos[1], pos[2], sx, sy, sz);
+            body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, px, py, pz, sx, sy, sz);
             float qx, qy, qz;
-            body_xf(0.0f, 1.0f, 0.0f, t, pos[0], pos[1], pos[2], qx, qy, qz);
-            ux = qx - pos[0]; uy = qy - pos[1]; uz = qz - pos[2];
+            body_xf(0.0f, 1.0f, 0.0f, t, px, py, pz, qx, qy, qz);
+            ux = qx - px; uy = qy - py; uz = qz - pz;
             m = &a.rocks;
             rec.flags = 3u;
         } else {                            // camera.py:165-212, float64 like the distribution tensor
-            uint32_t p = slot - 26u;
-            double x = a.dist[3ull * p], y = a.dist[3ull * p + 1], z = a.dist[3ull * p + 2];
+            double x = dpx, y = dpy, z = dpz;
             double dsx = (double)t.sx, dcx = (double)t.cx, dsy = (double)t.sy, dcy = (double)t.cy,
                    dsz = (double)t.sz, dcz = (double)t.cz;
-            double X = (double)pos[0], Y = (double)pos[1], Z = (double)pos[2];
+            double X = (double)px, Y = (double)py, Z = (double)pz;
             {
                 double A = y * dcx + z * dsx, C = z * dcx - y * dsx, B = x * dcy - dsy * C;
                 sx = (float)(X + dsz * A + dcz * B);
@@ -270,10 +289,21 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         rec.cell = ix * (uint32_t)m->Y + iy;
         bin = ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell;
     }
-    if (a.bin_out) a.bin_out[gid] = bin;                      // key of the bucket sort; 0xffffffff for padding slots
-    float4* dst = reinterpret_cast<float4*>(a.rays + gid);
-    dst[0] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
-    dst[1] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
+    if (a.bin_out && live) a.bin_out[gid] = bin;              // key of the bucket sort; 0xffffffff for padding slots
+    // The wave's 64 records are 2 KB in a row: transposed through LDS, each of the two stores writes 1 KB contiguously
+    // (lane i: 16 bytes at 16 i) instead of every other 16 bytes of the 2 KB.
+    __shared__ float4 s_t[4][128];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    s_t[w][2u * lane] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
+    s_t[w][2u * lane + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t base = gid - lane, total = a.E * a.R8;
+    const uint32_t n_here = base < total ? min(64u, total - base) : 0u;    // records of this wave (64 but for the last ones)
+    float4* dst = reinterpret_cast<float4*>(a.rays + base);
+    if (lane < 2u * n_here) dst[lane] = s_t[w][lane];
+    if (lane + 64u < 2u * n_here) dst[lane + 64u] = s_t[w][lane + 64u];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -342,27 +372,51 @@ __global__ void __launch_bounds__(256) raycast_kernel(const RayRec* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // obs assembly: one thread per obs element -> coalesced row writes (rover.py:320-325)
 // ---------------------------------------------------------------------------------------------------
+#define OBS_ILP 4
 __global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t total = (uint64_t)a.E * a.W;
-    if (i >= total) return;
-    uint32_t e = (uint32_t)(i / a.W), col = (uint32_t)(i % a.W);
-    float v;
-    if (col >= 4u) {
-        int32_t p = a.obs_idx[col - 4u];                       // sparse then dense, heightmap_distribution.py:126-133
-        v = a.dist[(uint64_t)e * a.R8 + 26u + (uint32_t)p] / 2.0f;
-        if (a.fp16_div) v = (float)(_Float16)v;                // as shipped: `sparse / 2` is an fp16 division (rover.py:324-325)
-    } else if (col == 0u) {
-        float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
-        v = sqrtf(tx * tx + ty * ty) / 9.0f;                   // :320
-    } else if (col == 1u) {
-        v = a.heading[e] / 3.14159265358979323846f;            // :321
-    } else if (col == 2u) {
-        v = a.lin_hist[3ull * e];                              // :322
-    } else {
-        v = a.ang_hist[3ull * e];                              // :323
+    // One thread = OBS_ILP obs elements, a grid apart.  All loads come first and from addresses that are valid for every lane: a
+    // wave holds the four proprioceptive columns of one or two envs next to heightmap columns, and with the loads inside the
+    // five branches it waited for memory once per branch (six round trips in a row, 3.9 us per wave: 21 us for 21 MB).  Now the
+    // chain is index -> distance with everything else beside it, four elements in flight per lane.
+    const uint64_t total = (uint64_t)a.E * a.W, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool small = total <= 0xffffffffull;      // (uniform) the usual case: no 64-bit division chain in front of the loads
+    uint32_t e[OBS_ILP], col[OBS_ILP];
+    int32_t p[OBS_ILP];
+    bool on[OBS_ILP];
+#pragma unroll
+    for (int k = 0; k < OBS_ILP; ++k) {
+        const uint64_t i = i0 + k * stride;
+        on[k] = i < total;
+        const uint64_t ic = on[k] ? i : 0;
+        if (small) { e[k] = a.w_div.div((uint32_t)ic); col[k] = (uint32_t)ic - e[k] * a.W; }
+        else { e[k] = (uint32_t)(ic / a.W); col[k] = (uint32_t)(ic % a.W); }
+        p[k] = a.obs_idx[col[k] >= 4u ? col[k] - 4u : 0u];       // sparse then dense, heightmap_distribution.py:126-133
     }
-    a.obs[(uint64_t)e * a.obs_stride + col] = v;
+    float sv[OBS_ILP], tx[OBS_ILP], ty[OBS_ILP], dv[OBS_ILP];
+#pragma unroll
+    for (int k = 0; k < OBS_ILP; ++k) {
+        const uint64_t e3 = 3ull * e[k];
+        const float* one = col[k] == 1u ? a.heading + e[k] : (col[k] == 2u ? a.lin_hist + e3 : a.ang_hist + e3);
+        sv[k] = *one;
+        tx[k] = a.target[e3] - a.pos[e3]; ty[k] = a.target[e3 + 1] - a.pos[e3 + 1];
+        dv[k] = a.dist[(uint64_t)e[k] * a.R8 + 26u + (uint32_t)p[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < OBS_ILP; ++k) {
+        float v;
+        if (col[k] >= 4u) {
+            v = dv[k] / 2.0f;
+            if (a.fp16_div) v = (float)(_Float16)v;            // as shipped: `sparse / 2` is an fp16 division (rover.py:324-325)
+        } else if (col[k] == 0u) {
+            v = sqrtf(tx[k] * tx[k] + ty[k] * ty[k]) / 9.0f;   // :320
+        } else if (col[k] == 1u) {
+            v = sv[k] / 3.14159265358979323846f;               // :321
+        } else {
+            v = sv[k];                                         // :322 lin_hist, :323 ang_hist
+        }
+        if (on[k]) a.obs[(uint64_t)e[k] * a.obs_stride + col[k]] = v;
+    }
 }
 
 // optional intermediates for parity tests
@@ -393,37 +447,59 @@ __device__ __forceinline__ void block_count_flags(bool flag, uint32_t* __restric
 __device__ __forceinline__ bool collides_grid(const StoneGridDev& g, const float* __restrict__ info7, float x, float y, float thr);
 
 __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t e, bool& done_flag) {
-    int64_t progress = (a.do_increment | a.do_metrics | a.do_done) ? a.progress[e] : 0;
-    if (a.do_increment) { progress += 1; a.progress[e] = progress; }       // rl_task.py:250
-    int64_t coll;
-    if (a.do_collision) {                                                   // check_collision, rover.py:663-668
-        coll = 0;
-        if (a.curriculum_level >= 2) {
-            const float* d = a.dist + (uint64_t)e * a.R8;
-            float mw = d[0];
+    // Every load of the env first, every store after: the compiler may not move a load above a store it cannot prove
+    // disjoint, so loads placed where they are used made the thread wait for memory five or six times in a row (one env per
+    // thread: 1 024 waves, nothing else to run meanwhile).
+    const bool need_progress = a.do_increment | a.do_metrics | a.do_done;
+    int64_t progress = need_progress ? a.progress[e] : 0;
+    const bool cast = a.do_collision && a.curriculum_level >= 2;
+    float4 dw[6];
+    float2 db = make_float2(0.0f, 0.0f);
+    if (cast) {                                                             // rows are 32-byte aligned (R8 is a multiple of 8)
+        const float4* d4 = reinterpret_cast<const float4*>(a.dist + (uint64_t)e * a.R8);
 #pragma unroll
-            for (int r = 1; r < 24; ++r) mw = (d[r] < mw) ? d[r] : mw;
-            float mb = (d[25] < d[24]) ? d[25] : d[24];
+        for (int r = 0; r < 6; ++r) dw[r] = d4[r];
+        db = *reinterpret_cast<const float2*>(a.dist + (uint64_t)e * a.R8 + 24u);
+    }
+    const float px = a.pos[3ull * e], py = a.pos[3ull * e + 1];
+    const float tx = a.target[3ull * e] - px, ty = a.target[3ull * e + 1] - py;
+    int64_t coll = a.do_collision ? 0 : a.rock_collision[e];
+    float hd = 0.0f, j0 = 0.0f, j1 = 0.0f, j2 = 0.0f, lin = 0.0f, lin_prev = 0.0f, ang = 0.0f, ang_prev = 0.0f;
+    if (a.do_metrics) {
+        hd = a.heading[e];
+        const float* jn = a.joints + 13ull * e;
+        j0 = jn[0]; j1 = jn[1]; j2 = jn[2];
+        lin = a.lin_hist[3ull * e]; lin_prev = a.lin_hist[3ull * e + 1];
+        ang = a.ang_hist[3ull * e]; ang_prev = a.ang_hist[3ull * e + 1];
+    }
+    float ep0 = 0.0f, ep1 = 0.0f;
+    if (a.do_done) { ep0 = a.euler_pre[3ull * e]; ep1 = a.euler_pre[3ull * e + 1]; }
+    // additional output (not in the reference's step): stone_info occupancy mask at the rover's position,
+    // the clearance test of rover.py:536-539 through the stone-occupancy grid (a chain of dependent loads: started here)
+    const bool stone = (a.do_collision && a.stone_collision) ? collides_grid(a.sgrid, a.info7, px, py, a.stone_margin) : false;
+
+    if (a.do_increment) { progress += 1; a.progress[e] = progress; }       // rl_task.py:250
+    if (a.do_collision) {                                                   // check_collision, rover.py:663-668
+        if (cast) {
+            float mw = dw[0].x;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                if (r) mw = (dw[r].x < mw) ? dw[r].x : mw;
+                mw = (dw[r].y < mw) ? dw[r].y : mw;
+                mw = (dw[r].z < mw) ? dw[r].z : mw;
+                mw = (dw[r].w < mw) ? dw[r].w : mw;
+            }
+            float mb = (db.y < db.x) ? db.y : db.x;
             coll = (fabsf(mw) < a.wheel_thr) ? 1 : 0;            // 0.8 / 0.45, as fp16 values in the as-shipped mode
             if (fabsf(mb) < a.body_thr) coll = 1;
         }
         a.rock_collision[e] = coll;
-        // additional output (not in the reference's step): stone_info occupancy mask at the rover's position,
-        // the clearance test of rover.py:536-539 through the stone-occupancy grid
-        if (a.stone_collision)
-            a.stone_collision[e] = collides_grid(a.sgrid, a.info7, a.pos[3ull * e], a.pos[3ull * e + 1], a.stone_margin) ? 1 : 0;
-    } else {
-        coll = a.rock_collision[e];
+        if (a.stone_collision) a.stone_collision[e] = stone ? 1 : 0;
     }
-    float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
     float td = sqrtf(tx * tx + ty * ty);                                    // :482 / :617
     if (a.do_metrics) {
-        float hd = a.heading[e];
-        const float* jn = a.joints + 13ull * e;
-        float lin = a.lin_hist[3ull * e], lin_prev = a.lin_hist[3ull * e + 1];
-        float ang = a.ang_hist[3ull * e], ang_prev = a.ang_hist[3ull * e + 1];
         float heading_pen = ((lin < 0.0f) ? -1.0f : 0.0f) * a.heading_contraint_reward;           // :486
-        float boogie = (fabsf(jn[0]) + fabsf(jn[1]) + fabsf(jn[2])) * a.boogie_contraint_reward;   // :492
+        float boogie = (fabsf(j0) + fabsf(j1) + fabsf(j2)) * a.boogie_contraint_reward;       // :492
         float goal_pen = (fabsf(hd) > 2.0f) ? -fabsf(hd * 0.3f * a.goal_angle_reward) : 0.0f;      // :495
         float dl = fabsf(lin * 3.0f - 3.0f * lin_prev), da = fabsf(ang * 3.0f - 3.0f * ang_prev);
         float p1 = (dl > 0.05f) ? dl * dl : 0.0f;                                                  // :498
@@ -447,11 +523,10 @@ __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t 
         if (a.ex_ang) a.ex_ang[e] = ang;
     }
     if (a.do_done) {                                                        // is_done, rover.py:610-647
-        const float* ep = a.euler_pre + 3ull * e;
         const float tilt = (float)(0.78 * 1.5);
         int64_t reset = (progress >= (int64_t)a.max_episode_length) ? 1 : 0;
-        if (fabsf(ep[0]) >= tilt) reset = 1;
-        if (fabsf(ep[1]) >= tilt) reset = 1;
+        if (fabsf(ep0) >= tilt) reset = 1;
+        if (fabsf(ep1) >= tilt) reset = 1;
         if (td >= 11.0f) reset = 1;
         if (td <= 0.18f) reset = 1;
         if (a.curriculum_level >= 2 && coll == 1) reset = 1;
@@ -1436,8 +1511,10 @@ hipError_t launch_knn_select(const float* cx, const float* cy, const uint32_t* b
     return hipGetLastError();
 }
 
-hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(assemble_obs_kernel, dim3(blocks_for((uint64_t)a.E * a.W, 256)), dim3(256), 0, s, a);
+hipError_t launch_assemble_obs(const ObsArgs& a_in, hipStream_t s) {
+    ObsArgs a = a_in;
+    a.w_div = make_fastdiv(a.W);
+    hipLaunchKernelGGL(assemble_obs_kernel, dim3(blocks_for((uint64_t)a.E * a.W, 256 * OBS_ILP)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
