@@ -62,6 +62,8 @@ struct rover_ctx {
     int precision = 0;                  // option "ray_precision": 0 fp32 mode, 1 fp16 sources, 2 as shipped (fp16 maths)
     uint32_t* d_block_sums = nullptr;   // [4096] bucket totals + [4097] bucket starts
     uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
+    bool defer_obs = false, obs_pending = false;   // rover_step: assemble_obs waits for do_metrics and shares its launch
+    ObsArgs pending_obs{};
     uint32_t n_bins = 0;
     int variant = 0;                    // 0 = auto
     int last_variant = 1;
@@ -540,7 +542,8 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
     o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2;
-    HIP_TRY(c, launch_assemble_obs(o, s));
+    if (c->defer_obs) { c->pending_obs = o; c->obs_pending = true; }
+    else HIP_TRY(c, launch_assemble_obs(o, s));
     if (out->ray_dist || out->wheel_dist || out->body_dist)
         HIP_TRY(c, launch_export_dist(c->d_dist_out, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
     if (out->euler) HIP_TRY(c, hipMemcpyAsync(out->euler, c->d_euler, (uint64_t)E * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -580,7 +583,12 @@ static int do_metrics(rover_ctx* c, const rover_step_in* in, const rover_step_ou
     m.done_u8 = done ? out->done_u8 : nullptr;
     m.sgrid = c->sgrid; m.info7 = c->d_stones;
     m.ex_goal_angle = out->ex_goal_angle_penalty; m.ex_lin = out->ex_torque_penalty_driving; m.ex_ang = out->ex_torque_penalty_steering;
-    HIP_TRY(c, launch_metrics_done(m, s));
+    if (c->obs_pending) {
+        c->obs_pending = false;
+        HIP_TRY(c, launch_obs_metrics(c->pending_obs, m, s));
+    } else {
+        HIP_TRY(c, launch_metrics_done(m, s));
+    }
     return ROVER_OK;
 }
 
@@ -630,9 +638,16 @@ int rover_step(rover_ctx* c, const rover_step_in* in, const rover_step_out* out,
     hipStream_t s = (hipStream_t)stream;
     if ((flags & ROVER_STEP_COMPACT) && (!out->reset_ids || !out->n_reset))
         return fail(c, ROVER_E_INVALID, "step: ROVER_STEP_COMPACT needs reset_ids and n_reset");
-    if (int r = do_observations(c, in, out, s)) return r;
+    c->defer_obs = true;              // the obs pass is launched by do_metrics, in one grid with the metrics pass
+    c->obs_pending = false;
+    const int ro = do_observations(c, in, out, s);
+    c->defer_obs = false;
+    if (ro) { c->obs_pending = false; return ro; }
     const bool compact = (flags & ROVER_STEP_COMPACT) != 0;
-    if (int r = do_metrics(c, in, out, (flags & ROVER_STEP_INCREMENT_PROGRESS) ? 1 : 0, 1, 1, 1, s, compact)) return r;
+    if (int r = do_metrics(c, in, out, (flags & ROVER_STEP_INCREMENT_PROGRESS) ? 1 : 0, 1, 1, 1, s, compact)) {
+        c->obs_pending = false;
+        return r;
+    }
     if (compact)
         HIP_TRY(c, launch_compact(out->reset, (uint32_t)c->cfg.num_envs, (int64_t)c->cfg.env_offset, c->d_block_cnt, true,
                                   out->reset_ids, out->n_reset, s));

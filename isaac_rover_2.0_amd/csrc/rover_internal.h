@@ -191,6 +191,7 @@ hipError_t launch_knn_select(const float* cx, const float* cy, const uint32_t* b
 hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
 hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
                               hipStream_t s);
+hipError_t launch_obs_metrics(const ObsArgs& o, const MetricsArgs& m, hipStream_t s);     // both in one launch (rover_step)
 hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s);
 hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint32_t* block_cnt, bool counted, int64_t* ids,
                           int32_t* count, hipStream_t s);

@@ -373,13 +373,13 @@ __global__ void __launch_bounds__(256) raycast_kernel(const RayRec* __restrict__
 // obs assembly: one thread per obs element -> coalesced row writes (rover.py:320-325)
 // ---------------------------------------------------------------------------------------------------
 #define OBS_ILP 4
-__global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
+__device__ __forceinline__ void assemble_obs_block(const ObsArgs& a, uint32_t bid, uint32_t n_blocks) {
     // One thread = OBS_ILP obs elements, a grid apart.  All loads come first and from addresses that are valid for every lane: a
     // wave holds the four proprioceptive columns of one or two envs next to heightmap columns, and with the loads inside the
     // five branches it waited for memory once per branch (six round trips in a row, 3.9 us per wave: 21 us for 21 MB).  Now the
     // chain is index -> distance with everything else beside it, four elements in flight per lane.
-    const uint64_t total = (uint64_t)a.E * a.W, stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)a.E * a.W, stride = (uint64_t)n_blocks * 256u;
+    const uint64_t i0 = (uint64_t)bid * 256u + threadIdx.x;
     const bool small = total <= 0xffffffffull;      // (uniform) the usual case: no 64-bit division chain in front of the loads
     uint32_t e[OBS_ILP], col[OBS_ILP];
     int32_t p[OBS_ILP];
@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) {
         if (on[k]) a.obs[(uint64_t)e[k] * a.obs_stride + col[k]] = v;
     }
 }
+__global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) { assemble_obs_block(a, blockIdx.x, gridDim.x); }
 
 // optional intermediates for parity tests
 __global__ void __launch_bounds__(256) export_dist_kernel(const float* __restrict__ dist, uint32_t E, uint32_t R8, uint32_t P,
@@ -436,12 +437,12 @@ __global__ void __launch_bounds__(256) export_dist_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 // collision mask + reward + extras + done: one thread per env (rover.py:663-668, 460-531, 610-647)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_count_flags(bool flag, uint32_t* __restrict__ block_cnt) {
+__device__ __forceinline__ void block_count_flags(bool flag, uint32_t* __restrict__ block_cnt, uint32_t bid) {
     __shared__ uint32_t wcnt[4];
     unsigned long long ballot = __ballot(flag);
     if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = __popcll(ballot);
     __syncthreads();
-    if (threadIdx.x == 0) block_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (threadIdx.x == 0) block_cnt[bid] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
 __device__ __forceinline__ bool collides_grid(const StoneGridDev& g, const float* __restrict__ info7, float x, float y, float thr);
@@ -536,11 +537,20 @@ __device__ __forceinline__ void metrics_done_env(const MetricsArgs& a, uint32_t 
     }
 }
 
-__global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void metrics_done_block(const MetricsArgs& a, uint32_t bid) {
+    uint32_t e = bid * 256u + threadIdx.x;
     bool done_flag = false;
     if (e < a.E) metrics_done_env(a, e, done_flag);
-    if (a.block_cnt) block_count_flags(done_flag, a.block_cnt);           // per-block done count for the compaction
+    if (a.block_cnt) block_count_flags(done_flag, a.block_cnt, bid);      // per-block done count for the compaction
+}
+__global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) { metrics_done_block(a, blockIdx.x); }
+
+// rover_step: both consumers of the ray distances in ONE launch — the first n_met workgroups are metrics_done_kernel's (one env per
+// thread, a long chain of dependent loads: they start first), the rest assemble_obs_kernel's.  Neither reads what the other
+// writes; side by side the 9 us of the metrics pass hide behind the obs pass instead of following it.
+__global__ void __launch_bounds__(256) obs_metrics_kernel(ObsArgs o, MetricsArgs m, uint32_t n_met) {
+    if (blockIdx.x < n_met) metrics_done_block(m, blockIdx.x);
+    else assemble_obs_block(o, blockIdx.x - n_met, gridDim.x - n_met);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -551,7 +561,7 @@ __global__ void __launch_bounds__(256) metrics_done_kernel(MetricsArgs a) {
 __global__ void __launch_bounds__(256) compact_count_kernel(const int64_t* __restrict__ reset, uint32_t n,
                                                             uint32_t* __restrict__ block_cnt) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    block_count_flags((i < n) && (reset[i] != 0), block_cnt);
+    block_count_flags((i < n) && (reset[i] != 0), block_cnt, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(256) compact_write_kernel(const int64_t* __restrict__ reset, uint32_t n, int64_t offset,
@@ -1522,6 +1532,14 @@ hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32
                               hipStream_t s) {
     hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, E, R8, P,
                        ray_dist, wheel, body);
+    return hipGetLastError();
+}
+
+hipError_t launch_obs_metrics(const ObsArgs& o_in, const MetricsArgs& m, hipStream_t s) {
+    ObsArgs o = o_in;
+    o.w_div = make_fastdiv(o.W);
+    const uint32_t n_met = blocks_for(m.E, 256), n_obs = blocks_for((uint64_t)o.E * o.W, 256 * OBS_ILP);
+    hipLaunchKernelGGL(obs_metrics_kernel, dim3(n_met + n_obs), dim3(256), 0, s, o, m, n_met);
     return hipGetLastError();
 }
 
