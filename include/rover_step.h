@@ -242,8 +242,9 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
  * (learning/model.py:122-150: 634 -> 80 -> 60) or the MLP with its head (:176-195: 124 -> 256 -> 160 -> 128 -> 2).  Only x and the
  * last layer's output touch HBM: the activations stay in the MFMA accumulator registers, which are the next layer's B operand as
  * they are (csrc/rover_mlp.hip).  weights[i] is nn.Linear's [widths[i]][widths[i-1]] (K0 for i = 0), biases[i] may be NULL.
- * Built tile shapes: 2 layers with widths <= 96, <= 64; 4 layers with widths <= 256, <= 160, <= 128, <= 32 (else ROVER_E_INVALID:
- * use rover_linear_forward per layer).  Same numerics as rover_linear_forward up to the summation order inside a layer. */
+ * Built tile shapes: 2 layers with widths <= 96, <= 64; 4 layers with widths <= 256, <= 160, <= 128, <= 16 and activation 0, 1 or 3
+ * (none / LeakyReLU / ReLU) on the three hidden layers (else ROVER_E_INVALID: use rover_linear_forward per layer).  Same numerics as
+ * rover_linear_forward up to the summation order inside a layer. */
 ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers,
                                       const float *const *weights, const float *const *biases, const int32_t *widths,
                                       const int32_t *activations, float *y, int64_t y_stride, void *stream);

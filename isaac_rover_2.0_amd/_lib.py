@@ -381,12 +381,15 @@ class Engine:
                     "rover_linear_forward")
         return out
 
-    CHAIN_SHAPES = {2: (96, 64), 4: (256, 160, 128, 32)}        # widths the fused chain kernel is built for
+    CHAIN_SHAPES = {2: (96, 64), 4: (256, 160, 128, 16)}        # widths the fused chain kernel is built for
+    CHAIN_HIDDEN_ACTS = (None, "none", "leakyrelu", "relu")      # hidden activations the 4-layer chain is built for
 
     def chain_fits(self, layers):
         """True if ``layers`` (objects with .weight [n, k]) can run as one rover_mlp_chain_forward launch."""
         lim = self.CHAIN_SHAPES.get(len(layers))
-        return lim is not None and all(l.weight.shape[0] <= m for l, m in zip(layers, lim)) and layers[0].weight.shape[1] > 0
+        if lim is None or not all(l.weight.shape[0] <= m for l, m in zip(layers, lim)) or layers[0].weight.shape[1] <= 0:
+            return False
+        return len(layers) == 2 or all(l.activation in self.CHAIN_HIDDEN_ACTS for l in layers[:-1])
 
     def chain_forward(self, x, layers, out):
         """out = layers[-1](... layers[0](x)) in one kernel; ``layers``: objects with .weight [n, k], .bias [n], .activation."""

@@ -928,7 +928,7 @@ int rover_mlp_chain_forward(rover_ctx* c, const float* x, int64_t x_stride, int3
     if (M == 0) return ROVER_OK;
     USE_DEVICE(c);
     hipError_t e = launch_chain(a, (hipStream_t)stream);
-    if (e == hipErrorInvalidValue) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: layer widths outside the built tile shapes (<= 96 -> <= 64, or <= 256 -> <= 160 -> <= 128 -> <= 32)");
+    if (e == hipErrorInvalidValue) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: net outside the built tile shapes (<= 96 -> <= 64, or <= 256 -> <= 160 -> <= 128 -> <= 16 with hidden activations none / LeakyReLU / ReLU)");
     HIP_TRY(c, e);
     return ROVER_OK;
 }

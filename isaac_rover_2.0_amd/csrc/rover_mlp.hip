@@ -130,216 +130,280 @@ hipError_t launch_linear_act(const LinearArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// A CHAIN of up to four layers in one kernel (an encoder 634 -> 80 -> 60, or the MLP 124 -> 256 -> 160 -> 128 -> 2 of
+// A CHAIN of two or four layers in one kernel (an encoder 634 -> 80 -> 60, or the MLP 124 -> 256 -> 160 -> 128 -> 2 of
 // learning/model.py:122-150,176-195): only the chain's input and its last output touch HBM.
 //
-// The MFMA runs transposed, D[n][m] = W[n][k] X^T[k][m]: the 32 x 32 accumulator tile then has the batch row m on the LANE
-// (col = lane & 31) and the output feature n in the registers (n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r < 16) — exactly
-// the B-operand shape of the next layer's MFMA (B[k][m]: lane half h takes k-step entry h).  Register r of an input tile is
-// k-step r of the next layer, fed with the weight column kmap(r, h) as its A operand: activations never leave the
-// registers, no LDS transpose, and only the weight slabs (N x 32 floats per input tile) are staged through LDS.
-// Layer 1 takes its B operand from an LDS slab of the input rows (128 rows x 32 k, coalesced loads, next slab prefetched
-// into registers under the MFMAs).  Every wave owns 32 batch rows through the whole chain.
+// The MFMA runs transposed, D[n][m] = W[n][k] X^T[k][m]: the accumulator tile then has the batch row m on the LANE and the output
+// feature n in the registers — exactly the B-operand shape of the next layer's MFMA.  Activations never leave the registers, no
+// LDS transpose, and only weight slabs are staged through LDS.  Layer 1 takes its B operand from an LDS slab of the input rows.
+//
+// 16 x 16 x 4 MFMAs (v_mfma_f32_16x16x4_f32), 16 batch rows per wave, 8 waves per workgroup.  (Round 2's first version used
+// 32 x 32 x 2 tiles and 32 rows per wave: 0.54 ms for the actor forward at 65 536 rows, this one 0.34 ms.)
+//   * a wave's state is 4 VGPRs per 16 output features instead of 16 per 32: the whole MLP chain fits in ~128 VGPRs (the 32-wide
+//     version needed 384: one wave per SIMD, every barrier and every exposed load stalled the matrix pipe), the encoder chain in ~70;
+//     with 65 536 rows there are 4 waves per SIMD to overlap one workgroup's staging with another's MFMAs;
+//   * 80 output features are 5 tiles, not 3 x 32 = 96: no padded MFMA work in the two layers that hold 60 % of the flops;
+//   * operands come from LDS as 16-byte reads: lane (m = lane & 15, g = lane >> 4) reads k = 4 g .. 4 g + 3 of its row, which
+//     feeds FOUR MFMAs (MFMA j takes element j: its four k-indices are j, 4 + j, 8 + j, 12 + j on both operands — a sum over k does
+//     not care).  Row pitches of 36 / 20 floats put the 8 lanes of a 16-byte read phase on 8 different bank groups.
+// Transposed as above: D[n][m] = W[n][k] X^T[k][m].  D: lane holds features n = 16 t + 4 g + r (r < 4) of batch row m — as the next
+// layer's B operand (k-index g <-> lane group g) register r pairs with weight column 16 t + 4 g + r, i.e. element r of the 16-byte
+// read at column 4 g of the [n_out][16] weight slab of input tile t.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mlp_kmap(uint32_t r, uint32_t h) { return (r & 3u) + 8u * (r >> 2) + 4u * h; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // a float4 at any float address (global_load_dwordx4)
+#define C16_XP 36
+#define C16_WP 20
 
-// bias + activation on a layer's accumulator tiles.  The activation is a template parameter of the unrolled body and the
-// (wave-uniform) switch sits outside it: with the switch inside, every one of the T x 16 elements carried tanhf, expm1f
-// and the rest — 49 000 instructions for the 4-layer chain, far beyond the instruction cache.
 template <int T, int ACT>
-__device__ __forceinline__ void chain_bias_act_as(f32x16 (&acc)[T], const float* __restrict__ bias, int n_valid, uint32_t lane) {
+__device__ __forceinline__ void c16_bias_act_as(f32x4 (&acc)[T], const float* __restrict__ bias, int n_valid, uint32_t g) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t n = 32u * t + mlp_kmap((uint32_t)r, lane >> 5);
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t n = 16u * t + 4u * g + (uint32_t)r;
             const float b = (bias && n < (uint32_t)n_valid) ? bias[n] : 0.0f;
             acc[t][r] = n < (uint32_t)n_valid ? mlp_act(acc[t][r] + b, ACT) : 0.0f;
         }
 }
 template <int T>
-__device__ __forceinline__ void chain_bias_act(f32x16 (&acc)[T], const float* __restrict__ bias, int n_valid, int act, uint32_t lane) {
-    switch (act) {
-        case 1: chain_bias_act_as<T, 1>(acc, bias, n_valid, lane); break;
-        case 2: chain_bias_act_as<T, 2>(acc, bias, n_valid, lane); break;
-        case 3: chain_bias_act_as<T, 3>(acc, bias, n_valid, lane); break;
-        case 4: chain_bias_act_as<T, 4>(acc, bias, n_valid, lane); break;
-        default: chain_bias_act_as<T, 0>(acc, bias, n_valid, lane); break;
+__device__ __forceinline__ void c16_bias_act(f32x4 (&acc)[T], const float* __restrict__ bias, int n_valid, int act, uint32_t g) {
+    switch (act) {                                                   // (wave-uniform; outside the unrolled body, see chain_bias_act)
+        case 1: c16_bias_act_as<T, 1>(acc, bias, n_valid, g); break;
+        case 2: c16_bias_act_as<T, 2>(acc, bias, n_valid, g); break;
+        case 3: c16_bias_act_as<T, 3>(acc, bias, n_valid, g); break;
+        case 4: c16_bias_act_as<T, 4>(acc, bias, n_valid, g); break;
+        default: c16_bias_act_as<T, 0>(acc, bias, n_valid, g); break;
     }
 }
-
-// one register-fed layer: out[TO] (+)= W[:, cols of `in`] . in[TI]; W is [n_out][ldw] row-major, its column for feature f of the
-// input is col0[tile] + f (f < cols[tile]; the rest of a tile is padding).  The weight slab of input tile ti + 1 is fetched into
-// registers before the MFMAs of tile ti and stored after them — with DB to the OTHER LDS buffer (one barrier per slab; the
-// 4-layer chain runs one wave per SIMD anyway and nothing else hides the latency), without DB to the same buffer between two
-// barriers (the 2-layer encoder chain: 50 KB of LDS, three workgroups per CU).
-template <int TI, int TO, bool DB>
-__device__ __forceinline__ void chain_layer(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* __restrict__ w, int ldw, int n_out,
-                                            const int (&col0)[TI], const int (&cols)[TI], float* __restrict__ Ws /* 2 buffers */, uint32_t tid,
-                                            uint32_t lane) {
-    const uint32_t sc = tid & 31u, sr = tid >> 5;
-    constexpr uint32_t BUF = 256u * MLP_PITCH;
-    float pw[TO * 4];
-    auto fetch = [&](int ti) {
+// hidden layers of the 4-layer chain (up to 64 values per lane): none / LeakyReLU / ReLU only, as one select per value — five
+// unrolled copies of 64 activations, tanhf and expm1f among them, made the kernel 280 KB (launch_chain sends other nets layer by layer)
+template <int T>
+__device__ __forceinline__ void c16_bias_act_hidden(f32x4 (&acc)[T], const float* __restrict__ bias, int n_valid, int act, uint32_t g) {
+    const float slope = act == 1 ? 0.01f : (act == 3 ? 0.0f : 1.0f);
 #pragma unroll
-        for (int j = 0; j < TO * 4; ++j) {                           // slab [TO * 32 rows][32 features of input tile ti]
-            const uint32_t n = sr + 8u * j;
-            pw[j] = (n < (uint32_t)n_out && (int)sc < cols[ti]) ? w[(size_t)n * ldw + col0[ti] + sc] : 0.0f;
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t n = 16u * t + 4u * g + (uint32_t)r;
+            const float b = (bias && n < (uint32_t)n_valid) ? bias[n] : 0.0f;
+            const float v = acc[t][r] + b;
+            const float neg = act == 3 ? 0.0f : slope * v;
+            acc[t][r] = n < (uint32_t)n_valid ? (v > 0.0f ? v : neg) : 0.0f;
+        }
+}
+
+// one register-fed layer: out[TO] = W[:, features of in[TI]] . in.  The [n_out][16] weight slab of input tile ti + 1 is fetched into
+// registers before the MFMAs of tile ti and stored into the other LDS buffer after them: one barrier per slab.
+template <int TI, int TO>
+__device__ __forceinline__ void c16_layer(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* __restrict__ w, int n_in, int n_out,
+                                          uint32_t col0 /* feature index of in[0]'s first row */, float* __restrict__ Wb /* 2 x [TO * 16][C16_WP] */,
+                                          uint32_t tid, uint32_t m, uint32_t g) {
+    constexpr uint32_t BUF = TO * 16u * C16_WP;
+    constexpr int NJ = (TO * 16 + 127) / 128;
+    const uint32_t c4 = tid & 3u, sr = tid >> 2;                     // 16-byte column of the slab; first slab row of this thread (128 rows per pass)
+    f32x4 pw[NJ];
+    auto fetch = [&](int ti) {
+        const uint32_t col = col0 + 16u * ti + 4u * c4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t n = sr + 128u * j;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (n < (uint32_t)n_out && n < TO * 16u) {
+                const float* __restrict__ p = w + (size_t)n * n_in;
+                if (col + 4u <= (uint32_t)n_in) v = *reinterpret_cast<const f32x4u*>(p + col);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (col + e < (uint32_t)n_in) v[e] = p[col + e];
+                }
+            }
+            pw[j] = v;
         }
     };
     auto stash = [&](uint32_t buf) {
 #pragma unroll
-        for (int j = 0; j < TO * 4; ++j) Ws[buf * BUF + (sr + 8u * j) * MLP_PITCH + sc] = pw[j];
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t n = sr + 128u * j;
+            if (n < TO * 16u) *reinterpret_cast<f32x4*>(Wb + buf * BUF + n * C16_WP + 4u * c4) = pw[j];
+        }
     };
-    __syncthreads();                                                 // the previous layer's readers are done with both buffers
+    __syncthreads();                                                 // the previous user of the LDS is done
     fetch(0);
     stash(0);
     __syncthreads();
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-        const uint32_t buf = DB ? ((uint32_t)ti & 1u) : 0u;
+        const uint32_t buf = (uint32_t)ti & 1u;
         if (ti + 1 < TI) fetch(ti + 1);                              // in flight during the MFMAs below
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t kc = mlp_kmap((uint32_t)r, lane >> 5);
+        for (int to = 0; to < TO; ++to) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(Wb + buf * BUF + (16u * to + m) * C16_WP + 4u * g);
 #pragma unroll
-            for (int to = 0; to < TO; ++to) {
-                const float av = Ws[buf * BUF + (to * 32u + (lane & 31u)) * MLP_PITCH + kc];
-                out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, in[ti][r], out[to], 0, 0, 0);
-            }
+            for (int r = 0; r < 4; ++r) out[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], in[ti][r], out[to], 0, 0, 0);
         }
         if (ti + 1 < TI) {
-            if (!DB) __syncthreads();                                // one buffer: this slab's readers first
-            stash(DB ? buf ^ 1u : 0u);                               // (two buffers: nobody reads the other one now)
+            stash(buf ^ 1u);                                         // nobody reads the other buffer now
             __syncthreads();
         }
     }
 }
 
 template <int T>
-__device__ __forceinline__ void chain_zero(f32x16 (&acc)[T]) {
+__device__ __forceinline__ void c16_zero(f32x4 (&acc)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// the chain's last activations -> y[row][n]: lane (m, g) holds n = 16 t + 4 g .. + 3 of row m (16 bytes in a row)
+template <int T>
+__device__ __forceinline__ void c16_store(const f32x4 (&acc)[T], float* __restrict__ y, int64_t y_stride, int n_valid, int M, uint32_t row,
+                                          uint32_t g) {
+    if (row >= (uint32_t)M) return;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t n = 16u * t + 4u * g + (uint32_t)r;
+            if (n < (uint32_t)n_valid) y[(size_t)row * y_stride + n] = acc[t][r];
+        }
 }
 
-// the chain's last activations -> y[m][n] through an LDS transpose (coalesced 128-byte row segments)
-template <int T>
-__device__ __forceinline__ void chain_store(const f32x16 (&acc)[T], float* __restrict__ y, int64_t y_stride, int n_valid, int M, uint32_t row0,
-                                            float* __restrict__ Xs, uint32_t lane, uint32_t wave) {
+// layer 1 for the TN output tiles that start at weight row n_off: both operands from LDS slabs of 32 k.  Staging is 16 bytes per
+// lane and instruction (global_load_dwordx4 at 4-byte alignment -> ds_write_b128): 2 + 2 loads and stores per thread and slab where
+// dword staging took 13 + 13 with a 64-bit address and two bounds tests each — measured, the staging instructions do not hide
+// under the MFMAs of the other waves of the SIMD, they add to them.  The 16 bytes that hold the end of the k range are fetched element by element.
+// PF: the next slab is fetched into registers under the MFMAs (the encoders' long k ranges); without it the 16 staging registers are
+// not live across the MFMAs (the MLP's first layer: k = 124 is four slabs, and the kernel has no registers to spare).
+template <int TN, bool PF>
+__device__ __forceinline__ void c16_layer1(f32x4 (&a1)[TN], const ChainArgs& a, uint32_t n_off, uint32_t row0, float* __restrict__ Xs,
+                                           float* __restrict__ Ws, uint32_t tid, uint32_t wave, uint32_t m, uint32_t g) {
+    constexpr int WJ = (TN * 16 + 63) / 64;                         // weight-row passes of 64 rows
+    const uint32_t c4 = tid & 7u, r0 = tid >> 3;                     // 16-byte column of the slab; first slab row of this thread
+    f32x4 px[2], pw[WJ];
+    auto load4 = [&](const float* __restrict__ p, uint32_t k, bool row_ok) {     // elements k .. k + 3 of a row, zero past K0 / the rows
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row_ok) {
+            if (k + 4u <= (uint32_t)a.K0) v = *reinterpret_cast<const f32x4u*>(p + k);
+            else {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+                for (int e = 0; e < 4; ++e) if (k + e < (uint32_t)a.K0) v[e] = p[k + e];
+            }
+        }
+        return v;
+    };
+    auto fetch = [&](uint32_t k0) {
+        const uint32_t k = k0 + 4u * c4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t gr = row0 + r0 + 64u * j;
+            px[j] = load4(a.x + (size_t)gr * a.x_stride, k, gr < (uint32_t)a.M);
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const uint32_t nl = r0 + 64u * j, n = n_off + nl;
+            pw[j] = load4(a.w[0] + (size_t)n * a.K0, k, nl < TN * 16u && n < (uint32_t)a.n[0]);
+        }
+    };
+    if (PF) fetch(0);
+    for (uint32_t k0 = 0; k0 < (uint32_t)a.K0; k0 += 32u) {
+        if (!PF) fetch(k0);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Xs[(wave * 32u + (lane & 31u)) * MLP_PITCH + mlp_kmap((uint32_t)r, lane >> 5)] = acc[t][r];
-        __syncthreads();
-        const uint32_t col = 32u * t + (lane & 31u);
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(Xs + (r0 + 64u * j) * C16_XP + 4u * c4) = px[j];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t rr = 2u * j + (lane >> 5), row = row0 + wave * 32u + rr;
-            if (col < (uint32_t)n_valid && row < (uint32_t)M) y[(size_t)row * y_stride + col] = Xs[(wave * 32u + rr) * MLP_PITCH + (lane & 31u)];
+        for (int j = 0; j < WJ; ++j)
+            if (r0 + 64u * j < TN * 16u) *reinterpret_cast<f32x4*>(Ws + (r0 + 64u * j) * C16_XP + 4u * c4) = pw[j];
+        __syncthreads();
+        if (PF && k0 + 32u < (uint32_t)a.K0) fetch(k0 + 32u);          // in flight during the MFMAs below
+#pragma unroll
+        for (uint32_t kq = 0; kq < 2; ++kq) {
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(Xs + (wave * 16u + m) * C16_XP + 16u * kq + 4u * g);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(Ws + (16u * t + m) * C16_XP + 16u * kq + 4u * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[j], a1[t], 0, 0, 0);
+            }
         }
     }
 }
 
-// T1..T4: 32-wide output tiles of the layers (0 = layer absent).  Layer-1 inputs are x[:, 0:K0]; the layers after the
-// first see their predecessor's outputs, except that layer 1 may be SKIPPED (T1 = 0 is not allowed; see CONCAT below).
-// CONCAT (the MLP of model.py:185-195): the input row is [p proprioceptive | f encoder-0 | f encoder-1 features] and K0 = p + 2 f
-// is not a multiple of 32; it is simply streamed as layer 1's k range (zero-padded past K0), nothing special is needed.
+// T1..T4: 16-wide output tiles of the layers (T3 = T4 = 0: a 2-layer chain).  The 4-layer chain computes layer 1 in two halves of
+// T1 / 2 tiles, each fed into layer 2's accumulators as soon as it is done (the input rows are staged twice: k = 124 is four
+// slabs): 32 + 40 live accumulator registers instead of 64 + 40, and the kernel stays under 128 VGPRs without spilling.
 template <int T1, int T2, int T3, int T4>
-__global__ void __launch_bounds__(256) chain_kernel(ChainArgs a) {
-    __shared__ float Xs[128 * MLP_PITCH];
-    constexpr bool DB = T3 != 0;                                   // see chain_layer
-    __shared__ float Ws[(DB ? 2 : 1) * 256 * MLP_PITCH];
+__global__ void __launch_bounds__(512, 4) chain16_kernel(ChainArgs a) {       // four waves per SIMD (two workgroups per CU): <= 128 VGPRs
+    constexpr bool LONG = T3 != 0;
+    constexpr int T1H = LONG ? T1 / 2 : T1;
+    constexpr uint32_t L1 = (128u + T1H * 16u) * C16_XP;                                 // layer 1: input rows + weight rows, 32 k each
+    constexpr uint32_t TOMAX = T2 > T3 ? (T2 > T4 ? T2 : T4) : (T3 > T4 ? T3 : T4);
+    constexpr uint32_t LN = 2u * TOMAX * 16u * C16_WP;                                   // later layers: two weight slabs
+    __shared__ __attribute__((aligned(16))) float lds[L1 > LN ? L1 : LN];
+    float* Xs = lds;
+    float* Ws = lds + 128u * C16_XP;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t m = lane & 15u, g = lane >> 4;
     const uint32_t row0 = blockIdx.x * 128u;
-    const uint32_t sc = tid & 31u, sr = tid >> 5;
-    // ---- layer 1: B operand from the LDS slab of the input rows
-    f32x16 a1[T1];
-    chain_zero(a1);
-    {
-        float pa[16], pw[T1 * 4];
-        auto fetch = [&](uint32_t k0) {
-            const uint32_t gk = k0 + sc;
-            const bool kin = gk < (uint32_t)a.K0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t gr = row0 + sr + 8u * j;
-                pa[j] = (kin && gr < (uint32_t)a.M) ? a.x[(size_t)gr * a.x_stride + gk] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < T1 * 4; ++j) {
-                const uint32_t n = sr + 8u * j;
-                pw[j] = (kin && n < (uint32_t)a.n[0]) ? a.w[0][(size_t)n * a.K0 + gk] : 0.0f;
-            }
-        };
-        fetch(0);
-        for (uint32_t k0 = 0; k0 < (uint32_t)a.K0; k0 += MLP_BK) {
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) Xs[(sr + 8u * j) * MLP_PITCH + sc] = pa[j];
-#pragma unroll
-            for (int j = 0; j < T1 * 4; ++j) Ws[(sr + 8u * j) * MLP_PITCH + sc] = pw[j];
-            __syncthreads();
-            if (k0 + MLP_BK < (uint32_t)a.K0) fetch(k0 + MLP_BK);        // in flight during the MFMAs below
-#pragma unroll 4
-            for (uint32_t kk = 0; kk < MLP_BK; kk += 2) {
-                const float bv = Xs[(wave * 32u + (lane & 31u)) * MLP_PITCH + kk + (lane >> 5)];
-#pragma unroll
-                for (int t = 0; t < T1; ++t) {
-                    const float av = Ws[(t * 32u + (lane & 31u)) * MLP_PITCH + kk + (lane >> 5)];
-                    a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, a1[t], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if constexpr (T2 == 0) {
-        chain_bias_act(a1, a.b[0], a.n[0], a.act[0], lane);
-        chain_store(a1, a.y, a.y_stride, a.n[0], a.M, row0, Xs, lane, wave);
-    } else {
-        chain_bias_act(a1, a.b[0], a.n[0], a.act[0], lane);
-        int c0[T1], cn[T1];
-#pragma unroll
-        for (int t = 0; t < T1; ++t) { c0[t] = 32 * t; cn[t] = a.n[0] - 32 * t < 32 ? (a.n[0] - 32 * t > 0 ? a.n[0] - 32 * t : 0) : 32; }
-        f32x16 a2[T2];
-        chain_zero(a2);
-        chain_layer<T1, T2, DB>(a1, a2, a.w[1], a.n[0], a.n[1], c0, cn, Ws, tid, lane);
-        chain_bias_act(a2, a.b[1], a.n[1], a.act[1], lane);
-        if constexpr (T3 == 0) {
-            chain_store(a2, a.y, a.y_stride, a.n[1], a.M, row0, Xs, lane, wave);
+    const uint32_t row = row0 + wave * 16u + m;
+    if constexpr (!LONG) {
+        f32x4 a1[T1];
+        c16_zero(a1);
+        c16_layer1<T1, true>(a1, a, 0u, row0, Xs, Ws, tid, wave, m, g);
+        c16_bias_act(a1, a.b[0], a.n[0], a.act[0], g);
+        if constexpr (T2 == 0) {
+            c16_store(a1, a.y, a.y_stride, a.n[0], a.M, row, g);
         } else {
-            int d0[T2], dn[T2];
+            f32x4 a2[T2];
+            c16_zero(a2);
+            c16_layer<T1, T2>(a1, a2, a.w[1], a.n[0], a.n[1], 0u, lds, tid, m, g);
+            c16_bias_act(a2, a.b[1], a.n[1], a.act[1], g);
+            c16_store(a2, a.y, a.y_stride, a.n[1], a.M, row, g);
+        }
+    } else {
+        f32x4 a2[T2];
+        c16_zero(a2);
 #pragma unroll
-            for (int t = 0; t < T2; ++t) { d0[t] = 32 * t; dn[t] = a.n[1] - 32 * t < 32 ? (a.n[1] - 32 * t > 0 ? a.n[1] - 32 * t : 0) : 32; }
-            f32x16 a3[T3];
-            chain_zero(a3);
-            chain_layer<T2, T3, DB>(a2, a3, a.w[2], a.n[1], a.n[2], d0, dn, Ws, tid, lane);
-            chain_bias_act(a3, a.b[2], a.n[2], a.act[2], lane);
-            if constexpr (T4 == 0) {
-                chain_store(a3, a.y, a.y_stride, a.n[2], a.M, row0, Xs, lane, wave);
-            } else {
-                int e0[T3], en[T3];
-#pragma unroll
-                for (int t = 0; t < T3; ++t) { e0[t] = 32 * t; en[t] = a.n[2] - 32 * t < 32 ? (a.n[2] - 32 * t > 0 ? a.n[2] - 32 * t : 0) : 32; }
-                f32x16 a4[T4];
-                chain_zero(a4);
-                chain_layer<T3, T4, DB>(a3, a4, a.w[3], a.n[2], a.n[3], e0, en, Ws, tid, lane);
-                chain_bias_act(a4, a.b[3], a.n[3], a.act[3], lane);
-                chain_store(a4, a.y, a.y_stride, a.n[3], a.M, row0, Xs, lane, wave);
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a1[T1H];
+            c16_zero(a1);
+            if (h) __syncthreads();                                  // layer 2's weight slabs share the LDS with layer 1's
+            c16_layer1<T1H, false>(a1, a, (uint32_t)h * T1H * 16u, row0, Xs, Ws, tid, wave, m, g);
+            {   // bias + activation of this half: feature index = h T1H 16 + 16 t + 4 g + r
+                const float* bh = a.b[0] ? a.b[0] + h * T1H * 16 : nullptr;
+                c16_bias_act_hidden(a1, bh, a.n[0] - h * T1H * 16, a.act[0], g);
             }
+            c16_layer<T1H, T2>(a1, a2, a.w[1], a.n[0], a.n[1], (uint32_t)h * T1H * 16u, lds, tid, m, g);
+        }
+        c16_bias_act_hidden(a2, a.b[1], a.n[1], a.act[1], g);
+        f32x4 a3[T3];
+        c16_zero(a3);
+        c16_layer<T2, T3>(a2, a3, a.w[2], a.n[1], a.n[2], 0u, lds, tid, m, g);
+        if constexpr (T4 == 0) {
+            c16_bias_act(a3, a.b[2], a.n[2], a.act[2], g);
+            c16_store(a3, a.y, a.y_stride, a.n[2], a.M, row, g);
+        } else {
+            c16_bias_act_hidden(a3, a.b[2], a.n[2], a.act[2], g);
+            f32x4 a4[T4];
+            c16_zero(a4);
+            c16_layer<T3, T4>(a3, a4, a.w[3], a.n[2], a.n[3], 0u, lds, tid, m, g);
+            c16_bias_act(a4, a.b[3], a.n[3], a.act[3], g);
+            c16_store(a4, a.y, a.y_stride, a.n[3], a.M, row, g);
         }
     }
 }
 
-// tile shapes instantiated: the reference's encoder (<= 96 -> <= 64) and MLP (<= 256 -> <= 160 -> <= 128 -> <= 32)
+// tile shapes instantiated: the reference's encoder (<= 80 -> <= 64, or <= 96 -> <= 64) and MLP (<= 256 -> <= 160 -> <= 128 -> <= 16,
+// hidden activations none / LeakyReLU / ReLU); anything else: hipErrorInvalidValue (the caller runs layer by layer)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
     const dim3 grid((uint32_t)((a.M + 127) / 128));
-    auto tiles = [](int n) { return (n + 31) / 32; };
-    if (a.n_layers == 2 && tiles(a.n[0]) <= 3 && tiles(a.n[1]) <= 2) {
-        hipLaunchKernelGGL((chain_kernel<3, 2, 0, 0>), grid, dim3(256), 0, s, a);
-    } else if (a.n_layers == 4 && tiles(a.n[0]) <= 8 && tiles(a.n[1]) <= 5 && tiles(a.n[2]) <= 4 && tiles(a.n[3]) <= 1) {
-        hipLaunchKernelGGL((chain_kernel<8, 5, 4, 1>), grid, dim3(256), 0, s, a);
+    auto cheap = [](int act) { return act == 0 || act == 1 || act == 3; };
+    if (a.n_layers == 2 && a.n[0] <= 80 && a.n[1] <= 64) {
+        hipLaunchKernelGGL((chain16_kernel<5, 4, 0, 0>), grid, dim3(512), 0, s, a);
+    } else if (a.n_layers == 2 && a.n[0] <= 96 && a.n[1] <= 64) {
+        hipLaunchKernelGGL((chain16_kernel<6, 4, 0, 0>), grid, dim3(512), 0, s, a);
+    } else if (a.n_layers == 4 && a.n[0] <= 256 && a.n[1] <= 160 && a.n[2] <= 128 && a.n[3] <= 16 && cheap(a.act[0]) && cheap(a.act[1]) &&
+               cheap(a.act[2])) {
+        hipLaunchKernelGGL((chain16_kernel<16, 10, 8, 1>), grid, dim3(512), 0, s, a);
     } else {
         return hipErrorInvalidValue;
     }

@@ -111,17 +111,31 @@ def test_mlp_chain_forward_shapes_and_errors():
     want = torch.tanh(F.linear(F.leaky_relu(F.linear(x, ok2[0].weight, ok2[0].bias)), ok2[1].weight, ok2[1].bias))
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-5)
-    ok4 = [Layer(45, 200, "elu", generator=g), Layer(200, 130, "relu", generator=g), Layer(130, 100, "leakyrelu", generator=g),
-           Layer(100, 3, None, generator=g)]
+    ok4 = [Layer(45, 200, None, generator=g), Layer(200, 130, "relu", generator=g), Layer(130, 100, "leakyrelu", generator=g),
+           Layer(100, 3, "elu", generator=g)]
     out4 = torch.empty(301, 3, device="cuda")
     eng.chain_forward(x, ok4, out4)
-    h = F.elu(F.linear(x, ok4[0].weight, ok4[0].bias))
+    h = F.linear(x, ok4[0].weight, ok4[0].bias)
     h = F.relu(F.linear(h, ok4[1].weight, ok4[1].bias))
     h = F.leaky_relu(F.linear(h, ok4[2].weight, ok4[2].bias))
-    want4 = F.linear(h, ok4[3].weight, ok4[3].bias)
+    want4 = F.elu(F.linear(h, ok4[3].weight, ok4[3].bias))
     torch.cuda.synchronize()
     np.testing.assert_allclose(out4.cpu().numpy(), want4.cpu().numpy(), rtol=2e-4, atol=2e-5)
     assert eng.chain_fits(ok2) and eng.chain_fits(ok4)
+    ok2b = [Layer(45, 90, "elu", generator=g), Layer(90, 64, "relu", generator=g)]             # the <= 96 -> <= 64 shape, full last tile
+    out2b = torch.empty(301, 64, device="cuda")
+    eng.chain_forward(x, ok2b, out2b)
+    want2b = F.relu(F.linear(F.elu(F.linear(x, ok2b[0].weight, ok2b[0].bias)), ok2b[1].weight, ok2b[1].bias))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out2b.cpu().numpy(), want2b.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    # the 4-layer kernel is built for none / LeakyReLU / ReLU on its hidden layers and <= 16 outputs: other nets run layer by layer
+    tanh_hidden = [Layer(45, 200, "tanh", generator=g)] + ok4[1:]
+    wide_head = ok4[:3] + [Layer(100, 20, None, generator=g)]
+    assert not eng.chain_fits(tanh_hidden) and not eng.chain_fits(wide_head)
+    with pytest.raises(_lib.RoverError, match="tile shapes"):
+        eng.chain_forward(x, tanh_hidden, out4)
+    with pytest.raises(_lib.RoverError, match="tile shapes"):
+        eng.chain_forward(x, wide_head, torch.empty(301, 20, device="cuda"))
     wide = [Layer(45, 120, "relu", generator=g), Layer(120, 33, "relu", generator=g)]          # 120 > 96: no built shape
     assert not eng.chain_fits(wide)
     with pytest.raises(_lib.RoverError, match="tile shapes"):
