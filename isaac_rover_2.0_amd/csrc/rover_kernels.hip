@@ -1029,22 +1029,51 @@ __global__ void __launch_bounds__(256) bucket_hist_kernel(const uint32_t* __rest
     for (uint32_t it = 0; it < BKT_ITEMS; ++it)
         if (bv[it] != 0xffffffffu) atomicAdd(&h[bv[it] >> low_bits], 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) counts[(size_t)i * n_blocks + blockIdx.x] = h[i];
+    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) counts[(size_t)blockIdx.x * n_buckets + i] = h[i];   // [block][bucket]: coalesced
 }
 
 // counts[bucket][block] -> exclusive prefix inside every bucket row (one workgroup per bucket) + the row total
-__global__ void __launch_bounds__(256) bucket_rowscan_kernel(uint32_t* __restrict__ counts, uint32_t n_blocks,
-                                                             uint32_t* __restrict__ bucket_tot) {
-    __shared__ uint32_t wl[4];
-    uint32_t* row = counts + (size_t)blockIdx.x * n_blocks;
-    const uint32_t per = (n_blocks + 255u) >> 8, first = threadIdx.x * per;
-    uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_blocks) ? row[first + j] : 0u;
-    uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
-    for (uint32_t j = 0; j < per; ++j) {
-        if (first + j < n_blocks) { const uint32_t c = row[first + j]; row[first + j] = run; run += c; }
+// counts [block][bucket] -> exclusive prefix over the BLOCKS, in place, and the bucket totals.  One workgroup per 16 buckets, 16 waves;
+// a wave takes 64 consecutive blocks of a 1 024-block tile: lane (kb = lane & 15, ph = lane >> 4) holds bucket kb of blocks b0 + 4 j + ph,
+// j < 16, in registers — one round of loads (four 64-byte rows per instruction), a register / cross-lane scan, one round of stores.
+// (The table was [bucket][block] with one workgroup scanning a row: the histogram's 720 k stores and the scatter's 720 k loads were
+// 4 bytes at a 4 KB stride; as [block][bucket] with one lane per bucket and 64 buckets per workgroup only 11 CUs worked: 10.6 us.)
+#define RSCAN_WAVES 16
+__global__ void __launch_bounds__(64 * RSCAN_WAVES) bucket_rowscan_kernel(uint32_t* __restrict__ counts, uint32_t n_blocks, uint32_t n_buckets,
+                                                                          uint32_t* __restrict__ bucket_tot) {
+    __shared__ uint32_t part[RSCAN_WAVES][16];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6, kb = lane & 15u, ph = lane >> 4;
+    const uint32_t k = blockIdx.x * 16u + kb;
+    const bool kin = k < n_buckets;
+    uint32_t carry = 0;                                              // rays of this bucket in the tiles before
+    for (uint32_t tile0 = 0; tile0 < n_blocks; tile0 += 64u * RSCAN_WAVES) {
+        const uint32_t b0 = tile0 + w * 64u + ph;                    // this lane's blocks: b0 + 4 j
+        uint32_t* __restrict__ p = counts + (size_t)b0 * n_buckets + (kin ? k : 0u);
+        uint32_t v[16], ex[16], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) v[j] = (kin && b0 + 4u * j < n_blocks) ? p[(size_t)(4u * j) * n_buckets] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) {
+            // blocks 4 j .. 4 j + 3 sit in the four lane groups: inclusive scan over ph, then this lane's exclusive share
+            uint32_t inc = v[j];
+            uint32_t o = (uint32_t)__shfl_up((int)inc, 16, 64); if (ph >= 1u) inc += o;
+            o = (uint32_t)__shfl_up((int)inc, 32, 64);          if (ph >= 2u) inc += o;
+            const uint32_t four = (uint32_t)__shfl((int)inc, 48 + (int)kb, 64);       // all four blocks of this j
+            ex[j] = sum + inc - v[j];
+            sum += four;
+        }
+        if (ph == 0u) part[w][kb] = sum;
+        __syncthreads();
+        uint32_t run = carry, total = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < RSCAN_WAVES; ++i) { const uint32_t c = part[i][kb]; run += i < w ? c : 0u; total += c; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j)
+            if (kin && b0 + 4u * j < n_blocks) p[(size_t)(4u * j) * n_buckets] = run + ex[j];
+        carry += total;
     }
-    if (threadIdx.x == 0) bucket_tot[blockIdx.x] = total;
+    if (w == 0 && ph == 0u && kin) bucket_tot[k] = carry;
 }
 
 // every block turns the bucket totals into bucket start offsets in LDS (n_buckets <= 4096: 16 values per thread);
@@ -1063,7 +1092,7 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
         for (uint32_t j = 0; j < per; ++j) {
             const uint32_t i = first + j;
             if (i < n_buckets) {
-                cur[i] = run + offsets[(size_t)i * n_blocks + blockIdx.x];
+                cur[i] = run + offsets[(size_t)blockIdx.x * n_buckets + i];
                 if (blockIdx.x == 0) bucket_base[i] = run;
                 run += bucket_tot[i];
             }
@@ -1463,7 +1492,7 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
     uint32_t* bucket_tot = block_sums;                 // [BKT_MAX]
     uint32_t* bucket_base = block_sums + BKT_MAX;      // [BKT_MAX + 1]
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table);
-    hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(n_buckets), dim3(256), 0, s, table, n_blocks, bucket_tot);
+    hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(blocks_for(n_buckets, 16)), dim3(64 * RSCAN_WAVES), 0, s, table, n_blocks, n_buckets, bucket_tot);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table,
                        bucket_tot, bucket_base, pairs);
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(256), 0, s, pairs, bucket_base, low_bits, sorted);
