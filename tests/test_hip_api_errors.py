@@ -122,6 +122,14 @@ def test_mlp_chain_forward_shapes_and_errors():
     torch.cuda.synchronize()
     np.testing.assert_allclose(out4.cpu().numpy(), want4.cpu().numpy(), rtol=2e-4, atol=2e-5)
     assert eng.chain_fits(ok2) and eng.chain_fits(ok4)
+    # a column slice at an odd float offset with an odd row stride: the 16-byte staging loads are only 4-byte aligned
+    big = (torch.rand(301, 51, generator=g) * 2 - 1).cuda()
+    xs = big[:, 3:48]
+    out_s = torch.empty(301, 33, device="cuda")
+    eng.chain_forward(xs, ok2, out_s)
+    want_s = torch.tanh(F.linear(F.leaky_relu(F.linear(xs, ok2[0].weight, ok2[0].bias)), ok2[1].weight, ok2[1].bias))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_s.cpu().numpy(), want_s.cpu().numpy(), rtol=2e-4, atol=2e-5)
     ok2b = [Layer(45, 90, "elu", generator=g), Layer(90, 64, "relu", generator=g)]             # the <= 96 -> <= 64 shape, full last tile
     out2b = torch.empty(301, 64, device="cuda")
     eng.chain_forward(x, ok2b, out2b)
