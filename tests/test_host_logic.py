@@ -323,3 +323,41 @@ def test_bench_parent_never_touches_the_gpu_runtime():
     assert "torch" not in names and "isaac_rover_amd" not in names and "numpy" not in names
     fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "launch_ranks")
     assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) for n in ast.walk(fn))
+
+
+def test_fastdiv_matches_integer_division(tmp_path):
+    """`make_fastdiv` / `FastDiv::div` (csrc/rover_internal.h, used by assemble_obs_kernel for i / W): the host half builds the
+    magic numbers, the device half is three integer instructions — restated here on the host and compared with `/` for divisors
+    around powers of two, the obs widths of the configs and the 32-bit extremes."""
+    import shutil
+    if not (shutil.which("g++") and os.path.isdir("/opt/rocm/include")):
+        pytest.skip("needs g++ and the ROCm headers")
+    src = tmp_path / "fd.cpp"
+    src.write_text(r'''
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include "rover_internal.h"
+int main() {
+    unsigned long long bad = 0;
+    const uint32_t ds[] = {1, 2, 3, 4, 5, 7, 41, 63, 64, 65, 124, 146, 150, 1000, 1750, 4099, 65535, 65536, 65537, 0x7fffffffu,
+                           0x80000000u, 0x80000001u, 0xfffffffeu, 0xffffffffu};
+    for (uint32_t d : ds) {
+        const rover::FastDiv f = rover::make_fastdiv(d);
+        for (uint64_t k = 0; k < 3000000; ++k) {
+            const uint32_t n = k < 1000000 ? (uint32_t)k : (k < 2000000 ? 0xffffffffu - (uint32_t)(k - 1000000) : (uint32_t)(k * 2654435761ull + 12345u));
+            const uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);              // __umulhi
+            const uint32_t q = (t + ((n - t) >> f.s1)) >> f.s2;
+            if (q != n / d) ++bad;
+        }
+    }
+    std::printf("%llu\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "fd"
+    inc = os.path.join(ROOT, "isaac_rover_2.0_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", inc, "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", str(exe), str(src)],
+                   check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True)
+    assert out.stdout.strip() == "0"
