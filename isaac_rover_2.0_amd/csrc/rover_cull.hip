@@ -334,19 +334,22 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
-        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint2 *__restrict__ queue,                                      \
+        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chs, uint32_t chr, uint2 *__restrict__ queue,                                      \
         const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, queue, rtab0, rtab1, out
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, chs, chr, queue, rtab0, rtab1, out
 
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
-    // XCD-aware order (blocks b, b + 8, ... run on one XCD): each XCD walks one contiguous eighth of the TERRAIN blocks
-    // [0, split) and then one contiguous eighth of the ROCKS blocks [split, n_blocks) — contiguous so that the ctab / rtab records
-    // it touches (a band of the map) stay in its own L2, an eighth of EACH map because a terrain ray costs about a third more
-    // than a rock ray (8 candidate pairs against 0.7): eighths of the whole sorted list left the rocks' XCDs idle at the end.
+
+    // XCD-aware order (blocks b, b + 8, ... run on one XCD): the TERRAIN blocks [0, split) are dealt to the XCDs in chunks of
+    // 2^chs consecutive blocks, round robin, then the ROCKS blocks [split, n_blocks) the same way (chunks of 2^chr).  Chunks, so that neighbouring bins
+    // (which share most of their triangles' ctab / rtab records) stay on one L2; round robin, because the cost of a ray depends on where
+    // it is — with one contiguous eighth of each map per XCD the slowest XCD finished 27 % after the fastest (per-XCD end times of a
+    // diagnostic build) and the launch takes as long as the slowest; terrain before rocks on every XCD, so that the cheap rays
+    // (0.7 candidate pairs against 8) are the ones that drain at the end.
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
     uint32_t lb;
-    if (j < t8) { lb = x * t8 + j; if (lb >= split) return; }
-    else { lb = split + x * r8 + (j - t8); if (lb >= n_blocks) return; }
+    if (j < t8) { lb = ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u)); if (lb >= split) return; }
+    else { const uint32_t jr = j - t8; lb = split + ((((jr >> chr) << 3) + x) << chr) + (jr & ((1u << chr) - 1u)); if (lb >= n_blocks) return; }
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
     const uint32_t i0 = wave * run;
@@ -509,10 +512,15 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     // the sorted list is all terrain rays, then all rock rays: blocks [0, split) are (all but one mixed block) terrain
     uint32_t split = blocks_for(blocks_for(a.n_terrain, a.run), 4);
     if (split > a.n_blocks) split = a.n_blocks;
-    const uint32_t t8 = blocks_for(split, 8), r8 = blocks_for(a.n_blocks - split, 8);
+    // chunks of blocks dealt round robin to the 8 XCDs, per XCD ceil(chunks / 8) chunks of each part.  Chunk size: 64 blocks (4 096
+    // runs) when a part has >= 100 chunks of them, smaller on small batches so that every XCD still gets >= 12 chunks
+    // (65 536 envs, one call: 4 / 8 / 16 / 32 blocks 0.584-0.596 ms, 64 blocks 0.579-0.581, 256 blocks 0.631; contiguous eighths 0.590-0.597)
+    auto chunk_shift = [](uint32_t blocks) { uint32_t c = 0; while (c < 6u && (blocks >> (c + 1u)) >= 100u) ++c; return c; };
+    const uint32_t chs = chunk_shift(split), chr = chunk_shift(a.n_blocks - split);
+    const uint32_t t8 = blocks_for(blocks_for(split, 1u << chs), 8) << chs, r8 = blocks_for(blocks_for(a.n_blocks - split, 1u << chr), 8) << chr;
     hipLaunchKernelGGL(cull_scan_kernel, dim3((t8 + r8) * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
-                       a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
+                       a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, chs, chr, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
                        reinterpret_cast<const RawTri*>(a.rtab1), a.out);
     return hipGetLastError();
 }
