@@ -334,9 +334,9 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
-        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chs, uint32_t chr, uint2 *__restrict__ queue,                                      \
+        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chs, uint32_t chr, uint32_t run_r, uint2 *__restrict__ queue,                                      \
         const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, chs, chr, queue, rtab0, rtab1, out
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, chs, chr, run_r, queue, rtab0, rtab1, out
 
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
 
@@ -352,9 +352,11 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     else { const uint32_t jr = j - t8; lb = split + ((((jr >> chr) << 3) + x) << chr) + (jr & ((1u << chr) - 1u)); if (lb >= n_blocks) return; }
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
-    const uint32_t i0 = wave * run;
+    // blocks [0, split) walk runs of `run` rays, the blocks behind them (the rocks part) runs of `run_r`
+    const uint32_t my_run = lb < split ? run : run_r;
+    const uint32_t i0 = lb < split ? wave * run : split * 4u * run + (wave - split * 4u) * run_r;
     if (i0 >= n_sorted) return;
-    const uint32_t n_run = min(run, n_sorted - i0);                  // <= 64
+    const uint32_t n_run = min(my_run, n_sorted - i0);               // <= 64
     // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
     // id rows ahead.  The rays' parameters come by scalar loads (s_load_dwordx8 through the ray id of lane r), requested one
     // ray ahead so that their latency passes under the previous ray's arithmetic.
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
 #pragma unroll 1
     for (int d = 0; d < CULL_RING; ++d)
         if (pf_heads) prefetch_row();
-    uint2* const qw = queue + (size_t)wave * run * 128u;     // the wave's region of the candidate queue
+    uint2* const qw = queue + (size_t)i0 * 128u;             // the wave's region of the candidate queue (128 entries per ray)
     uint32_t cused = 0;
     auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
         const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
@@ -507,11 +509,14 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     if (a.run > CULL_RUNMAX) a.run = CULL_RUNMAX;
     if (a.run == 0) a.run = 1;
-    const uint32_t n_waves = blocks_for(a.n_sorted, a.run);
-    a.n_blocks = blocks_for(n_waves, 4);
-    // the sorted list is all terrain rays, then all rock rays: blocks [0, split) are (all but one mixed block) terrain
+    // the sorted list is all terrain rays, then all rock rays: blocks [0, split) are (but for a few rays) terrain
+    // The rocks part comes last on every XCD and drains the launch: with runs of 32 there its waves live half as long and the
+    // machine empties faster at the end (last workgroup start to kernel end was 70 us of 580) — 0.575 -> 0.570 ms; 16: 0.581
+    const uint32_t run_r = a.run >= 64u ? 32u : a.run;
     uint32_t split = blocks_for(blocks_for(a.n_terrain, a.run), 4);
-    if (split > a.n_blocks) split = a.n_blocks;
+    const uint64_t covered = (uint64_t)split * 4u * a.run;
+    if (covered >= a.n_sorted) { split = blocks_for(blocks_for(a.n_sorted, a.run), 4); a.n_blocks = split; }
+    else a.n_blocks = split + blocks_for(blocks_for(a.n_sorted - (uint32_t)covered, run_r), 4);
     // chunks of blocks dealt round robin to the 8 XCDs, per XCD ceil(chunks / 8) chunks of each part.  Chunk size: 64 blocks (4 096
     // runs) when a part has >= 100 chunks of them, smaller on small batches so that every XCD still gets >= 12 chunks
     // (65 536 envs, one call: 4 / 8 / 16 / 32 blocks 0.584-0.596 ms, 64 blocks 0.579-0.581, 256 blocks 0.631; contiguous eighths 0.590-0.597)
@@ -520,7 +525,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const uint32_t t8 = blocks_for(blocks_for(split, 1u << chs), 8) << chs, r8 = blocks_for(blocks_for(a.n_blocks - split, 1u << chr), 8) << chr;
     hipLaunchKernelGGL(cull_scan_kernel, dim3((t8 + r8) * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
-                       a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, chs, chr, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
+                       a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, chs, chr, run_r, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
                        reinterpret_cast<const RawTri*>(a.rtab1), a.out);
     return hipGetLastError();
 }
