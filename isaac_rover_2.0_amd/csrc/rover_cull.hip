@@ -348,8 +348,15 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     // (0.7 candidate pairs against 8) are the ones that drain at the end.
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
     uint32_t lb;
-    if (j < t8) { lb = ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u)); if (lb >= split) return; }
-    else { const uint32_t jr = j - t8; lb = split + ((((jr >> chr) << 3) + x) << chr) + (jr & ((1u << chr) - 1u)); if (lb >= n_blocks) return; }
+    // (chs / chr = 31: one contiguous eighth per XCD — small batches, where a chunk would be too few bins to share anything)
+    if (j < t8) {
+        lb = chs == 31u ? x * t8 + j : ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u));
+        if (lb >= split) return;
+    } else {
+        const uint32_t jr = j - t8;
+        lb = split + (chr == 31u ? x * r8 + jr : ((((jr >> chr) << 3) + x) << chr) + (jr & ((1u << chr) - 1u)));
+        if (lb >= n_blocks) return;
+    }
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
     // blocks [0, split) walk runs of `run` rays, the blocks behind them (the rocks part) runs of `run_r`
@@ -517,12 +524,18 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const uint64_t covered = (uint64_t)split * 4u * a.run;
     if (covered >= a.n_sorted) { split = blocks_for(blocks_for(a.n_sorted, a.run), 4); a.n_blocks = split; }
     else a.n_blocks = split + blocks_for(blocks_for(a.n_sorted - (uint32_t)covered, run_r), 4);
-    // chunks of blocks dealt round robin to the 8 XCDs, per XCD ceil(chunks / 8) chunks of each part.  Chunk size: 64 blocks (4 096
-    // runs) when a part has >= 100 chunks of them, smaller on small batches so that every XCD still gets >= 12 chunks
+    // chunks of blocks dealt round robin to the 8 XCDs, per XCD ceil(chunks / 8) chunks of each part.  A chunk is 16 384 rays (64 blocks of
+    // 4 runs of 64: a few map rows of bins, which share most of their triangles) when that gives every XCD >= 12 chunks of the part;
+    // otherwise one contiguous eighth per XCD (4 096 envs, one call: chunks of 16 small blocks 0.112 ms, contiguous 0.104)
     // (65 536 envs, one call: 4 / 8 / 16 / 32 blocks 0.584-0.596 ms, 64 blocks 0.579-0.581, 256 blocks 0.631; contiguous eighths 0.590-0.597)
-    auto chunk_shift = [](uint32_t blocks) { uint32_t c = 0; while (c < 6u && (blocks >> (c + 1u)) >= 100u) ++c; return c; };
-    const uint32_t chs = chunk_shift(split), chr = chunk_shift(a.n_blocks - split);
-    const uint32_t t8 = blocks_for(blocks_for(split, 1u << chs), 8) << chs, r8 = blocks_for(blocks_for(a.n_blocks - split, 1u << chr), 8) << chr;
+    auto chunk_shift = [](uint32_t blocks, uint32_t run) {
+        uint32_t c = 0;
+        while ((4u * run << c) < 16384u) ++c;                        // blocks per chunk = 2^c
+        return (blocks >> c) >= 96u ? c : 31u;
+    };
+    const uint32_t chs = chunk_shift(split, a.run), chr = chunk_shift(a.n_blocks - split, run_r);
+    const uint32_t t8 = chs == 31u ? blocks_for(split, 8) : blocks_for(blocks_for(split, 1u << chs), 8) << chs;
+    const uint32_t r8 = chr == 31u ? blocks_for(a.n_blocks - split, 8) : blocks_for(blocks_for(a.n_blocks - split, 1u << chr), 8) << chr;
     hipLaunchKernelGGL(cull_scan_kernel, dim3((t8 + r8) * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
                        a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, chs, chr, run_r, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
