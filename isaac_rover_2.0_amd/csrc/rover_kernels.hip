@@ -1123,6 +1123,37 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
     if (s1 <= s0) return;
     for (uint32_t i = tid; i < nl; i += 256) h[i] = 0;
     __syncthreads();
+    if (s1 - s0 <= 64u * 256u) {
+        // The usual bucket (6-12 k rays): ONE pass of LDS atomics.  A thread keeps its <= 64 items in registers with the rank the
+        // histogram atomic returned (rank inside the bin), so after the scan the position is start[bin] + rank — no second read of
+        // the pairs and no second round of atomics.
+        uint32_t slot[64], br[64];                                   // br = low bin bits | rank << 12
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            uint2 pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u; pv[j] = k < s1 ? pairs[k] : make_uint2(0u, 0xffffffffu); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u, lo = pv[j].x & mask;
+                slot[8 * g + j] = pv[j].y;
+                br[8 * g + j] = k < s1 ? (lo | (atomicAdd(&h[lo], 1u) << 12)) : 0u;
+            }
+        }
+        __syncthreads();
+        const uint32_t per = nl >> 8, first = tid * per;
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; ++j) sum += h[first + j];
+        uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
+        for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t k = s0 + tid + (uint32_t)i * 256u;
+            if (k < s1) sorted[s0 + h[br[i] & 0xfffu] + (br[i] >> 12)] = slot[i];
+        }
+        return;
+    }
     // eight loads in flight per thread before their atomics: the kernel waits on memory 93 % of the time otherwise
     for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
         uint32_t bx[8];
