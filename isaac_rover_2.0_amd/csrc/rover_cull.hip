@@ -257,10 +257,13 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
                                            const uint2* qw, uint32_t n, uint32_t gid /* per lane: ray id of run position `lane` */,
                                            uint32_t lane, uint32_t* bk) {
+    // The queue entries are read one round ahead: a round then waits for ONE memory round trip (the gathers its entries
+    // address: two triangle records and the ray, 72 bytes per lane), not two.
+    if (n == 0u) return;
+    uint2 en_next = qw[min(lane, n - 1u)];
     for (uint32_t base = 0; base < n; base += 64u) {                // wave-uniform
-        const uint32_t e = base + lane;
-        const bool live = e < n;
-        const uint2 en = qw[live ? e : base];
+        const bool live = base + lane < n;
+        const uint2 en = en_next;
         const uint32_t map = en.x >> 31, pos = en.y >> 26;
         const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
         const RawTri* rt = map ? rtab1 : rtab0;
@@ -268,6 +271,7 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
         const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
         const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
+        if (base + 64u < n) en_next = qw[min(base + 64u + lane, n - 1u)];
         const float qnan = __builtin_nanf("");
         f2 v[9];
 #pragma unroll
