@@ -95,6 +95,26 @@ def test_raycast_variants_bit_identical(dist_name, num_envs, k):
         eng.close()
 
 
+def test_crowded_cell_variants_bit_identical():
+    """All 4 096 envs stand on the same spot (two poses): a handful of (map, cell) bins hold every ray — one coarse bucket of
+    150 k rays (the bucket sort's general path, past the 16 384 rays its one-pass path takes), runs that never leave a bin, bins
+    that span hundreds of runs.  Variants 3 and 2 must still agree with variant 1 bit for bit."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    num_envs = 4096
+    scene = synth.make_scene(n_cells=64, k=40, n_stones=24)
+    distn = synth.ray_distribution("37")
+    one = synth.make_states(2, 6.4, seed=5)
+    st = {k: v[torch.arange(num_envs) % 2].clone() for k, v in one.items()}
+    ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
+    for variant in (3, 2):
+        eng = make_engine(scene, distn, num_envs, variant=variant)
+        got = hip_step(eng, st)
+        for key in ref:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant}")
+        eng.close()
+
+
 def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
     """ray_precision 1: origins / directions rounded to fp16 like the reference as shipped, f32 maths after."""
     from hip_helpers import hip_step, make_engine
