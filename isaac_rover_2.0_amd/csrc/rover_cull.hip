@@ -381,14 +381,20 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     __shared__ int4 s_ids[4][CULL_RING][64];
     uint64_t pf_heads = heads;                 // bins whose row is not requested yet
     uint32_t pf_n = 0, use_n = 0;              // rows requested / consumed so far (slot = count % CULL_RING)
+    // Per ray, for all 64 at once: the address of its bin's id row and the bin's normal cone (the cell's q as a 16-bit fraction,
+    // 0 = none) — a bin then costs two v_readlane for its row address and one for its cone instead of a chain of scalar selects,
+    // a 64-bit multiply and an LDS read per bin.
+    const uint32_t kmap = key >> 31, kcell = key & 0x7fffffffu, kL = (kmap ? kp1 : kp0) >> 2;
+    const uint64_t row_addr = reinterpret_cast<uint64_t>(kmap ? idx1 : idx0) + (uint64_t)kcell * kL * 16ull;
+    const uint32_t q16v = (kmap ? qrow1 : qrow0)[kcell].x;
     auto prefetch_row = [&]() {
         const uint32_t j = (uint32_t)__builtin_ctzll(pf_heads);
         pf_heads &= pf_heads - 1ull;
-        const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j);
-        const uint32_t c2 = k2 & 0x7fffffffu, m2 = k2 >> 31, L2 = (m2 ? kp1 : kp0) >> 2;
+        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) >> 31, L2 = (m2 ? kp1 : kp0) >> 2;
+        const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)row_addr, (int)j) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(row_addr >> 32), (int)j) << 32);
         // lanes past K (K8 < 256) repeat the last lane's triangles: a duplicate candidate cannot change a min
-        const int4* src = (m2 ? idx1 : idx0) + (size_t)c2 * L2 + (lane < L2 ? lane : L2 - 1u);
-        if (lane == 63u && L2 < 64u) src = reinterpret_cast<const int4*>((m2 ? qrow1 : qrow0) + c2);   // slot 63: the cell's q
+        const char* src = reinterpret_cast<const char*>(base) + ((lane < L2 ? lane : L2 - 1u) << 4);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
         ++pf_n;
@@ -415,8 +421,8 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         wave_lds_sync();
         const uint32_t L = (map ? kp1 : kp0) >> 2;
         const int4 id4 = s_ids[w][use_n % CULL_RING][lane < L ? lane : L - 1u];
-        // the cell's normal cone as a 16-bit fraction (0: none; K8 = 256 leaves no slot for it)
-        const uint32_t q16 = L < 64u ? (uint32_t)__builtin_amdgcn_readfirstlane(s_ids[w][use_n % CULL_RING][63].x) : 0u;
+        // the cell's normal cone as a 16-bit fraction (0: none)
+        const uint32_t q16 = (uint32_t)__builtin_amdgcn_readlane((int)q16v, (int)i);
         ++use_n;
         const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
         const uint4* ct = map ? ctab1 : ctab0;
