@@ -286,16 +286,10 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
         const uint64_t none[1][2] = {{0, 0}};
         const float best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
                                          f2{rb.z, rb.z}, none, 0u);
-        // segmented min over the lanes with the same ray (contiguous); dead lanes carry a position no live lane has
-        uint32_t k = live ? fkey(best) : 0xffffffffu;
-        const uint32_t seg = live ? pos : 64u + lane;
-#pragma unroll
-        for (uint32_t off = 1; off < 64u; off <<= 1) {
-            const uint32_t ok = (uint32_t)__shfl_down((int)k, off, 64), os = (uint32_t)__shfl_down((int)seg, off, 64);
-            if (lane + off < 64u && os == seg) k = ok < k ? ok : k;
-        }
-        const uint32_t ps = (uint32_t)__shfl_up((int)seg, 1, 64);
-        if (live && (lane == 0u || ps != seg)) atomicMin(bk + pos, k);
+        // the ray's running min lives in LDS as an ordered-u32 key: only lanes that HIT something take part (a ray meets 1-3 of
+        // its ~16 candidates), so the atomic sees a handful of lanes — cheaper than a segmented wave min over all 64 first
+        const uint32_t k = fkey(best);
+        if (live && k < fkey(RAY_MISS)) atomicMin(bk + pos, k);
     }
 }
 
