@@ -381,14 +381,16 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const uint32_t kmap = key >> 31, kcell = key & 0x7fffffffu, kL = (kmap ? kp1 : kp0) >> 2;
     const uint64_t row_addr = reinterpret_cast<uint64_t>(kmap ? idx1 : idx0) + (uint64_t)kcell * kL * 16ull;
     const uint32_t q16v = (kmap ? qrow1 : qrow0)[kcell].x;
+    // this lane's slot in an id row of either map (lanes past K8 / 4 repeat the last one), as a byte offset
+    const uint32_t lo0 = min(lane, (kp0 >> 2) - 1u) << 4, lo1 = min(lane, (kp1 >> 2) - 1u) << 4;
     auto prefetch_row = [&]() {
         const uint32_t j = (uint32_t)__builtin_ctzll(pf_heads);
         pf_heads &= pf_heads - 1ull;
-        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) >> 31, L2 = (m2 ? kp1 : kp0) >> 2;
+        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) >> 31;
         const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)row_addr, (int)j) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(row_addr >> 32), (int)j) << 32);
         // lanes past K (K8 < 256) repeat the last lane's triangles: a duplicate candidate cannot change a min
-        const char* src = reinterpret_cast<const char*>(base) + ((lane < L2 ? lane : L2 - 1u) << 4);
+        const char* src = reinterpret_cast<const char*>(base) + (m2 ? lo1 : lo0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
         ++pf_n;
@@ -413,8 +415,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
-        const uint32_t L = (map ? kp1 : kp0) >> 2;
-        const int4 id4 = s_ids[w][use_n % CULL_RING][lane < L ? lane : L - 1u];
+        const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[w][use_n % CULL_RING][0]) + (map ? lo1 : lo0));
         // the cell's normal cone as a 16-bit fraction (0: none)
         const uint32_t q16 = (uint32_t)__builtin_amdgcn_readlane((int)q16v, (int)i);
         ++use_n;
