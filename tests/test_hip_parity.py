@@ -73,7 +73,7 @@ def test_step_matches_oracle(dist_name, num_envs, seed):
 
 
 @pytest.mark.parametrize("dist_name,num_envs,k", [("37", 4096, 24), ("120", 512, 200), ("9", 300, 7), ("37", 700, 100),
-                                                  ("9", 200, 16)])
+                                                  ("9", 200, 16), ("37", 600, 256), ("37", 300, 250)])   # 256 / 250: a full id row (64 lanes x 4)
 def test_raycast_variants_bit_identical(dist_name, num_envs, k):
     """Variant 1 (half-wave per ray, env order), variant 2 (rays binned by cell, shared-reciprocal IEEE division,
     any run length, early out on or off) and variant 3 (culled: bounding-sphere / normal test first, exact arithmetic on the
