@@ -36,6 +36,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -80,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--debug-timing", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     ap.add_argument("--scene-cache", default=os.environ.get("ROVER_SCENE_CACHE", ""))
+    ap.add_argument("--rank-timeout-s", type=float, default=900.0,
+                    help="N > 1 self-launch: kill every rank and exit 124 when the run has not finished after this many seconds")
     return ap.parse_args(argv)
 
 
@@ -93,39 +96,51 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
-    """Spawn ``n`` rank processes of this script, relay rank 0's JSON line to stdout; returns the exit code."""
+def launch_ranks(n, argv, rank_timeout_s=900.0, poll_s=0.2):
+    """Spawn ``n`` rank processes of this script, relay rank 0's JSON line to stdout; returns the exit code.
+
+    All children are watched together: the first one that exits non-zero (or the overall ``rank_timeout_s``) ends the run — the
+    others are killed (exactly the PIDs started here) instead of being left blocked in a collective or in RCCL's rendezvous."""
     child = os.environ.get("ROVER_BENCH_CHILD", os.path.abspath(__file__))      # tests substitute a stand-in engine here
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL between processes on this host
-        procs.append(subprocess.Popen([sys.executable, child] + list(argv), env=env, text=True,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = ""
+    out0 = tempfile.TemporaryFile(mode="w+")         # rank 0's stdout: a file, so a long line can never block the child on a full pipe
     rc = 0
+    t_start = time.time()
     try:
-        out0, _ = procs[0].communicate()
-        # rank 0 ends last by construction (final barrier), but a crashed peer must not leave the others hanging
-        deadline = time.time() + 60.0
-        for p in procs[1:]:
-            try:
-                p.wait(timeout=max(1.0, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                pass
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL between processes on this host
+            procs.append(subprocess.Popen([sys.executable, child] + list(argv), env=env, text=True,
+                                          stdout=out0 if r == 0 else sys.stderr))
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                for r, c in bad:
+                    print(f"bench.py: rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
+                rc = bad[0][1] if bad[0][1] > 0 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t_start > rank_timeout_s:
+                alive = [r for r, c in enumerate(codes) if c is None]
+                print(f"bench.py: ranks {alive} still running after --rank-timeout-s {rank_timeout_s:.0f}; killing them", file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(poll_s)
     finally:
-        for r, p in enumerate(procs):
+        for p in procs:
             if p.poll() is None:
                 p.kill()                     # exactly the PIDs started above
                 p.wait()
                 rc = rc or 1
-            elif p.returncode != 0:
-                print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
-                rc = rc or (p.returncode if p.returncode > 0 else 1)
-    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
-    for ln in out0.splitlines():
+    out0.seek(0)
+    text = out0.read()
+    out0.close()
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    for ln in text.splitlines():
         if not ln.startswith("{"):
             print(ln, file=sys.stderr)
     if rc == 0 and len(lines) != 1:
@@ -515,7 +530,7 @@ def main(argv=None):
     args = parse(argv)
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and (world_env is None or (world_env == "1" and "RANK" not in os.environ)):
-        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv)
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv, rank_timeout_s=args.rank_timeout_s)
     return run_rank(args)
 
 

@@ -157,6 +157,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // a
 
 template <int T, int ACT>
 __device__ __forceinline__ void c16_bias_act_as(f32x4 (&acc)[T], const float* __restrict__ bias, int n_valid, uint32_t g) {
+    n_valid = n_valid < 0 ? 0 : n_valid;          // a half past the layer's width (n[0] < 128 in the 4-layer chain): all lanes invalid
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -181,6 +182,7 @@ __device__ __forceinline__ void c16_bias_act(f32x4 (&acc)[T], const float* __res
 template <int T>
 __device__ __forceinline__ void c16_bias_act_hidden(f32x4 (&acc)[T], const float* __restrict__ bias, int n_valid, int act, uint32_t g) {
     const float slope = act == 1 ? 0.01f : (act == 3 ? 0.0f : 1.0f);
+    n_valid = n_valid < 0 ? 0 : n_valid;          // second half of a first layer narrower than 128: no bias read, every value 0
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll

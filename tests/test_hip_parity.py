@@ -774,6 +774,37 @@ def test_policy_forward_matches_torch_fp32(num_envs, ns, nd):
     eng.close()
 
 
+@pytest.mark.parametrize("mlp", [(64, 48, 32), (100, 37, 20), (128, 160, 128), (129, 16, 5)])
+def test_fused_chain_narrow_and_odd_widths(mlp):
+    """The 4-layer chain computes its first layer in two halves of 128 features: a first hidden width below 128 leaves the second
+    half empty (no bias read past the tensor, every value 0).  The bias tensors sit at the END of NaN-filled buffers, so a read past
+    them returns NaN and poisons the row.  Fused vs one launch per layer vs PyTorch fp32."""
+    from isaac_rover_amd import _lib
+    from isaac_rover_amd.learning.model import HeightmapNet
+    eng = _lib.Engine(8, device=0)
+    ns, nd, rows = 37, 0, 300
+    w = 4 + ns + nd
+    g = torch.Generator().manual_seed(9)
+    states = (torch.rand(rows, w, generator=g) * 4 - 1).cuda()
+    net = HeightmapNet(eng, w, ns, nd, 2, "tanh", mlp_features=mlp, encoder_features=(50, 33), device="cuda:0", seed=4)
+    for layer in net.encoder0 + net.encoder1 + net.network:      # bias as the tail of a NaN buffer: bias[n + i] is NaN
+        n = layer.bias.numel()
+        if n == 0:
+            continue
+        buf = torch.full((n + 512,), float("nan"), device="cuda:0")
+        buf[:n] = layer.bias
+        layer.bias = buf[:n]
+        layer._keep = buf
+    assert eng.chain_fits(net.network) and eng.chain_fits(net.encoder0)
+    want = _torch_net_reference(net, states)
+    for fused in (False, True):
+        got = net.compute(states, fused=fused)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(got).all()), f"fused={fused}: non-finite output (a read past a bias tensor)"
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=f"fused={fused}")
+    eng.close()
+
+
 @pytest.mark.parametrize("act", ["none", "leakyrelu", "tanh", "relu", "elu"])
 def test_linear_forward_shapes_and_activations(act):
     from isaac_rover_amd import _lib

@@ -4,6 +4,7 @@ import os
 import re
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -283,14 +284,28 @@ def test_bench_self_launch_gloo(tmp_path, extra):
 
 
 def test_bench_self_launch_reports_a_failed_rank(tmp_path):
-    """A rank that dies makes the parent exit non-zero without a JSON line (and without hanging on the survivors)."""
+    """A rank that dies makes the parent exit non-zero without a JSON line — at once, although rank 0 would block FOREVER (a rank
+    stuck in RCCL's rendezvous or in a collective whose peer is gone): every child is watched, the survivors are killed."""
     script = tmp_path / "bad_worker.py"
-    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(2)\nprint('{}')\n")
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    time.sleep(1)\n    sys.exit(7)\ntime.sleep(3600)\nprint('{}')\n")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(ROVER_BENCH_CHILD=str(script))
+    t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode == 7 and p.stdout.strip() == "" and "rank 1 exited with code 7" in p.stderr
+    assert time.time() - t0 < 60, "the parent waited for a rank that can never finish"
+
+
+def test_bench_self_launch_rank_timeout(tmp_path):
+    """--rank-timeout-s: ranks that neither finish nor fail are killed and the parent exits 124 without a JSON line."""
+    script = tmp_path / "stuck_worker.py"
+    script.write_text("import time\ntime.sleep(3600)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ROVER_BENCH_CHILD=str(script))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-timeout-s", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 124 and p.stdout.strip() == "" and "still running after --rank-timeout-s" in p.stderr
 
 
 def test_bench_under_torchrun_env_does_not_spawn(tmp_path):
