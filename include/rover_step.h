@@ -285,6 +285,20 @@ typedef struct {
     int32_t raycast_variant;       /* the variant the next step will run (1, 2 or 3) */
 } rover_info;
 ROVER_API int rover_get_info(const rover_ctx *ctx, rover_info *info);
+/* Diagnostics of the culled ray cast (variant 3, csrc/rover_cull.hip).  Per map: how many triangles its conservative
+ * rejection test can never reject (slivers, non-finite vertices: stored with a zero normal = "always a candidate") and how
+ * many cells have no normal cone (their rays run both tests on every pair).  Of the LAST culled launch on this ctx: rays
+ * scanned, (ray, lane-pair) candidates handed to the exact arithmetic (camera.py:84-117 evaluated K per ray), rays that ran
+ * both tests, (map, cell) bins walked.  Synchronises the device (a test / bench call, not a step call). */
+typedef struct {
+    int64_t triangles[2];
+    int64_t always_candidate_triangles[2];
+    int64_t cells_without_cone[2];
+    uint64_t rays, candidate_pairs, rays_both_tests, bins;
+    uint64_t max_pairs_per_run;    /* most queue entries any one run of sorted rays produced */
+    uint64_t queue_bytes;          /* size of the candidate queue allocation */
+} rover_cull_info;
+ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with
  * hipEvents on the caller's stream (ring of 256 pairs).  rover_get_profile synchronises those events and
  * returns the summed ray-cast time and launch count since the last rover_set_profiling(ctx, 1). */

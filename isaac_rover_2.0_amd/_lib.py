@@ -58,6 +58,12 @@ class Info(C.Structure):
                 ("table_bytes", C.c_uint64 * 2), ("workspace_bytes", C.c_uint64), ("raycast_variant", C.c_int32)]
 
 
+class CullInfo(C.Structure):
+    _fields_ = [("triangles", C.c_int64 * 2), ("always_candidate_triangles", C.c_int64 * 2), ("cells_without_cone", C.c_int64 * 2),
+                ("rays", C.c_uint64), ("candidate_pairs", C.c_uint64), ("rays_both_tests", C.c_uint64), ("bins", C.c_uint64),
+                ("max_pairs_per_run", C.c_uint64), ("queue_bytes", C.c_uint64)]
+
+
 class ResetIO(C.Structure):
     _fields_ = [("reset_ids", C.c_void_p), ("n_reset_dev", C.c_void_p), ("n_reset_host", C.c_int32),
                 ("initial_pos3", C.c_void_p), ("pos3", C.c_void_p), ("quat4", C.c_void_p), ("joint_pos13", C.c_void_p),
@@ -97,6 +103,7 @@ SYMBOLS = {
     "rover_pre_physics_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rover_ackermann": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
+    "rover_get_cull_info": (C.c_int, [_P, C.POINTER(CullInfo)]),
     "rover_replay_raycast": (C.c_int, [_P, _P]),
     "rover_build_knn_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "rover_build_knn_map_ref": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
@@ -112,7 +119,8 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_mlp.hip", "rover_internal.h", "build.sh")]
+    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_cull.hip", "rover_mlp.hip", "rover_internal.h",
+                                             "rover_raymath.h", "build.sh")]
     srcs.append(os.path.join(os.path.dirname(_CSRC), "..", "include", "rover_step.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -246,6 +254,15 @@ class Engine:
         i = Info()
         self._check(self.lib.rover_get_info(self._h, C.byref(i)), "rover_get_info")
         return i
+
+    def cull_info(self):
+        """Diagnostics of the culled ray cast (rover_get_cull_info) as a dict; synchronises the device."""
+        i = CullInfo()
+        self._check(self.lib.rover_get_cull_info(self._h, C.byref(i)), "rover_get_cull_info")
+        d = {k: (list(getattr(i, k)) if k in ("triangles", "always_candidate_triangles", "cells_without_cone") else int(getattr(i, k)))
+             for k, _ in CullInfo._fields_}
+        d["pairs_per_ray"] = d["candidate_pairs"] / d["rays"] if d["rays"] else 0.0
+        return d
 
     # ---- step ---------------------------------------------------------------------------------
     def _chk(self, t, shape, dtype, name):

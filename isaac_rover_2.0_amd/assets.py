@@ -153,3 +153,13 @@ def generate_knn_triangles(engine, terrain_dir: str, res_x: int = 600, res_y: in
         torch.save(m.triangles.to(torch.int32), os.path.join(d, "triangles.pt"))
         out[sub] = m
     return out
+
+
+def build_irregular_scene(engine, spec, k: int = 200, ranking: str = "exact_f32"):
+    """A ``synth.IrregularSpec`` scene whose two KNN maps are built on the GPU by ``rover_build_knn_map`` (terrain: the whole
+    mesh = ``map.ply``; rocks: its rocks-only sub-mesh = ``big_stones.ply``, rover_utils.py:48-50) -> (Scene, height function)."""
+    from . import synth
+    verts, tris, rock_tris, _stones = synth.irregular_mesh(spec)
+    n_x, n_y = int(round(spec.extent_x / 0.1)), int(round(spec.extent_y / 0.1))
+    maps = [engine.build_knn_map(verts, t, n_x, n_y, 0.1, k, ranking=ranking).cpu() for t in (tris, rock_tris)]
+    return synth.make_irregular_scene(spec, k, maps[0], maps[1])

@@ -30,6 +30,9 @@ struct rover_ctx {
     uint64_t cull_bytes[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast (worst case: 128 entries per ray)
     uint64_t cull_entries = 0;
+    uint4* d_cull_stats = nullptr;      // per-wave counters of the last culled launch (rover_get_cull_info)
+    uint32_t cull_stat_slots = 0;
+    int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
     bool cull_queue_failed = false;     // the worst-case queue does not fit (huge E x rays): the binned kernel runs instead
     uint32_t cull_run = 0;              // run length the queue was sized for
     // distribution
@@ -209,6 +212,10 @@ static int alloc_cull_queue(rover_ctx* c) {
         return ROVER_OK;
     }
     c->cull_entries = entries; c->cull_run = run;
+    dfree(c->d_cull_stats);
+    c->cull_stat_slots = rover::cull_stat_slots(valid_rays(c), run);
+    HIP_TRY(c, hipMalloc((void**)&c->d_cull_stats, (size_t)c->cull_stat_slots * sizeof(uint4)));
+    HIP_TRY(c, hipMemset(c->d_cull_stats, 0, (size_t)c->cull_stat_slots * sizeof(uint4)));
     return ROVER_OK;
 }
 
@@ -280,7 +287,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
-    dfree(c->d_cull_queue);
+    dfree(c->d_cull_queue); dfree(c->d_cull_stats);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -323,6 +330,8 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint16_t* d_rtab = nullptr;
     uint4* d_qrow = nullptr;
     float* d_nz = nullptr;
+    uint32_t* d_cnt = nullptr;
+    uint32_t h_cnt[2] = {0, 0};
     uint64_t cull_bytes = 0;
     if (K8 <= 256 && (uint32_t)T < 0x3ffffffu) {
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t), b_ct = (uint64_t)T * sizeof(uint4), b_rt = (uint64_t)T * 20u;
@@ -330,15 +339,19 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint4))) != hipSuccess ||
             (e = hipMalloc((void**)&d_nz, (uint64_t)T * sizeof(float))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_cnt, 2 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMemset(d_cnt, 0, 2 * sizeof(uint32_t))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, (uint32_t)V, d_cidx, d_ctab, d_rtab,
-                                   d_qrow, d_nz, nullptr)) != hipSuccess ||
-            (e = hipDeviceSynchronize()) != hipSuccess) {
-            cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_qrow); dfree(d_nz); dfree(d_table);
+                                   d_qrow, d_nz, d_cnt, nullptr)) != hipSuccess ||
+            (e = hipDeviceSynchronize()) != hipSuccess ||
+            (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
+            cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_qrow); dfree(d_nz); dfree(d_cnt); dfree(d_table);
             return fail(c, ROVER_E_HIP, "set_knn_map: cull tables (%llu B): %s", (unsigned long long)cull_bytes, hipGetErrorString(e));
         }
     }
     cleanup();
-    dfree(d_nz);
+    dfree(d_nz); dfree(d_cnt);
+    c->cull_always[which] = h_cnt[0]; c->cull_nocone[which] = h_cnt[1]; c->cull_tris[which] = T;
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
@@ -492,6 +505,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.run = effective_run(c);
     a.out = c->d_dist_out;
     a.queue = c->d_cull_queue;
+    a.stats = c->d_cull_stats;
     return a;
 }
 
@@ -508,7 +522,9 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
     p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading; p.env_rec = c->d_env_rec;
     const int variant = effective_variant(c);
-    if (variant == 3) { if (int r = alloc_cull_queue(c)) return r; }
+    // (the queue is sized by every call that changes its size — never here: no hipMalloc inside a step / a stream capture)
+    if (variant == 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
+        return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
     if (variant >= 2) p.bin_out = c->d_bins;
@@ -774,6 +790,27 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
     return ROVER_OK;
 }
 
+int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
+    if (!c || !out) return ROVER_E_INVALID;
+    memset(out, 0, sizeof *out);
+    for (int w = 0; w < 2; ++w) {
+        out->triangles[w] = c->cull_tris[w];
+        out->always_candidate_triangles[w] = c->cull_always[w];
+        out->cells_without_cone[w] = c->cull_nocone[w];
+    }
+    out->queue_bytes = c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0;
+    if (!c->d_cull_stats || c->last_variant != 3) return ROVER_OK;
+    USE_DEVICE(c);
+    HIP_TRY(c, hipDeviceSynchronize());
+    std::vector<uint4> h(c->cull_stat_slots);
+    HIP_TRY(c, hipMemcpy(h.data(), c->d_cull_stats, h.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    for (const uint4& v : h) {
+        out->candidate_pairs += v.x; out->rays += v.y; out->rays_both_tests += v.z; out->bins += v.w;
+        out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
+    }
+    return ROVER_OK;
+}
+
 // IEEE binary16 <-> binary32 on the host (round to nearest even), for the reference-ranking coordinate tables
 static float half_bits_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
@@ -831,8 +868,8 @@ static int build_knn_map_impl(rover_ctx* c, const float* vertices, int32_t V, co
     USE_DEVICE(c);
     float *d_v = nullptr, *d_cx = nullptr, *d_cy = nullptr, *d_cell = nullptr;
     int32_t *d_t = nullptr, *d_over = nullptr;
-    uint32_t *d_cur = nullptr, *d_items = nullptr, *d_bs = nullptr;
-    auto cleanup = [&]() { dfree(d_v); dfree(d_cx); dfree(d_cy); dfree(d_t); dfree(d_over); dfree(d_cur); dfree(d_items); dfree(d_bs); dfree(d_cell); };
+    uint32_t *d_cur = nullptr, *d_items = nullptr, *d_bs = nullptr, *d_start = nullptr;
+    auto cleanup = [&]() { dfree(d_v); dfree(d_cx); dfree(d_cy); dfree(d_t); dfree(d_over); dfree(d_cur); dfree(d_items); dfree(d_bs); dfree(d_cell); dfree(d_start); };
 #define KNN_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e__ = (expr);                                                                          \
@@ -873,24 +910,33 @@ static int build_knn_map_impl(rover_ctx* c, const float* vertices, int32_t V, co
     const double area = ((double)x1 - x0 + 1e-6) * ((double)y1 - y0 + 1e-6);
     double gsz = std::sqrt(area * (double)K / (4.0 * (double)T));
     if (gsz < (double)res) gsz = (double)res;
-    uint32_t nbx = (uint32_t)(((double)x1 - x0) / gsz) + 1, nby = (uint32_t)(((double)y1 - y0) / gsz) + 1;
-    while ((uint64_t)nbx * nby > (1u << 22)) { gsz *= 2.0; nbx = (uint32_t)(((double)x1 - x0) / gsz) + 1; nby = (uint32_t)(((double)y1 - y0) / gsz) + 1; }
-    const float g = (float)gsz, inv_g = 1.0f / g;
-    const uint32_t nb = nbx * nby;
-    KNN_TRY(hipMalloc((void**)&d_cur, ((size_t)nb + 1) * sizeof(uint32_t)));
-    KNN_TRY(hipMemset(d_cur, 0, ((size_t)nb + 1) * sizeof(uint32_t)));
-    KNN_TRY(launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 1, nullptr));
-    KNN_TRY(launch_scan_exclusive(d_cur, nb + 1, d_bs, nullptr));
-    uint32_t* d_start = nullptr;
-    KNN_TRY(hipMalloc((void**)&d_start, ((size_t)nb + 1) * sizeof(uint32_t)));
-    hipError_t e2 = hipMemcpy(d_start, d_cur, ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice);
-    if (e2 == hipSuccess) e2 = launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 0, nullptr);
-    if (e2 == hipSuccess) e2 = launch_knn_select(d_cx, d_cy, d_start, d_items, x0, y0, g, nbx, nby, (uint32_t)X, (uint32_t)Y, res,
-                                                 (uint32_t)K, d_cell, d_cell ? d_cell + X : nullptr, map_idx_out, d_over, nullptr);
-    if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+    // A cell's search gathers whole rings of buckets into LDS (8192 candidates at most).  On a strongly non-uniform mesh (a
+    // decimated terrain: millimetre triangles on the rocks, metre-sized ones between them) a ring sized for the MEAN density can
+    // hold more than that next to a dense patch: the bucket edge is halved and the search repeated (same result: the ranking
+    // does not depend on the bucket size).
+    hipError_t e2 = hipSuccess;
     int32_t over = 0;
-    if (e2 == hipSuccess) e2 = hipMemcpy(&over, d_over, sizeof over, hipMemcpyDeviceToHost);
-    dfree(d_start);
+    for (int attempt = 0; attempt < 6; ++attempt, gsz *= 0.5) {
+        uint32_t nbx = (uint32_t)(((double)x1 - x0) / gsz) + 1, nby = (uint32_t)(((double)y1 - y0) / gsz) + 1;
+        while ((uint64_t)nbx * nby > (1u << 22)) { gsz *= 2.0; nbx = (uint32_t)(((double)x1 - x0) / gsz) + 1; nby = (uint32_t)(((double)y1 - y0) / gsz) + 1; attempt = 99; }
+        const float g = (float)gsz, inv_g = 1.0f / g;
+        const uint32_t nb = nbx * nby;
+        dfree(d_cur); dfree(d_start);
+        KNN_TRY(hipMalloc((void**)&d_cur, ((size_t)nb + 1) * sizeof(uint32_t)));
+        KNN_TRY(hipMemset(d_cur, 0, ((size_t)nb + 1) * sizeof(uint32_t)));
+        KNN_TRY(hipMemset(d_over, 0, sizeof(int32_t)));
+        KNN_TRY(launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 1, nullptr));
+        KNN_TRY(launch_scan_exclusive(d_cur, nb + 1, d_bs, nullptr));
+        e2 = hipMalloc((void**)&d_start, ((size_t)nb + 1) * sizeof(uint32_t));
+        if (e2 == hipSuccess) e2 = hipMemcpy(d_start, d_cur, ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+        if (e2 == hipSuccess) e2 = launch_knn_bucket(d_cx, d_cy, (uint32_t)T, x0, y0, inv_g, nbx, nby, d_cur, d_items, 0, nullptr);
+        if (e2 == hipSuccess) e2 = launch_knn_select(d_cx, d_cy, d_start, d_items, x0, y0, g, nbx, nby, (uint32_t)X, (uint32_t)Y, res,
+                                                     (uint32_t)K, d_cell, d_cell ? d_cell + X : nullptr, map_idx_out, d_over, nullptr);
+        if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
+        over = 0;
+        if (e2 == hipSuccess) e2 = hipMemcpy(&over, d_over, sizeof over, hipMemcpyDeviceToHost);
+        if (e2 != hipSuccess || !over) break;
+    }
     cleanup();
 #undef KNN_TRY
     if (e2 != hipSuccess) return fail(c, ROVER_E_HIP, "build_knn_map: %s", hipGetErrorString(e2));
@@ -1018,7 +1064,8 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
     if (v == 3) {
-        if (int r = alloc_cull_queue(c)) return r;
+        if (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c))
+            return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
         HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
     } else if (v == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,

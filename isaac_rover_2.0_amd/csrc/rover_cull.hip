@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restri
 }
 
 __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, uint4* __restrict__ ctab,
-                                                         float* __restrict__ nz_abs) {
+                                                         float* __restrict__ nz_abs, uint32_t* __restrict__ counts) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const _Float16* src = reinterpret_cast<const _Float16*>(rtab) + 10ull * t;
@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
         else nzq = (float)(fabs(N[2]) / nN * (1.0 - 1.0e-6));
     }
     nz_abs[t] = nzq;
+    if ((nh[0] | nh[1] | nh[2]) == 0) atomicAdd(counts + 0, 1u);       // stored with a zero normal: always a candidate (rover_get_cull_info)
     ctab[t] = make_uint4(__float_as_uint(mk[0]), __float_as_uint(mk[1]), (uint32_t)zh | ((uint32_t)nh[0] << 16),
                          (uint32_t)nh[1] | ((uint32_t)nh[2] << 16));
 }
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
 // qrow[cell] = {q16, 0, 0, 0}: q = min |N_z| / |N| over the cell's triangles as a 16-bit fraction rounded down (0 = none)
 __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restrict__ map_idx, uint32_t K, uint32_t K8, uint32_t T,
                                                          const float* __restrict__ nz_abs, int32_t* __restrict__ idx4,
-                                                         uint4* __restrict__ qrow) {
+                                                         uint4* __restrict__ qrow, uint32_t* __restrict__ counts) {
     __shared__ uint32_t key[256];
     __shared__ float qmin[256];
     const uint32_t cell = blockIdx.x, tid = threadIdx.x, L = K8 >> 2;
@@ -220,6 +221,7 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         uint32_t q16 = 0;
         if (q <= 1.0f && q > 0.0f) { q16 = (uint32_t)floorf(q * 65535.0f); q16 = q16 > 0xfffeu ? 0xfffeu : q16; }
         qrow[cell] = make_uint4(q16, 0u, 0u, 0u);
+        if (q16 == 0u) atomicAdd(counts + 1, 1u);                       // no normal cone: its rays run both tests on every pair
     }
 }
 
@@ -333,8 +335,8 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
         const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chs, uint32_t chr, uint32_t run_r, uint2 *__restrict__ queue,                                      \
-        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, chs, chr, run_r, queue, rtab0, rtab1, out
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats
+#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, chs, chr, run_r, queue, rtab0, rtab1, out, stats
 
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
 
@@ -400,6 +402,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         if (pf_heads) prefetch_row();
     uint2* const qw = queue + (size_t)i0 * 128u;             // the wave's region of the candidate queue (128 entries per ray)
     uint32_t cused = 0;
+    uint32_t n_both = 0;                                     // rays that ran both tests (rover_get_cull_info)
     auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
         const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
         a4 = rp[0]; b4 = rp[1];
@@ -453,6 +456,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             uint64_t any[2];
             // the ray's cone bound (prep_rays_kernel, flags bits 16..31) against the cell's: (B) holds for every triangle
             const bool cone = q16 >= (__float_as_uint(rb.w) >> 16);
+            n_both += cone ? 0u : 1u;
             if (cone) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -502,6 +506,8 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     cull_exact(rays, rtab0, rtab1, qw, cused, gid, lane, bk);
     wave_lds_sync();
     if (lane < n_run) out[gid] = funkey(bk[lane]);
+    // per-wave counters of THIS launch (plain stores, 16 B per wave; summed on the host by rover_get_cull_info)
+    if (lane == 0u) stats[wave] = make_uint4(cused, n_run, n_both, (uint32_t)__builtin_popcountll(heads));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -511,10 +517,11 @@ static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((
 
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow,
-                             float* nz_scratch, hipStream_t s) {
+                             float* nz_scratch, uint32_t* counts /* [2], zeroed: always-candidate triangles, cells without a cone */,
+                             hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, tris, verts, T, V, rtab);
-    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, rtab, T, ctab, nz_scratch);
-    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, nz_scratch, idx4, qrow);
+    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, rtab, T, ctab, nz_scratch, counts);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, nz_scratch, idx4, qrow, counts);
     return hipGetLastError();
 }
 
@@ -544,8 +551,16 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     hipLaunchKernelGGL(cull_scan_kernel, dim3((t8 + r8) * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                        reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
                        a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, chs, chr, run_r, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
-                       reinterpret_cast<const RawTri*>(a.rtab1), a.out);
+                       reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats);
     return hipGetLastError();
+}
+
+// upper bound of the waves a launch over n_rays rays starts (= slots of the per-wave counter array)
+uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run) {
+    if (run > CULL_RUNMAX) run = CULL_RUNMAX;
+    if (run == 0) run = 1;
+    const uint32_t rr = run >= 64u ? 32u : run;                     // the rocks part walks shorter runs (launch_raycast_culled)
+    return (uint32_t)(4u * ((n_rays / rr + 4u) / 4u + 3u));
 }
 
 // entries the candidate queue must hold for n_rays rays in runs of `run`: every run owns run x 128 (a ray adds at most 128)

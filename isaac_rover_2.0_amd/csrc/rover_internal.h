@@ -65,7 +65,9 @@ struct CullArgs {
     uint32_t kp0, kp1, run, n_blocks;
     float* out;                  // [E*R8] distances
     uint2* queue;                // candidate queue: one region of run x 128 8-byte entries per run
+    uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
+uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t run, uint64_t* n_runs);
 
 // n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own
@@ -178,7 +180,7 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
                                  hipStream_t s);
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow,
-                             float* nz_scratch, hipStream_t s);
+                             float* nz_scratch, uint32_t* counts, hipStream_t s);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);

@@ -220,6 +220,196 @@ def make_scene(n_cells: int = 600, k: int = 200, n_stones: int = 1024, device="c
     )
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Irregular scene: a decimated-style mesh (what the reference's real assets are: a heightfield with gaussian rocks,
+# utils/terrain_utils/terrain_generation.py:18-65,104-153, reduced by pymeshlab's quadric edge collapse, :217-243).
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class IrregularSpec:
+    """Parameters of :func:`irregular_mesh`; everything is derived from these and ``seed`` (numpy Generator + Qhull)."""
+    extent_x: float = 10.0
+    extent_y: float = 10.0
+    n_rocks: int = 14
+    fine: float = 0.0375            # finest target vertex spacing (on the rocks)
+    coarse: float = 1.2             # coarsest (far from every rock): triangles that span many 0.1 m cells
+    growth: float = 0.45            # target spacing grows by this much per metre of distance from the nearest rock
+    seed: int = 0
+    rock_r: tuple = (0.08, 0.5)     # rock radius range [m]
+    rock_h: tuple = (0.10, 0.60)    # rock height range [m]
+    frac_sliver_pts: float = 0.01   # extra points 1-5 mm from an existing one: needle triangles
+    n_dup: int = 24                 # duplicated vertices (same coordinates, another index) re-used by part of their fan
+    n_degenerate: int = 12          # explicit zero-area triangles (two equal indices / three collinear vertices)
+    flip_frac: float = 0.10         # triangles stored with the other winding
+
+
+def _irregular_rocks(spec: IrregularSpec, rng):
+    n = spec.n_rocks
+    xy = np.stack((rng.uniform(0.3, spec.extent_x - 0.3, n), rng.uniform(0.3, spec.extent_y - 0.3, n)), axis=1)
+    nc = min(4, n)                                                # the first rocks sit in the central third (fixtures park rovers on them)
+    xy[:nc, 0] = rng.uniform(0.36 * spec.extent_x, 0.64 * spec.extent_x, nc)
+    xy[:nc, 1] = rng.uniform(0.36 * spec.extent_y, 0.64 * spec.extent_y, nc)
+    r = rng.uniform(spec.rock_r[0], spec.rock_r[1], n)
+    h = rng.uniform(spec.rock_h[0], spec.rock_h[1], n)
+    p = rng.choice(np.array([2.0, 4.0, 6.0]), n)                  # 2: gaussian bump; 4, 6: flat top, flanks up to ~80 degrees
+    return xy, r, h, p
+
+
+def irregular_height(spec: IrregularSpec):
+    """-> (z(x, y) in metres for float64 arrays, rocks = (xy [n,2], radius [n], height [n], exponent [n]))."""
+    rng = np.random.default_rng(10_000 + spec.seed)
+    rocks = _irregular_rocks(spec, rng)
+    n_hill = 6
+    hill_xy = np.stack((rng.uniform(0, spec.extent_x, n_hill), rng.uniform(0, spec.extent_y, n_hill)), axis=1)
+    hill_a = rng.uniform(-0.35, 0.35, n_hill)
+    hill_s = rng.uniform(1.2, 3.0, n_hill)
+
+    def z(x, y):
+        x = np.asarray(x, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        out = 0.05 * np.sin(1.7 * x) * np.cos(1.3 * y)
+        for (cx, cy), a, sg in zip(hill_xy, hill_a, hill_s):
+            out = out + a * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2.0 * sg * sg))
+        rxy, rr, rh, rp = rocks
+        for (cx, cy), r_, h_, p_ in zip(rxy, rr, rh, rp):
+            d = np.sqrt((x - cx) ** 2 + (y - cy) ** 2) / (0.75 * r_)
+            out = out + h_ * np.exp(-(d ** p_))
+        return out
+
+    return z, rocks
+
+
+def irregular_mesh(spec: IrregularSpec):
+    """Vertices [V,3] float32, triangles [T,3] int32 of an irregular, decimated-style terrain mesh, its rocks-only sub-mesh
+    (own triangle list, shared vertex table) and the stone list — deterministic in ``spec``.
+
+    * non-uniform Delaunay triangulation of jittered multi-level point sets: vertex spacing ``fine`` on the rocks, growing to
+      ``coarse`` away from them (triangle edges from ~0.03 m to > 1 m: some triangles cover hundreds of 0.1 m map cells);
+    * gaussian / flat-topped rock bumps with flanks up to ~80 degrees on top of broad hills;
+    * needle triangles (points 1-5 mm apart), duplicated vertices, zero-area triangles, mixed windings;
+    * triangle and vertex ids shuffled (no spatial order in either table).
+    """
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(20_000 + spec.seed)
+    zf, rocks = irregular_height(spec)
+    rxy, rr, rh, rp = rocks
+
+    def target_spacing(x, y):
+        d = np.full(x.shape, np.inf)
+        for (cx, cy), r_ in zip(rxy, rr):
+            d = np.minimum(d, np.maximum(0.0, np.sqrt((x - cx) ** 2 + (y - cy) ** 2) - 1.2 * r_))
+        return np.clip(spec.fine + spec.growth * d, spec.fine, spec.coarse)
+
+    pts = []
+    s_l = spec.coarse
+    first = True
+    while s_l >= spec.fine * 0.999:
+        nx, ny = int(np.ceil(spec.extent_x / s_l)) + 1, int(np.ceil(spec.extent_y / s_l)) + 1
+        gx, gy = np.meshgrid(np.arange(nx) * s_l, np.arange(ny) * s_l, indexing="ij")
+        q = np.stack((gx.reshape(-1), gy.reshape(-1)), axis=1) + rng.uniform(-0.35, 0.35, (nx * ny, 2)) * s_l
+        keep = np.ones(len(q), dtype=bool) if first else target_spacing(q[:, 0], q[:, 1]) <= s_l
+        pts.append(q[keep])
+        first = False
+        s_l *= 0.5
+    # the frame: corners + edge points, so that the triangulation covers the whole map rectangle
+    ex, ey = spec.extent_x, spec.extent_y
+    fr = [np.stack((np.linspace(0, ex, 17), np.zeros(17)), 1), np.stack((np.linspace(0, ex, 17), np.full(17, ey)), 1),
+          np.stack((np.zeros(15), np.linspace(0, ey, 17)[1:-1]), 1), np.stack((np.full(15, ex), np.linspace(0, ey, 17)[1:-1]), 1)]
+    p2 = np.concatenate(pts + fr, axis=0)
+    p2[:, 0] = np.clip(p2[:, 0], 0.0, ex)
+    p2[:, 1] = np.clip(p2[:, 1], 0.0, ey)
+    n_sl = int(spec.frac_sliver_pts * len(p2))
+    if n_sl:
+        src = p2[rng.integers(0, len(p2), n_sl)]
+        ang = rng.uniform(0, 2 * np.pi, n_sl)
+        off = rng.uniform(1e-3, 5e-3, n_sl)
+        p2 = np.concatenate([p2, np.clip(src + np.stack((off * np.cos(ang), off * np.sin(ang)), 1), 0.0, [ex, ey])], axis=0)
+    p2 = np.unique(np.round(p2, 9), axis=0)
+    tri = Delaunay(p2)
+    tris = tri.simplices.astype(np.int64)
+    verts = np.concatenate([p2, zf(p2[:, 0], p2[:, 1])[:, None]], axis=1)
+    # duplicated vertices: a copy takes over part of the triangle fan of the original
+    if spec.n_dup:
+        orig = rng.choice(len(verts), spec.n_dup, replace=False)
+        base = len(verts)
+        verts = np.concatenate([verts, verts[orig]], axis=0)
+        for k, o in enumerate(orig):
+            rows, cols = np.nonzero(tris == o)
+            take = rng.random(len(rows)) < 0.5
+            tris[rows[take], cols[take]] = base + k
+    # explicit degenerate triangles
+    if spec.n_degenerate:
+        a = rng.integers(0, len(verts), (spec.n_degenerate, 2))
+        deg = np.stack((a[:, 0], a[:, 0], a[:, 1]), axis=1)
+        tris = np.concatenate([tris, deg], axis=0)
+    flip = rng.random(len(tris)) < spec.flip_frac
+    tris[flip] = tris[flip][:, ::-1]
+    # shuffle both tables
+    vperm = rng.permutation(len(verts))
+    inv = np.empty_like(vperm)
+    inv[vperm] = np.arange(len(verts))
+    verts = verts[vperm]
+    tris = inv[tris]
+    tris = tris[rng.permutation(len(tris))]
+    verts32 = verts.astype(np.float32)
+    tris32 = np.ascontiguousarray(tris.astype(np.int32))
+    # rocks-only sub-mesh (the reference's big_stones.ply): triangles whose centroid lies within 1.2 r of a rock centre
+    c = verts[tris].mean(axis=1)
+    inside = np.zeros(len(tris), dtype=bool)
+    for (cx, cy), r_ in zip(rxy, rr):
+        inside |= (c[:, 0] - cx) ** 2 + (c[:, 1] - cy) ** 2 <= (1.2 * r_) ** 2
+    rock_tris = np.ascontiguousarray(tris32[inside])
+    stones = np.zeros((len(rr), 6), dtype=np.float64)             # stone_info.npy: centre xyz, extents, unused
+    stones[:, 0:2] = rxy
+    stones[:, 3] = 4.0 * rr                                        # read_stone_info: radius = max(extents) / 4
+    stones[:, 4] = 3.0 * rr
+    return verts32, tris32, rock_tris, stones
+
+
+def knn_map_bruteforce(verts: np.ndarray, tris: np.ndarray, n_x: int, n_y: int, k: int, res: float = 0.1,
+                       chunk_cells: int = 1024) -> torch.Tensor:
+    """Exact K nearest triangle centroids (xy) per map cell: float64 distances, ties by triangle id — the definition
+    rover_utils.py:68-108 ranks in fp16.  [n_x, n_y, k] int32.  For small scenes (CPU tests); the GPU builder
+    (rover_build_knn_map) computes the same ranking on f32 squared distances."""
+    v = np.asarray(verts, dtype=np.float64)
+    t = np.asarray(tris, dtype=np.int64)
+    c = torch.from_numpy((v[t[:, 0], 0:2] + v[t[:, 1], 0:2] + v[t[:, 2], 0:2]) / 3.0)
+    n_t = c.shape[0]
+    if n_t < k:
+        raise ValueError(f"need at least K={k} triangles, got {n_t}")
+    out = torch.empty((n_x * n_y, k), dtype=torch.int32)
+    cells = torch.arange(n_x * n_y)
+    for s0 in range(0, n_x * n_y, chunk_cells):
+        cc = cells[s0:s0 + chunk_cells]
+        px = (cc // n_y).double().unsqueeze(1) * res
+        py = (cc % n_y).double().unsqueeze(1) * res
+        d2 = (c[:, 0].unsqueeze(0) - px) ** 2 + (c[:, 1].unsqueeze(0) - py) ** 2
+        # stable ranking: sort by (d2, id) — argsort of d2 with a stable sort keeps id order among equal distances
+        order = torch.sort(d2, dim=1, stable=True).indices[:, :k]
+        out[s0:s0 + chunk_cells] = order.to(torch.int32)
+    return out.reshape(n_x, n_y, k)
+
+
+def make_irregular_scene(spec: IrregularSpec, k: int = 200, terrain_idx=None, rocks_idx=None) -> tuple:
+    """Scene on the irregular mesh of ``spec`` -> (Scene, height function).  The KNN maps are ``terrain_idx`` / ``rocks_idx``
+    ([X, Y, K] int32: e.g. the reference's own ``_get_knn_triangles`` output from a fixture, or the GPU builder's) or, when None,
+    :func:`knn_map_bruteforce`."""
+    verts, tris, rock_tris, stones = irregular_mesh(spec)
+    zf, _ = irregular_height(spec)
+    n_x, n_y = int(round(spec.extent_x / 0.1)), int(round(spec.extent_y / 0.1))
+    if terrain_idx is None:
+        terrain_idx = knn_map_bruteforce(verts, tris, n_x, n_y, k)
+    if rocks_idx is None:
+        rocks_idx = knn_map_bruteforce(verts, rock_tris, n_x, n_y, k)
+    vertices = torch.from_numpy(verts).to(torch.float16)
+    hx = np.arange(n_x * 4, dtype=np.float64) * 0.025
+    hy = np.arange(n_y * 4, dtype=np.float64) * 0.025
+    hm = zf(hx[:, None], hy[None, :]).astype(np.float32)
+    scene = Scene(terrain=KnnMap(torch.as_tensor(terrain_idx, dtype=torch.int32), torch.from_numpy(tris), vertices),
+                  rocks=KnnMap(torch.as_tensor(rocks_idx, dtype=torch.int32), torch.from_numpy(rock_tris), vertices.clone()),
+                  stone_info_raw=stones, heightmap=torch.from_numpy(hm))
+    return scene, zf
+
+
 # fp16(-0.1) and fp16(1.1) as exact fractions: the padded barycentric thresholds of ray_casting.py:59 and the
 # values its det / n / m substitutions compare against (:46,:51,:56)
 NEG_EPS_H = 819.0 / 8192.0          # 0.0999755859375
@@ -345,17 +535,23 @@ def quat_from_euler(roll, pitch, yaw):
                         cr * cp * sy - sr * sp * cy), dim=1).to(torch.float32)
 
 
-def make_states(num_envs: int, extent_m: float, seed: int, heightfn=None):
+def make_states(num_envs: int, extent_m: float, seed: int, heightfn=None, margin_m: float | None = None):
     """Per-env sim state of SURVEY.md §8d (host tensors, float32 / int64)."""
     g = torch.Generator().manual_seed(1000 + seed)
     lo, hi = 5.0, extent_m - 5.0
-    if hi <= lo:
+    if margin_m is not None:
+        lo, hi = margin_m, extent_m - margin_m
+    elif hi <= lo:
         lo, hi = 0.25 * extent_m, 0.75 * extent_m
     pos = torch.empty(num_envs, 3)
     pos[:, 0:2] = lo + (hi - lo) * torch.rand(num_envs, 2, generator=g)
-    i = (pos[:, 0] / 0.1).numpy().astype(np.float64)
-    j = (pos[:, 1] / 0.1).numpy().astype(np.float64)
-    pos[:, 2] = torch.from_numpy(surface_height(i, j)).float() + 0.5
+    if heightfn is not None:                # z of the surface under the rover from the scene's own height function (metres)
+        pos[:, 2] = torch.from_numpy(np.asarray(heightfn(pos[:, 0].numpy().astype(np.float64),
+                                                         pos[:, 1].numpy().astype(np.float64)))).float() + 0.5
+    else:
+        i = (pos[:, 0] / 0.1).numpy().astype(np.float64)
+        j = (pos[:, 1] / 0.1).numpy().astype(np.float64)
+        pos[:, 2] = torch.from_numpy(surface_height(i, j)).float() + 0.5
     roll = 0.1 * torch.randn(num_envs, generator=g)
     pitch = 0.1 * torch.randn(num_envs, generator=g)
     yaw = (2 * torch.rand(num_envs, generator=g) - 1) * math.pi

@@ -114,8 +114,112 @@ def lattice_fixture(name, fp32):
     save(name, **arrays)
 
 
+def pack_sets(map_xyk: torch.Tensor) -> np.ndarray:
+    """[X, Y, K] ids -> the per-cell K-SETS (ids ascending) as LZMA bytes.  Every output of the step is a min over a cell's K
+    triangles, so it depends on the set only; sorted sets of neighbouring cells compress ten times better than the ranked lists."""
+    import lzma
+    a = np.sort(map_xyk.numpy().astype(np.int16), axis=2)
+    return np.frombuffer(lzma.compress(np.ascontiguousarray(a).tobytes(), preset=9), dtype=np.uint8)
+
+
+IRREGULAR_KW = dict(kind="irregular", k=200, spec=dict(extent_x=10.0, extent_y=10.0, n_rocks=14, seed=0))
+
+
+def irregular_states(spec, zf, rocks, num_envs, seed):
+    """Random poses whose rays stay on the 10 m map, plus rovers parked ON the rocks: centre, the steepest ring of the flank,
+    strongly tilted bodies (wheel rays graze near-vertical faces), and poses over the coarse corners' long triangles."""
+    st = synth.make_states(num_envs, spec.extent_x, seed=seed, heightfn=zf, margin_m=3.3)
+    rxy, rr, _rh, _rp = rocks
+    central = [i for i in range(len(rr)) if 3.4 < rxy[i, 0] < 6.6 and 3.4 < rxy[i, 1] < 6.6]
+    assert len(central) >= 3
+    e = 0
+    for i in central[:4]:
+        for frac, ang in ((0.0, 0.0), (0.75, 0.7), (0.75, 3.9), (1.1, 2.2)):
+            x, y = rxy[i, 0] + frac * rr[i] * np.cos(ang), rxy[i, 1] + frac * rr[i] * np.sin(ang)
+            st["pos"][e, 0], st["pos"][e, 1] = float(x), float(y)
+            st["pos"][e, 2] = float(zf(np.float64(x), np.float64(y))) + 0.35
+            e += 1
+    g = torch.Generator().manual_seed(77 + seed)
+    tilt = e + 8
+    roll = 0.5 * torch.randn(tilt - e, generator=g)
+    pitch = 0.5 * torch.randn(tilt - e, generator=g)
+    yaw = 3.0 * torch.randn(tilt - e, generator=g)
+    st["quat"][e:tilt] = synth.quat_from_euler(roll, pitch, yaw)
+    return st
+
+
+def irregular_fixtures():
+    """Steps of the reference on an IRREGULAR mesh with maps built by the reference's own _get_knn_triangles (rover_utils.py:52-118,
+    K = 200): non-uniform Delaunay triangulation, edges from millimetres to metres, rock flanks up to ~80 degrees, needle and
+    zero-area triangles, duplicated vertices, mixed windings, shuffled ids (synth.irregular_mesh)."""
+    kw = IRREGULAR_KW
+    spec = synth.IrregularSpec(**kw["spec"])
+    verts, tris, rock_tris, _stones = synth.irregular_mesh(spec)
+    zf, rocks = synth.irregular_height(spec)
+    n = int(round(spec.extent_x / 0.1))
+    maps, shas = [], []
+    for name, t in (("map.ply", tris), ("big_stones.ply", rock_tris)):
+        idx, _v16, _t32, _xx, _yy = rh.knn_triangles(verts, t, name, res_x=n, res_y=n, res=0.1, n_triangles=kw["k"])
+        shas.append(hashlib.sha256(idx.numpy().tobytes()).hexdigest())
+        maps.append(idx.permute(1, 2, 0).contiguous())             # [K, X, Y] -> [X, Y, K]
+    scene_ref, _ = synth.make_irregular_scene(spec, kw["k"], maps[0], maps[1])                       # the maps as the reference ranked them
+    sets = [torch.sort(m, dim=2).values for m in maps]
+    scene, _ = synth.make_irregular_scene(spec, kw["k"], sets[0], sets[1])                           # the same K-sets, ids ascending
+    digest = scene_digest(scene)
+    packed = dict(terrain_sets_lzma=pack_sets(maps[0]), rocks_sets_lzma=pack_sets(maps[1]),
+                  terrain_map_sha256=np.array(shas[0]), rocks_map_sha256=np.array(shas[1]))
+    for name, fp32, native, e, seed in (("step_irregular_p37_fp32", True, False, 64, 31),
+                                        ("step_irregular_p37_fp16_as_shipped", False, False, 64, 31),
+                                        ("step_irregular_native_fp32", True, True, 4, 32)):
+        distn = None if native else synth.ray_distribution("37")
+        st = irregular_states(spec, zf, rocks, 64, seed)
+        if native:                                                  # 1634 rays reach 4.6 m: keep the rovers near the centre
+            st = {k: v[:e].clone() for k, v in st.items()}
+            st["pos"][:, 0:2] = torch.tensor([[5.0, 5.0], [4.8, 5.3], [5.3, 4.7], [5.1, 5.2]])
+        outs = []
+        for sc in (scene_ref, scene):
+            ref = rh.Reference(sc, fp32=fp32, distribution=distn)
+            if native:
+                distn = (ref.native_distribution.numpy(), ref.native_sparse.numpy(), ref.native_dense.numpy())
+            outs.append(tonp(ref.step(st)))
+        for k in outs[0]:                                           # the ranked lists and the sorted sets give the same step, bit for bit
+            if k != "ray_sources":
+                assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+        arrays = {"in_" + k: v for k, v in tonp(st).items()}
+        arrays.update({"out_" + k: v for k, v in outs[0].items()})
+        if native:
+            arrays.pop("out_ray_sources")
+        arrays.update(distribution=np.asarray(distn[0], dtype=np.float64), sparse_idx=np.asarray(distn[1], dtype=np.int64),
+                      dense_idx=np.asarray(distn[2], dtype=np.int64), scene_digest=np.array(digest), scene_kw=np.array(repr(kw)),
+                      fp32=np.array(fp32), curriculum_level=np.array(2), num_envs_global=np.array(st["pos"].shape[0]))
+        if name == "step_irregular_p37_fp32":
+            arrays.update(packed)                                   # the maps travel once; the other two fixtures point here
+        else:
+            arrays.update(maps_in=np.array("step_irregular_p37_fp32"))
+        save(name, **arrays)
+
+
+def k200_fixtures():
+    """The reference's K (rover_utils.py:49: n_triangles = 200) on the regular scene: every step fixture above uses K = 16 / 48."""
+    kw = dict(n_cells=128, k=200, n_stones=64)
+    scene = synth.make_scene(**kw)
+    digest = scene_digest(scene)
+    global SCENE_KW
+    keep = SCENE_KW
+    SCENE_KW = kw
+    try:
+        step_fixture("step_e32_p37_k200_fp32", scene, digest, "37", 32, seed=41, edges=True)
+        step_fixture("step_e32_p37_k200_fp16_as_shipped", scene, digest, "37", 32, seed=41, fp32=False, edges=True)
+    finally:
+        SCENE_KW = keep
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-new" in sys.argv:
+        k200_fixtures()
+        irregular_fixtures()
+        return
     torch.manual_seed(0)
     scene = synth.make_scene(**SCENE_KW)
     digest = scene_digest(scene)
@@ -139,6 +243,8 @@ def main():
 
     lattice_fixture("step_lattice_fp32", fp32=True)
     lattice_fixture("step_lattice_fp16_as_shipped", fp32=False)
+    k200_fixtures()
+    irregular_fixtures()
 
     # ---- native distribution table (heightmap_distribution.py:36-115) -----------------------
     ref = rh.Reference(scene, fp32=True)

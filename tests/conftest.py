@@ -32,10 +32,15 @@ def scene_for(fixture):
 
     import ast
     kw = ast.literal_eval(str(fixture["scene_kw"]))  # repr of a plain dict of ints written by oracle/gen_golden.py
-    key = tuple(sorted(kw.items()))
+    key = repr(sorted(kw.items()))
     if key not in _scene_cache:
         if kw.get("kind") == "lattice":
             scene = synth.make_lattice_scene(k=kw["k"])
+        elif kw.get("kind") == "irregular":
+            # mesh, stones and heightfield are rebuilt from the spec; the two KNN maps are the reference's own
+            # _get_knn_triangles output (fp16 ranking, rover_utils.py:52-118), stored once as per-cell sorted K-sets
+            terrain_idx, rocks_idx = irregular_maps(fixture)
+            scene, _ = synth.make_irregular_scene(synth.IrregularSpec(**kw["spec"]), kw["k"], terrain_idx, rocks_idx)
         else:
             scene = synth.make_scene(**kw)
         h = hashlib.sha256()
@@ -49,16 +54,35 @@ def scene_for(fixture):
     return scene
 
 
+def irregular_maps(fixture):
+    """-> (terrain, rocks) [X, Y, K] int32 maps of an irregular-scene fixture (LZMA-packed sorted K-sets)."""
+    import ast
+    import lzma
+
+    import torch
+    kw = ast.literal_eval(str(fixture["scene_kw"]))
+    src = fixture if "terrain_sets_lzma" in fixture else load_golden(str(fixture["maps_in"]))
+    n_x, n_y = int(round(kw["spec"]["extent_x"] / 0.1)), int(round(kw["spec"]["extent_y"] / 0.1))
+    out = []
+    for name in ("terrain_sets_lzma", "rocks_sets_lzma"):
+        a = np.frombuffer(lzma.decompress(src[name].tobytes()), dtype=np.int16).reshape(n_x, n_y, kw["k"])
+        out.append(torch.from_numpy(a.astype(np.int32)))
+    return out
+
+
 def states_of(fixture):
     import torch
     return {k[3:]: torch.from_numpy(v) for k, v in fixture.items() if k.startswith("in_")}
 
 
 STEP_FIXTURES_FP32 = ["step_e256_p9_fp32", "step_e64_p37_fp32", "step_e64_p120_fp32", "step_e8_native_fp32",
-                      "step_e64_p37_fp32_level1", "step_lattice_fp32"]
+                      "step_e64_p37_fp32_level1", "step_lattice_fp32",
+                      "step_e32_p37_k200_fp32",                                  # the reference's K = 200 (rover_utils.py:49)
+                      "step_irregular_p37_fp32", "step_irregular_native_fp32"]   # irregular mesh, maps by the reference's builder
 
 STEP_FIXTURES_AS_SHIPPED = ["step_e64_p37_fp16_as_shipped", "step_e256_p9_fp16_as_shipped", "step_e64_p120_fp16_as_shipped",
-                            "step_e8_native_fp16_as_shipped", "step_lattice_fp16_as_shipped"]
+                            "step_e8_native_fp16_as_shipped", "step_lattice_fp16_as_shipped",
+                            "step_e32_p37_k200_fp16_as_shipped", "step_irregular_p37_fp16_as_shipped"]
 
 # ---- stated parity tolerances (SURVEY.md §8c), shared by the oracle and the HIP tests ----------
 TOL_SCALAR = 1e-5        # euler / heading / obs[:,0:4] / reward / extras: abs and rel

@@ -277,6 +277,95 @@ def test_culled_raycast_changes_no_bit(k, cells):
     assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
+@pytest.mark.parametrize("name,precision", [("step_irregular_p37_fp32", 0), ("step_irregular_native_fp32", 0),
+                                            ("step_e32_p37_k200_fp32", 0), ("step_irregular_p37_fp16_as_shipped", 2),
+                                            ("step_e32_p37_k200_fp16_as_shipped", 2)])
+def test_irregular_mesh_and_k200_all_variants(name, precision):
+    """Fixtures captured from the reference on (a) an IRREGULAR mesh — non-uniform Delaunay triangulation, edges from millimetres
+    to metres, ~80 degree rock flanks, needle / zero-area triangles, duplicated vertices, mixed windings, shuffled ids — with
+    K = 200 maps built by the reference's own _get_knn_triangles, and (b) the regular scene at the reference's K = 200:
+    the culled (3), binned (2) and env-order (1) kernels agree with the reference within the stated tolerance and with EACH
+    OTHER bit for bit; in the as-shipped fp16 mode the distances equal the reference's bit for bit."""
+    from hip_helpers import hip_step, make_engine
+    fx = load_golden(name)
+    scene = scene_for(fx)
+    st = states_of(fx)
+    distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
+    outs = {}
+    for variant in (3, 2, 1):
+        if precision == 2 and variant == 1:
+            continue                                  # the env-order kernel has no as-shipped fp16 arithmetic
+        eng = make_engine(scene, distn, st["pos"].shape[0], variant=variant)
+        eng.set_option("ray_precision", precision)
+        if eng.info().raycast_variant != variant:
+            eng.close()
+            continue                                  # (a precision this variant does not implement)
+        outs[variant] = hip_step(eng, st)
+        if variant == 3:
+            ci = eng.cull_info()
+            assert ci["rays"] == st["pos"].shape[0] * (distn[0].shape[0] + 26)
+            if "irregular" in name:                   # the paths a regular grid mesh never takes are taken here
+                assert ci["always_candidate_triangles"][0] > 0 and ci["cells_without_cone"][0] > 0
+                assert ci["rays_both_tests"] > 0 and ci["candidate_pairs"] > 0
+        eng.close()
+    assert 2 in outs and (3 in outs or precision == 2)
+    for variant, out in outs.items():
+        if precision == 2:
+            for key in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
+                np.testing.assert_array_equal(out[key], fx["out_" + key], err_msg=f"{key} variant={variant}")
+            np.testing.assert_array_equal(out["obs_buf"][:, 4:], fx["out_obs_buf"][:, 4:])
+        else:
+            assert_step_close(out, fx, f"{name} variant={variant}")
+        for key in out:
+            np.testing.assert_array_equal(out[key], outs[2][key], err_msg=f"{key} variant={variant} vs 2")
+
+
+@pytest.mark.parametrize("seed,k,coarse,fine", [(1, 200, 1.2, 0.0375), (2, 64, 3.0, 0.05), (3, 200, 0.6, 0.03)])
+def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine):
+    """The culled kernel against the binned kernel without early out and the env-order kernel on irregular meshes (maps by
+    the GPU builder): steep tilts, arbitrary orientations, rovers parked on rock flanks, poses outside the map, NaN."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import _lib, assets, synth
+    n = 3000
+    spec = synth.IrregularSpec(extent_x=12.0, extent_y=12.0, n_rocks=24, seed=seed, coarse=coarse, fine=fine)
+    tool = _lib.Engine(8, device=0)
+    scene, zf = assets.build_irregular_scene(tool, spec, k)
+    tool.close()
+    distn = synth.ray_distribution("120" if seed != 2 else "37")
+    st = synth.make_states(n, 12.0, seed=80 + seed, heightfn=zf, margin_m=1.0)
+    g = torch.Generator().manual_seed(seed)
+    st["quat"] = synth.quat_from_euler(0.5 * torch.randn(n, generator=g), 0.5 * torch.randn(n, generator=g), 3.0 * torch.randn(n, generator=g))
+    q = torch.randn(1000, 4, generator=g)
+    st["quat"][1000:2000] = q / q.norm(dim=1, keepdim=True)
+    _zf, (rxy, rr, _rh, _rp) = synth.irregular_height(spec)
+    for e in range(2000, 2600):                                                   # on the rocks' flanks, close to the surface
+        i = e % len(rr)
+        a = 0.37 * e
+        x, y = rxy[i, 0] + 0.75 * rr[i] * np.cos(a), rxy[i, 1] + 0.75 * rr[i] * np.sin(a)
+        st["pos"][e, 0], st["pos"][e, 1], st["pos"][e, 2] = float(x), float(y), float(zf(x, y)) + 0.3
+    st["pos"][2900:2950] *= 1.0e4
+    st["pos"][2950:2960] = float("nan")
+    st["pos"][2960:2970, 2] += 500.0
+    eng = make_engine(scene, distn, n, variant=2)
+    eng.set_option("raycast_early_out", 0)
+    ref = hip_step(eng, st)
+    eng.close()
+    eng = make_engine(scene, distn, n, variant=1)
+    ref1 = hip_step(eng, st)
+    eng.close()
+    for key in ref:
+        np.testing.assert_array_equal(ref1[key], ref[key], err_msg=f"{key} variant 1 vs 2")
+    for run in (0, 7, 64):
+        eng = make_engine(scene, distn, n, variant=3, run=run or None)
+        got = hip_step(eng, st)
+        ci = eng.cull_info()
+        eng.close()
+        for key in ref:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run}")
+        assert ci["always_candidate_triangles"][0] > 0 and ci["rays_both_tests"] > 0
+    assert (ref["ray_dist"] < 11.0).mean() > 0.3
+
+
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the culled kernel above (the binned one
     whenever the as-shipped fp16 maths are asked for); K8 > 256 always falls back to the env-order kernel."""
