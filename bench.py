@@ -64,6 +64,11 @@ def parse(argv=None):
     ap.add_argument("--cells", type=int, default=600)
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--stones", type=int, default=1024)
+    ap.add_argument("--mesh", default="grid", choices=["grid", "shuffled", "irregular"],
+                    help="grid = SURVEY 8(d)'s regular 0.1 m heightfield mesh in row-major triangle order (the headline workload); "
+                         "shuffled = the same mesh with its triangle table in random order; irregular = a decimated-style mesh "
+                         "(synth.irregular_mesh: non-uniform Delaunay triangulation, millimetre to metre edges, ~80 degree rock "
+                         "flanks, needle / zero-area triangles, shuffled ids) with K-nearest maps built by rover_build_knn_map")
     ap.add_argument("--validate-goals", action="store_true",
                     help="configs[4]: also run the reset/spawn-goal validation kernel on the envs flagged done each step")
     ap.add_argument("--ray-precision", default="fp32", choices=["fp32", "fp16_sources", "fp16_as_shipped"],
@@ -159,18 +164,34 @@ def algorithmic_bytes_per_env_step(p, k, ns, nd, r=26):
     return (p + r) * k * 18 + 128 + (4 + ns + nd) * 4 + 56
 
 
-def load_scene(args, device):
+def load_scene(args, device, local_rank=0):
+    """-> (scene, height function or None)"""
     import torch
     from isaac_rover_amd import synth
-    key = f"scene_c{args.cells}_k{args.k}_s{args.stones}.pt"
+    key = f"scene_{args.mesh}_c{args.cells}_k{args.k}_s{args.stones}.pt"
     path = os.path.join(args.scene_cache, key) if args.scene_cache else ""
+    zf = None
+    spec = None
+    if args.mesh == "irregular":
+        spec = synth.IrregularSpec(extent_x=args.cells * 0.1, extent_y=args.cells * 0.1, n_rocks=args.stones, seed=5, fine=0.05)
+        zf, _ = synth.irregular_height(spec)
     if path and os.path.exists(path):
-        return torch.load(path, weights_only=False)
-    scene = synth.make_scene(n_cells=args.cells, k=args.k, n_stones=args.stones, device=device)
+        return torch.load(path, weights_only=False), zf
+    if args.mesh == "irregular":
+        from isaac_rover_amd import _lib, assets
+        tool = _lib.Engine(8, device=local_rank)
+        scene, _ = assets.build_irregular_scene(tool, spec, args.k)
+        tool.close()
+    else:
+        scene = synth.make_scene(n_cells=args.cells, k=args.k, n_stones=args.stones, device=device)
+        if args.mesh == "shuffled":
+            import dataclasses
+            host = lambda m: dataclasses.replace(m, map_indices=m.map_indices.cpu(), triangles=m.triangles.cpu(), vertices=m.vertices.cpu())
+            scene = synth.shuffle_triangle_ids(dataclasses.replace(scene, terrain=host(scene.terrain), rocks=host(scene.rocks)), seed=9)
     if path:
         os.makedirs(args.scene_cache, exist_ok=True)
         torch.save(scene, path)
-    return scene
+    return scene, zf
 
 
 def cpu_baseline(args, scene, distn, states):
@@ -273,7 +294,8 @@ def roofline(args, E, n_rays, prof, info):
     bytes per launch of the same workload (rocprofv3 --pmc, tools/collect_profiles.sh), see profiles/README.md."""
     ray_ms = prof.raycast_ms / max(prof.launches, 1)
     t = ray_ms * 1e-3
-    key = f"E{E}_P{args.rays}_K{args.k}_C{args.cells}" + ("" if args.ray_precision == "fp32" else "_" + args.ray_precision)
+    key = f"E{E}_P{args.rays}_K{args.k}_C{args.cells}" + ("" if args.ray_precision == "fp32" else "_" + args.ray_precision) \
+        + ("" if args.mesh == "grid" else "_" + args.mesh)
     valu = _profile_entry("valu.json", key)
     traf = _profile_entry("traffic.json", key)
     rays = E * (n_rays + 26)
@@ -338,7 +360,7 @@ def run_rank(args):
 
     E = args.envs_per_gpu
     E_global = E * world
-    scene = load_scene(args, device)
+    scene, zf = load_scene(args, device, local_rank)
     if args.rays == "native":
         from isaac_rover_amd.tasks.utils.heightmap_distribution import generate_native
         distn = tuple(np.asarray(x) for x in generate_native())
@@ -355,7 +377,7 @@ def run_rank(args):
     # 4 resident state batches, rotated, so consecutive steps do not replay identical rays
     batches = []
     for b in range(4):
-        st = synth.make_states(E, args.cells * 0.1, seed=100 * rank + b)
+        st = synth.make_states(E, args.cells * 0.1, seed=100 * rank + b, heightfn=zf)
         batches.append({k: v.to(device) for k, v in st.items()})
     can_overlap = world > 1 and not args.validate_goals
     depth = 2 if can_overlap else 1
@@ -496,6 +518,7 @@ def run_rank(args):
             "config": {"workload": f"BASELINE configs[{cfg_idx}]: {E} envs/GPU x {world} GPU, "
                                    f"{args.rays}-point heightmap + 26 rock rays, K={args.k}, {args.cells}x{args.cells} "
                                    f"cells @0.1 m, stone_info mask over {args.stones} stones"
+                                   + (f", mesh={args.mesh}" if args.mesh != "grid" else "")
                                    + (", + goal validation" if args.validate_goals else "")
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
                                    + (f", cell_index_mode={args.cell_index_mode}" if args.cell_index_mode != "cpu_div" else "")
@@ -510,6 +533,12 @@ def run_rank(args):
             "backend": dist.get_backend() if world > 1 else None,
             "roofline": roofline(args, E, n_rays, prof, info),
         }
+        if info.raycast_variant == 3:
+            ci = eng.cull_info()
+            line["cull"] = {"candidate_pairs_per_ray": ci["pairs_per_ray"], "rays_with_both_tests": ci["rays_both_tests"] / max(ci["rays"], 1),
+                            "rays_per_bin": ci["rays"] / max(ci["bins"], 1), "max_pairs_per_run": ci["max_pairs_per_run"],
+                            "always_candidate_triangles": ci["always_candidate_triangles"], "cells_without_cone": ci["cells_without_cone"],
+                            "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"]}
         if world > 1:
             line["gather_check"] = ok
             line["gather_bytes_per_rank_per_step"] = E * (4 * W + 4 + 1)

@@ -3,6 +3,7 @@
 #include "../../include/rover_step.h"
 #include "rover_internal.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -243,6 +244,100 @@ static int alloc_workspace(rover_ctx* c) {
     return alloc_bins(c);
 }
 
+
+// ---- internal triangle numbering of the culled ray cast's tables (rover_set_knn_map) -----------------------------------------
+// The caller's triangle order means nothing (a decimated .ply lists triangles in no spatial order), but the kernel gains from
+// two properties of the ids it works with: (i) consecutive ids are neighbours in space (one gather instruction of a wave then
+// touches few cache lines, and bins that follow each other re-use each other's records in L2), (ii) a lane's packed pair holds two
+// triangles that are candidates for the same rays (a queue entry then carries two candidates: fewer entries, fewer exact-phase
+// lanes).  So: triangles are matched into spatial partners — mutual nearest centroids first (on a grid mesh exactly the two
+// halves of every mesh cell), then greedily the nearest unmatched neighbour — and a pair gets the ids 2p, 2p + 1, pairs in
+// Morton order of their first member; an unmatched triangle gets 2p and leaves 2p + 1 a hole.  order[new] = old (0xffffffff =
+// hole), newid[old] = new.  A min over the same set of triangles does not depend on the numbering: results are unchanged.
+static void cull_numbering(const std::vector<float2>& cen, std::vector<uint32_t>& order, std::vector<uint32_t>& newid) {
+    const uint32_t T = (uint32_t)cen.size(), NONE = 0xffffffffu;
+    auto finite = [](const float2& p) { return std::fabs(p.x) < 1e30f && std::fabs(p.y) < 1e30f; };
+    float bx0 = 0.f, bx1 = 0.f, by0 = 0.f, by1 = 0.f;
+    bool any = false;
+    uint32_t n_fin = 0;
+    for (const float2& p : cen) {
+        if (!finite(p)) continue;
+        ++n_fin;
+        if (!any) { bx0 = bx1 = p.x; by0 = by1 = p.y; any = true; }
+        bx0 = p.x < bx0 ? p.x : bx0; bx1 = p.x > bx1 ? p.x : bx1; by0 = p.y < by0 ? p.y : by0; by1 = p.y > by1 ? p.y : by1;
+    }
+    // Morton rank (16 bits per axis of the bounding box; broken triangles last)
+    const double sx = bx1 > bx0 ? 65535.0 / ((double)bx1 - bx0) : 0.0, sy = by1 > by0 ? 65535.0 / ((double)by1 - by0) : 0.0;
+    auto spread = [](uint32_t v) {                     // 16 bits -> every second bit of 32
+        v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
+        v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    std::vector<uint64_t> key((size_t)T);
+    for (uint32_t t = 0; t < T; ++t) {
+        uint32_t m = 0xffffffffu;
+        if (finite(cen[t])) m = (spread((uint32_t)(((double)cen[t].x - bx0) * sx)) << 1) | spread((uint32_t)(((double)cen[t].y - by0) * sy));
+        key[t] = ((uint64_t)m << 32) | t;
+    }
+    std::sort(key.begin(), key.end());
+    // uniform hash grid over the centroids, ~4 per bucket at mean density
+    const double area = ((double)bx1 - bx0 + 1e-6) * ((double)by1 - by0 + 1e-6);
+    double h = std::sqrt(area * 4.0 / (double)(n_fin ? n_fin : 1));
+    uint32_t gx = (uint32_t)(((double)bx1 - bx0) / h) + 1, gy = (uint32_t)(((double)by1 - by0) / h) + 1;
+    while ((uint64_t)gx * gy > (1u << 24)) { h *= 2.0; gx = (uint32_t)(((double)bx1 - bx0) / h) + 1; gy = (uint32_t)(((double)by1 - by0) / h) + 1; }
+    auto bucket = [&](const float2& p, uint32_t& ix, uint32_t& iy) {
+        ix = (uint32_t)(((double)p.x - bx0) / h); iy = (uint32_t)(((double)p.y - by0) / h);
+        ix = ix >= gx ? gx - 1 : ix; iy = iy >= gy ? gy - 1 : iy;
+    };
+    std::vector<uint32_t> start((size_t)gx * gy + 1, 0), items((size_t)n_fin);
+    for (uint32_t t = 0; t < T; ++t) if (finite(cen[t])) { uint32_t ix, iy; bucket(cen[t], ix, iy); ++start[(size_t)ix * gy + iy + 1]; }
+    for (size_t b = 0; b < (size_t)gx * gy; ++b) start[b + 1] += start[b];
+    {
+        std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+        for (uint32_t t = 0; t < T; ++t) if (finite(cen[t])) { uint32_t ix, iy; bucket(cen[t], ix, iy); items[cur[(size_t)ix * gy + iy]++] = t; }
+    }
+    std::vector<uint32_t> partner((size_t)T, NONE);
+    // nearest other centroid in the 3 x 3 buckets around t among those for which ok(u); ties by id
+    auto nearest = [&](uint32_t t, auto&& ok) {
+        uint32_t ix, iy, best = NONE;
+        bucket(cen[t], ix, iy);
+        double bd = 1e300;
+        for (uint32_t a = ix ? ix - 1 : 0; a <= (ix + 1 < gx ? ix + 1 : gx - 1); ++a)
+            for (uint32_t b = iy ? iy - 1 : 0; b <= (iy + 1 < gy ? iy + 1 : gy - 1); ++b)
+                for (uint32_t k = start[(size_t)a * gy + b]; k < start[(size_t)a * gy + b + 1]; ++k) {
+                    const uint32_t u = items[k];
+                    if (u == t || !ok(u)) continue;
+                    const double dx = (double)cen[u].x - cen[t].x, dy = (double)cen[u].y - cen[t].y, d = dx * dx + dy * dy;
+                    if (d < bd || (d == bd && u < best)) { bd = d; best = u; }
+                }
+        return best;
+    };
+    {   // pass 1: mutual nearest neighbours
+        std::vector<uint32_t> nn((size_t)T, NONE);
+        for (uint32_t t = 0; t < T; ++t) if (finite(cen[t])) nn[t] = nearest(t, [](uint32_t) { return true; });
+        for (uint32_t t = 0; t < T; ++t) if (nn[t] != NONE && nn[t] > t && nn[nn[t]] == t) { partner[t] = nn[t]; partner[nn[t]] = t; }
+    }
+    // pass 2, in Morton order: the nearest still unmatched neighbour
+    for (uint32_t r = 0; r < T; ++r) {
+        const uint32_t t = (uint32_t)key[r];
+        if (partner[t] != NONE || !finite(cen[t])) continue;
+        const uint32_t u = nearest(t, [&](uint32_t v) { return partner[v] == NONE; });
+        if (u != NONE) { partner[t] = u; partner[u] = t; }
+    }
+    order.clear();
+    order.reserve((size_t)T + T / 8);
+    std::vector<uint8_t> done((size_t)T, 0);
+    for (uint32_t r = 0; r < T; ++r) {
+        const uint32_t t = (uint32_t)key[r];
+        if (done[t]) continue;
+        const uint32_t u = partner[t];
+        done[t] = 1;
+        newid[t] = (uint32_t)order.size(); order.push_back(t);
+        if (u != NONE) { done[u] = 1; newid[u] = (uint32_t)order.size(); order.push_back(u); }
+        else order.push_back(NONE);
+    }
+}
+
 extern "C" {
 
 const char* rover_version(void) { return "rover_step 0.1 (gfx950)"; }
@@ -333,24 +428,49 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint32_t* d_cnt = nullptr;
     uint32_t h_cnt[2] = {0, 0};
     uint64_t cull_bytes = 0;
-    if (K8 <= 256 && (uint32_t)T < 0x3ffffffu) {
-        const uint64_t b_idx = n_cells * K8 * sizeof(int32_t), b_ct = (uint64_t)T * sizeof(uint4), b_rt = (uint64_t)T * 20u;
+    uint32_t *d_order = nullptr, *d_newid = nullptr;
+    if (K8 <= 256 && (uint32_t)T < 0x1ffffffu) {
+        const uint64_t b_idx = n_cells * K8 * sizeof(int32_t);
+        uint32_t T_int = 0;
+        auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_qrow); dfree(d_nz); dfree(d_cnt);
+                            dfree(d_order); dfree(d_newid); dfree(d_table); };
+        // internal triangle numbering (spatial partners get ids 2p, 2p + 1, pairs ordered along a Morton curve): cull_numbering()
+        std::vector<uint32_t> order, newid((size_t)T);
+        {
+            float2* d_cen = nullptr;
+            std::vector<float2> cen((size_t)T);
+            if ((e = hipMalloc((void**)&d_cen, (uint64_t)T * sizeof(float2))) != hipSuccess ||
+                (e = launch_tri_centroids(d_tris, d_verts, (uint32_t)T, (uint32_t)V, d_cen, nullptr)) != hipSuccess ||
+                (e = hipMemcpy(cen.data(), d_cen, (uint64_t)T * sizeof(float2), hipMemcpyDeviceToHost)) != hipSuccess) {
+                dfree(d_cen); drop();
+                return fail(c, ROVER_E_HIP, "set_knn_map: triangle centroids: %s", hipGetErrorString(e));
+            }
+            dfree(d_cen);
+            cull_numbering(cen, order, newid);
+        }
+        T_int = (uint32_t)order.size();
+        if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
+        const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
         cull_bytes = b_idx + b_ct + b_rt + n_cells * sizeof(uint4);
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint4))) != hipSuccess ||
-            (e = hipMalloc((void**)&d_nz, (uint64_t)T * sizeof(float))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_nz, (uint64_t)T_int * sizeof(float))) != hipSuccess ||
             (e = hipMalloc((void**)&d_cnt, 2 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_order, (uint64_t)T_int * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_newid, (uint64_t)T * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMemcpy(d_order, order.data(), (uint64_t)T_int * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemset(d_cnt, 0, 2 * sizeof(uint32_t))) != hipSuccess ||
-            (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, (uint32_t)V, d_cidx, d_ctab, d_rtab,
-                                   d_qrow, d_nz, d_cnt, nullptr)) != hipSuccess ||
+            (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
+                                   d_ctab, d_rtab, d_qrow, d_nz, d_cnt, nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
-            cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_qrow); dfree(d_nz); dfree(d_cnt); dfree(d_table);
+            drop();
             return fail(c, ROVER_E_HIP, "set_knn_map: cull tables (%llu B): %s", (unsigned long long)cull_bytes, hipGetErrorString(e));
         }
     }
     cleanup();
-    dfree(d_nz); dfree(d_cnt);
+    dfree(d_nz); dfree(d_cnt); dfree(d_order); dfree(d_newid);
     c->cull_always[which] = h_cnt[0]; c->cull_nocone[which] = h_cnt[1]; c->cull_tris[which] = T;
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);

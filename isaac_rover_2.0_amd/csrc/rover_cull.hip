@@ -69,18 +69,40 @@ __device__ __forceinline__ float cull_r2(float nx, float ny, float nz) {
 //   idx4 [cell][L][4] i32: the cell's K triangle ids (-1 = empty slot), L = K8 / 4 lanes x 4; ids sorted ascending and dealt
 //                         as pairs of neighbours (pair m = sorted[2m], sorted[2m + 1] -> lane m % L, pair slot m / L) so
 //                         that one gather instruction of a wave touches neighbouring ctab records (few L2 lines)
+// The ids in these tables are INTERNAL: rover_set_knn_map renumbers the caller's triangles along a Morton curve over their
+// centroids, so that consecutive ids are neighbours in space whatever order the mesh file lists them in (a decimated .ply has
+// none).  A min over the same set of triangles does not depend on how they are numbered: results are unchanged.
 // The per-triangle tables are small (26 B x T: 18 MB for 720 k triangles) and stay in L2 / MALL; HBM only streams idx4.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restrict__ tris, const uint16_t* __restrict__ verts,
-                                                         uint32_t T, uint32_t V, uint16_t* __restrict__ rtab) {
+// centroid (xy) of every triangle from its fp16 vertices: the key of the internal renumbering (NaN for a broken triangle)
+__global__ void __launch_bounds__(256) tri_centroid_kernel(const int32_t* __restrict__ tris, const uint16_t* __restrict__ verts,
+                                                           uint32_t T, uint32_t V, float2* __restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
+    float x = 0.0f, y = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t vi = (uint32_t)tris[3ull * t + a];
+        const _Float16* v = reinterpret_cast<const _Float16*>(verts) + 3ull * (vi < V ? vi : 0u);
+        x += vi < V ? (float)v[0] : __builtin_nanf("");
+        y += vi < V ? (float)v[1] : __builtin_nanf("");
+    }
+    out[t] = make_float2(x * (1.0f / 3.0f), y * (1.0f / 3.0f));
+}
+
+// record t of the per-triangle tables belongs to the caller's triangle order[t] (the internal, spatially sorted numbering)
+__global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restrict__ tris, const uint16_t* __restrict__ verts,
+                                                         uint32_t T, uint32_t V, const uint32_t* __restrict__ order,
+                                                         uint16_t* __restrict__ rtab) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t src = order[t];                                      // 0xffffffff: a hole of the numbering (the partner slot of a single)
     uint16_t v[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) v[q] = 0x7e00u;                        // fp16 NaN: every test fails
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const uint32_t vi = (uint32_t)tris[3ull * t + a];
+        const uint32_t vi = src != 0xffffffffu ? (uint32_t)tris[3ull * src + a] : 0xffffffffu;
         if (vi < V) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[3 * a + c] = verts[3ull * vi + c];
@@ -91,8 +113,8 @@ __global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restri
     for (int q = 0; q < 10; ++q) rtab[10ull * t + q] = v[q];
 }
 
-__global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, uint4* __restrict__ ctab,
-                                                         float* __restrict__ nz_abs, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, const uint32_t* __restrict__ order,
+                                                         uint4* __restrict__ ctab, float* __restrict__ nz_abs, uint32_t* __restrict__ counts) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const _Float16* src = reinterpret_cast<const _Float16*>(rtab) + 10ull * t;
@@ -101,8 +123,8 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
 #pragma unroll
     for (int q = 0; q < 9; ++q) { v[q] = (float)src[q]; valid = valid && (v[q] == v[q]) && fabsf(v[q]) < 6.0e4f; }
     float mk[3] = {0.0f, 0.0f, 0.0f};                                // the centre as phase 1 decodes it
-    float nzq = 0.0f;                                                // |N_z| / |N| of the exact normal; 0 = no cone shortcut for its cells
-    uint16_t zh = 0, nh[3] = {0, 0, 0};                              // zero normal: guard (B) never holds = always a candidate
+    float nzq = 2.0f;                                                // |N_z| / |N| of the exact normal; 2 = always a candidate (not part of a cell's cone)
+    uint16_t zh = 0, nh[3] = {0x7c00u, 0x7c00u, 0x7c00u};            // infinite normal: r2 = +inf, neither test can hold = always a candidate
     if (valid) {
         // a, b, c exactly as ray_casting.py:34-36 / set_pair compute them (f32), widened
         const float af[3] = {v[6], v[7], v[8]};
@@ -172,25 +194,26 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
             }
             ok = done;
         }
-        if (!ok) nh[0] = nh[1] = nh[2] = 0;
+        if (!ok) nh[0] = nh[1] = nh[2] = 0x7c00u;
         else nzq = (float)(fabs(N[2]) / nN * (1.0 - 1.0e-6));
     }
     nz_abs[t] = nzq;
-    if ((nh[0] | nh[1] | nh[2]) == 0) atomicAdd(counts + 0, 1u);       // stored with a zero normal: always a candidate (rover_get_cull_info)
+    if (nh[0] == 0x7c00u && order[t] != 0xffffffffu) atomicAdd(counts + 0, 1u);     // always a candidate (rover_get_cull_info); holes of the numbering aside
     ctab[t] = make_uint4(__float_as_uint(mk[0]), __float_as_uint(mk[1]), (uint32_t)zh | ((uint32_t)nh[0] << 16),
                          (uint32_t)nh[1] | ((uint32_t)nh[2] << 16));
 }
 
-// one workgroup per cell: the cell's K ids sorted ascending (empty / out-of-range ids last), dealt to the lanes in quarters;
+// one workgroup per cell: the cell's K ids (internal numbering) sorted ascending, paired and dealt to the lanes;
 // qrow[cell] = {q16, 0, 0, 0}: q = min |N_z| / |N| over the cell's triangles as a 16-bit fraction rounded down (0 = none)
 __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restrict__ map_idx, uint32_t K, uint32_t K8, uint32_t T,
-                                                         const float* __restrict__ nz_abs, int32_t* __restrict__ idx4,
-                                                         uint4* __restrict__ qrow, uint32_t* __restrict__ counts) {
+                                                         const uint32_t* __restrict__ newid, const float* __restrict__ nz_abs,
+                                                         int32_t* __restrict__ idx4, uint4* __restrict__ qrow,
+                                                         uint32_t* __restrict__ counts) {
     __shared__ uint32_t key[256];
     __shared__ float qmin[256];
     const uint32_t cell = blockIdx.x, tid = threadIdx.x, L = K8 >> 2;
     uint32_t k = 0xffffffffu;
-    if (tid < K) { const uint32_t t = (uint32_t)map_idx[(uint64_t)cell * K + tid]; if (t < T) k = t; }
+    if (tid < K) { const uint32_t t = (uint32_t)map_idx[(uint64_t)cell * K + tid]; if (t < T) k = newid[t]; }     // internal numbering
     key[tid] = k;
     qmin[tid] = k != 0xffffffffu ? nz_abs[k] : 2.0f;
     __syncthreads();
@@ -209,13 +232,36 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         if (tid < sdt) qmin[tid] = fminf(qmin[tid], qmin[tid + sdt]);
         __syncthreads();
     }
-    if (tid < K8) {
-        // sorted position tid -> slot j of lane `lane`: neighbours 2m, 2m + 1 (on a grid mesh the two triangles of one mesh
-        // cell) share a packed pair, so that a pair sent to the exact kernel tends to hold two candidates; pair m goes to
-        // lane m % L, which keeps one gather instruction of a wave on consecutive records
-        const uint32_t m = tid >> 1, lane = m % L, j = 2u * (m / L) + (tid & 1u);
-        idx4[((uint64_t)cell * L + lane) * 4u + j] = (int32_t)key[tid];     // 0xffffffff -> -1
+    // Pairing.  The internal numbering gives two triangles that were matched as spatial partners (rover_set_knn_map: mutual
+    // nearest centroids — on a grid mesh the two halves of a mesh cell) the ids 2p, 2p + 1.  Partners that are both in this
+    // cell's list share a packed pair of a lane, so that a queue entry tends to hold two candidates; the rest (singles: the
+    // partner is not in the list, or the triangle has none) are paired up in id order behind them.  Pair m goes to lane m % L,
+    // pair slot m / L, which keeps one gather instruction of a wave on neighbouring records.
+    __shared__ int32_t row[256];
+    __shared__ uint32_t wsum[2][4];
+    row[tid] = -1;
+    const uint32_t id = key[tid];
+    const bool present = id != 0xffffffffu;
+    const bool first = present && !(id & 1u) && tid + 1u < 256u && key[tid + 1u] == (id | 1u);
+    const bool second = present && (id & 1u) && tid > 0u && key[tid - 1u] == (id ^ 1u);
+    const bool single = present && !first && !second;
+    const uint64_t mf = __builtin_amdgcn_ballot_w64(first), ms = __builtin_amdgcn_ballot_w64(single);
+    const uint32_t wv = tid >> 6, ln = tid & 63u;
+    if (ln == 0u) { wsum[0][wv] = (uint32_t)__builtin_popcountll(mf); wsum[1][wv] = (uint32_t)__builtin_popcountll(ms); }
+    __syncthreads();
+    uint32_t pf = (uint32_t)__builtin_popcountll(mf & ((1ull << ln) - 1ull)), ps = (uint32_t)__builtin_popcountll(ms & ((1ull << ln) - 1ull));
+    uint32_t n_pairs = 0;
+    for (uint32_t w2 = 0; w2 < 4u; ++w2) {
+        if (w2 < wv) { pf += wsum[0][w2]; ps += wsum[1][w2]; }
+        n_pairs += wsum[0][w2];
     }
+    // (a `second` sits right behind its `first`: the same pair index; across a wave boundary pf already counts that first)
+    if (present) {
+        const uint32_t m = first ? pf : (second ? pf - 1u : n_pairs + (ps >> 1)), e = first ? 0u : (second ? 1u : (ps & 1u));
+        if (m < (K8 >> 1)) row[(m % L) * 4u + 2u * (m / L) + e] = (int32_t)id;
+    }
+    __syncthreads();
+    if (tid < K8) idx4[(uint64_t)cell * K8 + tid] = row[tid];
     if (tid == 0) {
         const float q = qmin[0];
         uint32_t q16 = 0;
@@ -515,13 +561,19 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
 
+hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint32_t T, uint32_t V, float2* out, hipStream_t s) {
+    hipLaunchKernelGGL(tri_centroid_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, tris, verts, T, V, out);
+    return hipGetLastError();
+}
+
+// T: the caller's triangle count (ids in map_idx); T_int: slots of the internal numbering (order [T_int], newid [T])
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
-                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow,
-                             float* nz_scratch, uint32_t* counts /* [2], zeroed: always-candidate triangles, cells without a cone */,
-                             hipStream_t s) {
-    hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, tris, verts, T, V, rtab);
-    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T, 256)), dim3(256), 0, s, rtab, T, ctab, nz_scratch, counts);
-    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, nz_scratch, idx4, qrow, counts);
+                             uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
+                             int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow, float* nz_scratch,
+                             uint32_t* counts /* [2], zeroed: always-candidate triangles, cells without a cone */, hipStream_t s) {
+    hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
+    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab, nz_scratch, counts);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, idx4, qrow, counts);
     return hipGetLastError();
 }
 

@@ -178,9 +178,10 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
 hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uint32_t n_sorted, const uint16_t* tab0,
                                  const uint16_t* tab1, uint32_t kp0, uint32_t kp1, uint32_t run, bool fp16_math, uint32_t early_out, float* out,
                                  hipStream_t s);
+hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint32_t T, uint32_t V, float2* out, hipStream_t s);
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
-                             uint32_t K8, uint32_t T, uint32_t V, int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow,
-                             float* nz_scratch, uint32_t* counts, hipStream_t s);
+                             uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
+                             int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow, float* nz_scratch, uint32_t* counts, hipStream_t s);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);

@@ -270,10 +270,24 @@ def irregular_height(spec: IrregularSpec):
         for (cx, cy), a, sg in zip(hill_xy, hill_a, hill_s):
             out = out + a * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2.0 * sg * sg))
         rxy, rr, rh, rp = rocks
+        if len(rr) <= 64:                                          # (the fixtures' scenes: every rock at every point)
+            for (cx, cy), r_, h_, p_ in zip(rxy, rr, rh, rp):
+                d = np.sqrt((x - cx) ** 2 + (y - cy) ** 2) / (0.75 * r_)
+                out = out + h_ * np.exp(-(d ** p_))
+            return out
+        # many rocks (bench-size scenes): a rock only reaches 4 r (exp(-(4 / 0.75)^2) < 1e-12)
+        from scipy.spatial import cKDTree
+        xb, yb = np.broadcast_arrays(x, y)
+        shape = xb.shape
+        pts = np.stack((xb.reshape(-1), yb.reshape(-1)), axis=1)
+        out = np.broadcast_to(out, shape).reshape(-1).copy()
+        tree = cKDTree(pts)
         for (cx, cy), r_, h_, p_ in zip(rxy, rr, rh, rp):
-            d = np.sqrt((x - cx) ** 2 + (y - cy) ** 2) / (0.75 * r_)
-            out = out + h_ * np.exp(-(d ** p_))
-        return out
+            ids = np.asarray(tree.query_ball_point([cx, cy], 4.0 * r_), dtype=np.int64)
+            if ids.size:
+                d = np.sqrt((pts[ids, 0] - cx) ** 2 + (pts[ids, 1] - cy) ** 2) / (0.75 * r_)
+                out[ids] += h_ * np.exp(-(d ** p_))
+        return out.reshape(shape)
 
     return z, rocks
 
@@ -293,11 +307,23 @@ def irregular_mesh(spec: IrregularSpec):
     zf, rocks = irregular_height(spec)
     rxy, rr, rh, rp = rocks
 
+    rock_tree = None
+    if len(rr) > 64:
+        from scipy.spatial import cKDTree
+        rock_tree = cKDTree(rxy)
+
+    def rock_gap(x, y):
+        """distance to the nearest rock disc (radius 1.2 r), 0 inside one"""
+        if rock_tree is None:
+            d = np.full(x.shape, np.inf)
+            for (cx, cy), r_ in zip(rxy, rr):
+                d = np.minimum(d, np.maximum(0.0, np.sqrt((x - cx) ** 2 + (y - cy) ** 2) - 1.2 * r_))
+            return d
+        dist, idx = rock_tree.query(np.stack((x, y), axis=1), k=8)       # many rocks: the 8 nearest centres decide
+        return np.maximum(0.0, dist - 1.2 * rr[idx]).min(axis=1)
+
     def target_spacing(x, y):
-        d = np.full(x.shape, np.inf)
-        for (cx, cy), r_ in zip(rxy, rr):
-            d = np.minimum(d, np.maximum(0.0, np.sqrt((x - cx) ** 2 + (y - cy) ** 2) - 1.2 * r_))
-        return np.clip(spec.fine + spec.growth * d, spec.fine, spec.coarse)
+        return np.clip(spec.fine + spec.growth * rock_gap(x, y), spec.fine, spec.coarse)
 
     pts = []
     s_l = spec.coarse
@@ -354,9 +380,12 @@ def irregular_mesh(spec: IrregularSpec):
     tris32 = np.ascontiguousarray(tris.astype(np.int32))
     # rocks-only sub-mesh (the reference's big_stones.ply): triangles whose centroid lies within 1.2 r of a rock centre
     c = verts[tris].mean(axis=1)
-    inside = np.zeros(len(tris), dtype=bool)
-    for (cx, cy), r_ in zip(rxy, rr):
-        inside |= (c[:, 0] - cx) ** 2 + (c[:, 1] - cy) ** 2 <= (1.2 * r_) ** 2
+    if rock_tree is None:
+        inside = np.zeros(len(tris), dtype=bool)
+        for (cx, cy), r_ in zip(rxy, rr):
+            inside |= (c[:, 0] - cx) ** 2 + (c[:, 1] - cy) ** 2 <= (1.2 * r_) ** 2
+    else:
+        inside = rock_gap(c[:, 0], c[:, 1]) <= 0.0
     rock_tris = np.ascontiguousarray(tris32[inside])
     stones = np.zeros((len(rr), 6), dtype=np.float64)             # stone_info.npy: centre xyz, extents, unused
     stones[:, 0:2] = rxy
@@ -387,6 +416,22 @@ def knn_map_bruteforce(verts: np.ndarray, tris: np.ndarray, n_x: int, n_y: int, 
         order = torch.sort(d2, dim=1, stable=True).indices[:, :k]
         out[s0:s0 + chunk_cells] = order.to(torch.int32)
     return out.reshape(n_x, n_y, k)
+
+
+def shuffle_triangle_ids(scene: Scene, seed: int = 0) -> Scene:
+    """The same scene with the triangle tables of both maps in a random order (ids in ``map_indices`` follow): what a mesh
+    file without any spatial order looks like to the library.  Every result of the step is unchanged."""
+    g = torch.Generator().manual_seed(seed)
+
+    def one(m: KnnMap) -> KnnMap:
+        t = m.triangles.shape[0]
+        perm = torch.randperm(t, generator=g)                      # new position p holds old triangle perm[p]
+        inv = torch.empty(t, dtype=torch.int64)
+        inv[perm] = torch.arange(t)
+        return KnnMap(inv[m.map_indices.long()].to(torch.int32), m.triangles[perm].contiguous(), m.vertices, m.cell_size)
+
+    return Scene(terrain=one(scene.terrain), rocks=one(scene.rocks), stone_info_raw=scene.stone_info_raw, heightmap=scene.heightmap,
+                 horizontal_scale=scene.horizontal_scale, vertical_scale=scene.vertical_scale, shift=scene.shift)
 
 
 def make_irregular_scene(spec: IrregularSpec, k: int = 200, terrain_idx=None, rocks_idx=None) -> tuple:

@@ -240,7 +240,7 @@ bench._device = lambda local_rank: torch.device("cpu")
 bench._init_process_group = lambda dist, device: dist.init_process_group("gloo")
 bench._make_engine = lambda n, local_rank, n_global, off: FakeEngine(n, off)
 bench._sync = lambda: None
-bench.load_scene = lambda args, device: None
+bench.load_scene = lambda args, device, local_rank=0: (None, None)
 rc = bench.main(sys.argv[1:])
 print("rank", os.environ["RANK"], "done", file=sys.stderr)
 sys.exit(rc)
