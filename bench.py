@@ -280,6 +280,16 @@ def _sync():
     torch.cuda.synchronize()
 
 
+def _gpu_event():
+    """A timing event on the current stream, or None without a GPU (the CPU stand-in of tests/test_host_logic.py)."""
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
 def _profile_entry(fname, key):
     path = os.path.join(ROOT, "profiles", fname)
     try:
@@ -416,12 +426,20 @@ def run_rank(args):
             graphs[(b, d)] = g
         g.replay()
 
-    def one_step(i, overlap):
+    wait_events = []                         # N > 1: (before, after) pairs around every point where the compute stream waits for a transfer
+
+    def one_step(i, overlap, timed=False):
         b = i % len(batches)
         d = i % depth
+        e0 = _gpu_event() if (timed and world > 1) else None
         gather.wait(d)                       # overlapped mode: the transfer that last read buffer set d must be through
+        if e0 is not None:
+            wait_events.append((e0, _gpu_event()))
         launch_step(b, d)
+        e0 = _gpu_event() if (timed and world > 1 and not overlap) else None
         gather.gather(d, wait=not overlap)   # (obs, rew, done) of this step to the learner rank
+        if e0 is not None:
+            wait_events.append((e0, _gpu_event()))
         if args.validate_goals:
             # configs[4]: reset_idx + set_targets (goal re-draw + stone-clearance validation + goal z) for the envs the
             # step flagged done, consuming the compacted ids on the device — no host sync (rover.py:356-361 has one)
@@ -459,8 +477,9 @@ def run_rank(args):
         eng.set_profiling(True)              # resets the in-library ray-cast event counters
         t0 = time.perf_counter()
         stamps, evs = [], []
+        wait_events.clear()
         for i in range(args.steps):
-            one_step(first_step + i, overlap)
+            one_step(first_step + i, overlap, timed=True)
             if args.debug_timing:
                 stamps.append(time.perf_counter())
                 ev = torch.cuda.Event(enable_timing=True)
@@ -476,11 +495,19 @@ def run_rank(args):
                   "| fence ms", 1e3 * (elapsed - (t_enq - t0)), file=sys.stderr)
         prof = eng.get_profile()
         ok = gather_check()
+        per_rank = None
         if world > 1:
+            # per rank: its own elapsed time and the time its compute stream spent waiting for (obs, rew, done) transfers
+            waited = sum(a.elapsed_time(b) for a, b in wait_events if a is not None and b is not None) * 1e-3
+            mine = torch.tensor([elapsed, waited], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = {"ms_per_step": [1e3 * float(x[0]) / args.steps for x in every],
+                        "transfer_wait_ms_per_step": [1e3 * float(x[1]) / args.steps for x in every]}
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, prof, ok
+        return elapsed, prof, ok, per_rank
 
     # Event timing is switched on BEFORE the warm-up: the first timed hipEventRecord on a stream makes the runtime
     # enable queue profiling once (tens of ms); the warm-up absorbs that, then the counters are reset.
@@ -497,12 +524,12 @@ def run_rank(args):
     overlap = can_overlap and not args.sync_gather
     for i in range(args.warmup):
         one_step(i, overlap)
-    elapsed, prof, ok = timed_pass(args.warmup, overlap)
+    elapsed, prof, ok, per_rank = timed_pass(args.warmup, overlap)
     alt = None
     if world > 1 and can_overlap and not args.no_alt_pass:
-        e2, _p2, ok2 = timed_pass(args.warmup + args.steps, not overlap)
+        e2, _p2, ok2, pr2 = timed_pass(args.warmup + args.steps, not overlap)
         alt = {"mode": "overlapped" if not overlap else "sync_gather", "value": E_global * args.steps / e2,
-               "ms_per_step": 1e3 * e2 / args.steps, "gather_check": ok2}
+               "ms_per_step": 1e3 * e2 / args.steps, "gather_check": ok2, "per_rank": pr2}
     eng.set_profiling(False)
 
     rc = 0
@@ -541,6 +568,7 @@ def run_rank(args):
                             "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"]}
         if world > 1:
             line["gather_check"] = ok
+            line["per_rank"] = per_rank          # [rank]: ms per step of that rank; ms per step its compute stream waited for a transfer (rank 0 = the root's receive time that was not hidden)
             line["gather_bytes_per_rank_per_step"] = E * (4 * W + 4 + 1)
             if alt is not None:
                 line["alt_" + alt.pop("mode")] = alt

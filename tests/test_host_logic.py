@@ -260,6 +260,7 @@ def _check_bench_line(out, extra):
     assert "cpu_baseline" not in d and set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"          # the backend really saw both ranks
     assert d["gather_check"] is True                                # root-side buffers == per-rank checksums
+    assert len(d["per_rank"]["ms_per_step"]) == 2 and all(x > 0 for x in d["per_rank"]["ms_per_step"])
     alt = d["alt_sync_gather" if extra == "" else "alt_overlapped"]
     assert alt["gather_check"] is True and alt["value"] > 0
     assert d["gather_bytes_per_rank_per_step"] == 64 * (4 * 41 + 4 + 1)

@@ -1,10 +1,12 @@
 """GPU (-m gpu): the RoverTask / RLTask / VecEnv mirror of the reference API, driven like the reference's own
 post_physics_step (rl_task.py:239-259) and pre_physics_step (rover.py:338-414)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import assert_step_close, load_golden, scene_for, states_of
+from conftest import ROOT, assert_step_close, load_golden, scene_for, states_of
 
 pytestmark = pytest.mark.gpu
 
@@ -154,3 +156,49 @@ def test_vec_env_rollout():
     assert task.curriculum_level == 2 and task.global_step == 31
     assert int(task.progress_buf.max()) <= 31
     env.close()
+
+
+_RCCL_CHILD = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ROVER_ROOT"])
+import bench
+from isaac_rover_amd.distributed import StepGather
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+bench._init_process_group(dist, dev)                      # init_process_group("nccl", device_id=cuda:0): RCCL loads and binds the device
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dist.barrier()
+t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.25
+g = StepGather(64, 41, dev, world=1, rank=0, depth=2)
+obs, rew, done = g.local_views(1)
+obs.fill_(0.5); rew.fill_(2.0); done.fill_(1)            # done travels as uint8
+mine = torch.stack([bench._checksums(torch, *g.local_views(d)) for d in range(2)])
+got = [torch.zeros_like(mine)]
+dist.all_gather(got, mine)                                # the int64 checksum exchange of bench.py's gather_check
+assert torch.equal(got[0], mine)
+u8 = [torch.zeros_like(done)]
+dist.all_gather(u8, done)                                 # uint8 tensors through RCCL
+assert torch.equal(u8[0], done)
+assert g.gather(1) is not None and g.global_views(1)[2].dtype == torch.uint8
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("rccl world-size-1 ok")
+"""
+
+
+def test_rccl_world_size_1_in_a_fresh_process(tmp_path):
+    """First contact with RCCL before the 8-GPU node: in a FRESH child process (the parent test process has long initialised the
+    GPU: nothing is re-exec'ed, a new process is started and waited for) `init_process_group("nccl", device_id=...)` exactly as
+    bench.py does it, barrier, all_reduce(MAX) of the f64 elapsed time, all_gather of the int64 checksum tensor and of a uint8 done
+    tensor, StepGather(world=1), destroy_process_group."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29000 + os.getpid() % 2000),
+               ROVER_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0 and "rccl world-size-1 ok" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
