@@ -272,6 +272,11 @@ ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_
  *        vectors (captured from the reference on CPU) pin.  1 = cuda_rcp: multiplication by 1.0f / 0.1f = 10.0f, what ATen's
  *        CUDA kernel does ("a * reciprocal(b)" for a CPU-scalar divisor) — the device the reference actually runs on.  The
  *        two differ only for coordinates within an ulp of a .5 tie of the cell grid (tests/test_oracle_golden.py).
+ * name = "cull_queue_mb": most MiB the candidate queue of the culled ray cast may take (default 1024).  A wave of a launch owns a
+ *        region of 1 024 entries (8 KB; a run that finds more finishes them and scans on), so a launch needs 8 KB per run of 64
+ *        sorted rays: 712 MB at 65 536 envs x 63 rays.  Past the budget a step's ray cast is cut into several launches that
+ *        re-use the regions (each extra launch costs ~25 us); an allocation failure is an error (ROVER_E_NOMEM), never a
+ *        silent change of kernel.
  * name = "raycast_run": sorted rays per wave for variants 2 and 3 (default 0 = auto: 32 on full batches, down to 4 on small
  *        ones; variant 3 caps it at 64). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
@@ -297,6 +302,7 @@ typedef struct {
     uint64_t rays, candidate_pairs, rays_both_tests, bins;
     uint64_t max_pairs_per_run;    /* most queue entries any one run of sorted rays produced */
     uint64_t queue_bytes;          /* size of the candidate queue allocation */
+    uint64_t launches_per_step;    /* 1, unless the queue budget ("cull_queue_mb") forces a step's ray cast into slices */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

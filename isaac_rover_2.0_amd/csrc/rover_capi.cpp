@@ -29,12 +29,13 @@ struct rover_ctx {
     uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint4* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
-    uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast (worst case: 128 entries per ray)
+    uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
     uint4* d_cull_stats = nullptr;      // per-wave counters of the last culled launch (rover_get_cull_info)
     uint32_t cull_stat_slots = 0;
     int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
-    bool cull_queue_failed = false;     // the worst-case queue does not fit (huge E x rays): the binned kernel runs instead
+    uint64_t cull_budget = 1ull << 30;  // option "cull_queue_mb": most bytes the queue may take (a step is cast in several launches beyond it)
+    uint32_t cull_launches = 1;
     uint32_t cull_run = 0;              // run length the queue was sized for
     // distribution
     double* d_dist = nullptr;       // [P][3]
@@ -155,7 +156,7 @@ static int effective_variant(const rover_ctx* c) {
     if (c->variant == 1 || !v2_ok) return 1;
     if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
     // variant 3 (culled): f32 arithmetic only — the as-shipped fp16 mode keeps the binned kernel
-    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1] && c->precision != 2 && !c->cull_queue_failed;
+    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1] && c->precision != 2;
     if (c->variant == 2 || !v3_ok) return 2;
     return 3;
 }
@@ -193,27 +194,22 @@ static int alloc_bins(rover_ctx* c) {
     return alloc_cull_queue(c);       // sized here, not in the step: hipMalloc is not allowed while a stream is capturing
 }
 
-// candidate queue of the culled ray cast, sized for the worst case of the run length in force
+// candidate queue of the culled ray cast (one bounded region per resident wave) + its per-wave counters, for the options in force
 static int alloc_cull_queue(rover_ctx* c) {
-    c->cull_queue_failed = false;
     if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) != 3) return ROVER_OK;
     const uint32_t run = effective_run(c);
-    uint64_t n_runs = 0;
-    const uint64_t entries = cull_queue_entries(valid_rays(c), run, &n_runs);
-    if (c->d_cull_queue && entries <= c->cull_entries && run == c->cull_run) return ROVER_OK;
-    dfree(c->d_cull_queue);
+    const uint64_t entries = cull_queue_entries(valid_rays(c), (uint32_t)c->cfg.num_envs * (uint32_t)c->P, run, c->cull_budget, &c->cull_launches);
+    if (c->d_cull_queue && c->d_cull_stats && entries == c->cull_entries && run == c->cull_run) return ROVER_OK;
+    dfree(c->d_cull_queue); dfree(c->d_cull_stats);
     c->cull_entries = 0;
-    // 1 KB per ray (a ray can add 128 entries): 4.2 GB at 65 536 envs x 63 rays.  Beyond 64 GB, or when the device cannot
-    // give it, the step runs the binned kernel (variant 2, same results) instead of failing.
-    const uint64_t bytes = entries * sizeof(uint2);
-    if (bytes > (64ull << 30) || hipMalloc((void**)&c->d_cull_queue, bytes) != hipSuccess) {
+    // no fallback to another kernel: a queue that cannot be allocated is an error the caller sees
+    hipError_t e = hipMalloc((void**)&c->d_cull_queue, entries * sizeof(uint2));
+    if (e != hipSuccess) {
         (void)hipGetLastError();
         c->d_cull_queue = nullptr;
-        c->cull_queue_failed = true;
-        return ROVER_OK;
+        return fail(c, ROVER_E_NOMEM, "culled ray cast: candidate queue of %llu bytes: %s", (unsigned long long)(entries * sizeof(uint2)), hipGetErrorString(e));
     }
     c->cull_entries = entries; c->cull_run = run;
-    dfree(c->d_cull_stats);
     c->cull_stat_slots = rover::cull_stat_slots(valid_rays(c), run);
     HIP_TRY(c, hipMalloc((void**)&c->d_cull_stats, (size_t)c->cull_stat_slots * sizeof(uint4)));
     HIP_TRY(c, hipMemset(c->d_cull_stats, 0, (size_t)c->cull_stat_slots * sizeof(uint4)));
@@ -238,7 +234,7 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_pairs, n * sizeof(uint2)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
-    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (52 * sizeof(float) + sizeof(int64_t));
+    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (64 * sizeof(float) + sizeof(int64_t));
     c->rays_valid = false;
     c->ws_ok = true;
     return alloc_bins(c);
@@ -359,6 +355,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 2) ? x : 0; }
+    if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     DeviceGuard guard(cfg->device);
     e = guard.err;
@@ -626,6 +623,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.out = c->d_dist_out;
     a.queue = c->d_cull_queue;
     a.stats = c->d_cull_stats;
+    a.queue_entries = c->cull_entries;
     return a;
 }
 
@@ -905,7 +903,9 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
         info->K[w] = c->map[w].K; info->K8[w] = c->map[w].K8; info->X[w] = c->map[w].X; info->Y[w] = c->map[w].Y;
         info->table_bytes[w] = c->table_bytes[w];
     }
-    info->workspace_bytes = c->workspace_bytes;
+    // the per-step workspace: ray records, distances, sort buffers, env records, and the culled ray cast's queue + counters
+    info->workspace_bytes = c->workspace_bytes + (c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0) +
+                            (c->d_cull_stats ? (uint64_t)c->cull_stat_slots * sizeof(uint4) : 0);
     info->raycast_variant = (c->have_map[0] && c->have_map[1]) ? effective_variant(c) : 0;
     return ROVER_OK;
 }
@@ -919,6 +919,7 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
         out->cells_without_cone[w] = c->cull_nocone[w];
     }
     out->queue_bytes = c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0;
+    out->launches_per_step = c->d_cull_queue ? c->cull_launches : 0;
     if (!c->d_cull_stats || c->last_variant != 3) return ROVER_OK;
     USE_DEVICE(c);
     HIP_TRY(c, hipDeviceSynchronize());
@@ -1129,6 +1130,11 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->hf.rcp = c->cell_rcp;
         c->rays_valid = false;
         return ROVER_OK;
+    }
+    if (!strcmp(name, "cull_queue_mb")) {
+        if (value < 1 || value > (1 << 20)) return fail(c, ROVER_E_INVALID, "cull_queue_mb must be in [1, 1048576]");
+        c->cull_budget = (uint64_t)value << 20;
+        return alloc_cull_queue(c);
     }
     if (!strcmp(name, "raycast_run")) {
         if (value < 0 || value > 4096) return fail(c, ROVER_E_INVALID, "raycast_run must be 0 (auto) or in [1, 4096]");

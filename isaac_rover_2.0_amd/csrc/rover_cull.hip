@@ -372,19 +372,30 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 // bounding-sphere / normal records (4 per lane, as 2 packed pairs); per ray it runs tests (A), (B) on all of them and
 // appends one 8-byte entry per lane-pair that holds a candidate to the wave's own region of the global candidate queue:
 //     entry = { id0 | map << 31,  id1 | position in the run << 26 }          (CULL_NOID = empty slot next to a candidate)
-// Region w = [w * run * 128, ...): a ray adds at most 128 entries, so it cannot overflow and nothing is allocated on the
-// device (one returning atomic per wave on a shared counter cost 2.7 ms).
+// A wave owns a region of CULL_QCAP entries for the launch (nothing is allocated on the device: one returning atomic per wave on a
+// shared counter cost 2.7 ms).  A ray adds at most 128 entries; a wave that has more than CULL_QCAP - 128 after a ray runs phase 2
+// on what it has and scans on from the next ray (a "segment"), so the region cannot overflow whatever the mesh.
 // Nothing here is heavy in registers or LDS, so 7-8 waves per SIMD hide the latencies of the id rows (HBM, streamed
 // through LDS CULL_RING bins ahead) and of the record gathers (L2).
 // ---------------------------------------------------------------------------------------------------
+#define CULL_QCAP 1024u              // entries of one queue region (a wave's own).  A ray adds at most 128, so a wave that finds more than
+                                     // CULL_QCAP - 128 entries after a ray finishes (exact phase) what it has and scans on from the next ray
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
-        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp0, uint32_t kp1, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chs, uint32_t chr, uint32_t run_r, uint2 *__restrict__ queue,                                      \
-        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats
-#define CULL_SCAN_PASS rays, sorted, n_sorted, idx0, idx1, ctab0, ctab1, qrow0, qrow1, kp0, kp1, run, n_blocks, split, t8, r8, chs, chr, run_r, queue, rtab0, rtab1, out, stats
+        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0
 
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
+    // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
+    // exposed memory latency per run instead of one per bin); s_bk: the run's 64 running minima as ordered-u32 keys.
+    __shared__ int4 s_ids[4][CULL_RING][64];
+    __shared__ uint32_t s_bk[4][64];
+    const uint32_t x = blockIdx.x & 7u, w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* const bk = s_bk[w];
+    // the wave's region of the candidate queue (CULL_QCAP entries): by its position in THIS launch — a step whose regions would
+    // exceed the queue budget is cast in several launches over slices [j0, j0 + gridDim.x / 8) of the block slots, which re-use them
+    uint2* const qw = queue + (size_t)(blockIdx.x * 4u + w) * CULL_QCAP;
 
     // XCD-aware order (blocks b, b + 8, ... run on one XCD): the TERRAIN blocks [0, split) are dealt to the XCDs in chunks of
     // 2^chs consecutive blocks, round robin, then the ROCKS blocks [split, n_blocks) the same way (chunks of 2^chr).  Chunks, so that neighbouring bins
@@ -392,9 +403,15 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     // it is — with one contiguous eighth of each map per XCD the slowest XCD finished 27 % after the fastest (per-XCD end times of a
     // diagnostic build) and the launch takes as long as the slowest; terrain before rocks on every XCD, so that the cheap rays
     // (0.7 candidate pairs against 8) are the ones that drain at the end.
-    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    // (One workgroup per block slot, started by the hardware as others finish.  Measured against it, round 3: a grid of just the
+    //  resident workgroups, each walking the slots j, j + stride, ... of its XCD with a queue region of its own — 56 MB of queue for
+    //  any batch — took 0.69 - 0.82 ms instead of 0.58: the cost of a block depends on where its rays are, and the slowest of 1 792
+    //  static sums of ~12 blocks ends a third after the mean; the hardware's dynamic order ends one block after it.)
+    const uint32_t j = (blockIdx.x >> 3) + j0;
+    {
     uint32_t lb;
     // (chs / chr = 31: one contiguous eighth per XCD — small batches, where a chunk would be too few bins to share anything)
+    const uint32_t chs = chsr & 0xffu, chr = chsr >> 8;
     if (j < t8) {
         lb = chs == 31u ? x * t8 + j : ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u));
         if (lb >= split) return;
@@ -403,42 +420,48 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         lb = split + (chr == 31u ? x * r8 + jr : ((((jr >> chr) << 3) + x) << chr) + (jr & ((1u << chr) - 1u)));
         if (lb >= n_blocks) return;
     }
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
     // blocks [0, split) walk runs of `run` rays, the blocks behind them (the rocks part) runs of `run_r`
     const uint32_t my_run = lb < split ? run : run_r;
     const uint32_t i0 = lb < split ? wave * run : split * 4u * run + (wave - split * 4u) * run_r;
     if (i0 >= n_sorted) return;
     const uint32_t n_run = min(my_run, n_sorted - i0);               // <= 64
-    // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
-    // id rows ahead.  The rays' parameters come by scalar loads (s_load_dwordx8 through the ray id of lane r), requested one
-    // ray ahead so that their latency passes under the previous ray's arithmetic.
+    // The run's ray ids, one per lane.  The rays' parameters come by scalar loads (s_load_dwordx8 through the ray id of lane r),
+    // requested one ray ahead so that their latency passes under the previous ray's arithmetic.
     const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
+    wave_lds_sync();
+    bk[lane] = fkey(RAY_MISS);                 // 11.0 where a ray has no candidate at all (a culled triangle contributes exactly that)
+    uint32_t ctot = 0, n_both = 0, n_bins = 0; // queue entries / rays that ran both tests / bins walked (rover_get_cull_info)
+    uint32_t r_next = 0;                       // first ray of the run that is not scanned yet
+    // One SEGMENT = scan rays [r_next, ...) until the run ends or the queue region could overflow with one more ray, then the exact
+    // arithmetic on the entries.  Nearly every run is one segment (a run of 64 terrain rays queues ~500 entries).  Everything a
+    // segment needs besides the ray ids is derived here, inside the loop: nothing but `gid` stays live across the exact phase,
+    // which is the kernel's register high-water mark.
+    while (r_next < n_run) {
+    // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
+    // id rows ahead.
     const uint32_t key = rays[gid].cell | (rays[gid].flags << 31);                     // cell | map << 31
     const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
     // bit i: ray i starts a new (map, cell) bin
     const uint64_t heads = __builtin_amdgcn_ballot_w64(lane < n_run && (lane == 0u || key != prev));
-    // The id rows of the run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
-    // exposed memory latency per run instead of one per bin).
-    __shared__ int4 s_ids[4][CULL_RING][64];
-    uint64_t pf_heads = heads;                 // bins whose row is not requested yet
-    uint32_t pf_n = 0, use_n = 0;              // rows requested / consumed so far (slot = count % CULL_RING)
-    // Per ray, for all 64 at once: the address of its bin's id row and the bin's normal cone (the cell's q as a 16-bit fraction,
-    // 0 = none) — a bin then costs two v_readlane for its row address and one for its cone instead of a chain of scalar selects,
-    // a 64-bit multiply and an LDS read per bin.
-    const uint32_t kmap = key >> 31, kcell = key & 0x7fffffffu, kL = (kmap ? kp1 : kp0) >> 2;
-    const uint64_t row_addr = reinterpret_cast<uint64_t>(kmap ? idx1 : idx0) + (uint64_t)kcell * kL * 16ull;
+    // Per ray, for all 64 at once: the byte offset of its bin's id row in its map's table with the map in bit 0 (rows are
+    // multiples of 16 bytes; tables stay below 4 GB, rover_set_knn_map checks) and the bin's normal cone (the cell's q as a 16-bit
+    // fraction, 0 = none) — a bin then costs one v_readlane for its row and one for its cone, and these two registers and the ray
+    // ids are all the per-run state a lane carries through the scan.
+    const uint32_t kmap = key >> 31, kcell = key & 0x7fffffffu;
+    const uint32_t rowm = (kcell * (((kmap ? kp01 >> 16 : kp01) & 0xffffu) >> 2) * 16u) | kmap;
     const uint32_t q16v = (kmap ? qrow1 : qrow0)[kcell].x;
-    // this lane's slot in an id row of either map (lanes past K8 / 4 repeat the last one), as a byte offset
-    const uint32_t lo0 = min(lane, (kp0 >> 2) - 1u) << 4, lo1 = min(lane, (kp1 >> 2) - 1u) << 4;
+    uint64_t hm = (heads | (1ull << r_next)) & (~0ull << r_next);        // bins of the segment (its first ray opens one)
+    n_bins += (uint32_t)__builtin_popcountll(hm);
+    uint64_t pf_heads = hm;                    // bins whose row is not requested yet
+    uint32_t pf_n = 0, use_n = 0;              // rows requested / consumed so far (slot = count % CULL_RING)
+    // this lane's slot in an id row of map m (lanes past K8 / 4 repeat the last one: a duplicate candidate cannot change a min), as a byte offset
+    auto lane_off = [&](uint32_t m) { return min(lane, (((m ? kp01 >> 16 : kp01) & 0xffffu) >> 2) - 1u) << 4; };
     auto prefetch_row = [&]() {
-        const uint32_t j = (uint32_t)__builtin_ctzll(pf_heads);
+        const uint32_t jj = (uint32_t)__builtin_ctzll(pf_heads);
         pf_heads &= pf_heads - 1ull;
-        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) >> 31;
-        const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)row_addr, (int)j) |
-                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(row_addr >> 32), (int)j) << 32);
-        // lanes past K (K8 < 256) repeat the last lane's triangles: a duplicate candidate cannot change a min
-        const char* src = reinterpret_cast<const char*>(base) + (m2 ? lo1 : lo0);
+        const uint32_t rm = (uint32_t)__builtin_amdgcn_readlane((int)rowm, (int)jj), m2 = rm & 1u;
+        const char* src = reinterpret_cast<const char*>(m2 ? idx1 : idx0) + (rm & ~15u) + lane_off(m2);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
         ++pf_n;
@@ -446,25 +469,23 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
 #pragma unroll 1
     for (int d = 0; d < CULL_RING; ++d)
         if (pf_heads) prefetch_row();
-    uint2* const qw = queue + (size_t)i0 * 128u;             // the wave's region of the candidate queue (128 entries per ray)
     uint32_t cused = 0;
-    uint32_t n_both = 0;                                     // rays that ran both tests (rover_get_cull_info)
     auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
         const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
         a4 = rp[0]; b4 = rp[1];
     };
     float4 nxa, nxb;
-    load_ray(0u, nxa, nxb);
-    uint64_t hm = heads;
-    while (hm) {                               // one (map, cell) bin of the run: rays [i, i_end)
+    load_ray(r_next, nxa, nxb);
+    bool full = false;
+    while (hm && !full) {                      // one (map, cell) bin of the run: rays [i, i_end)
         const uint32_t i = (uint32_t)__builtin_ctzll(hm);
         hm &= hm - 1ull;
         const uint32_t i_end = hm ? (uint32_t)__builtin_ctzll(hm) : n_run;
-        const uint32_t map = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i) >> 31;
+        const uint32_t map = (uint32_t)__builtin_amdgcn_readlane((int)rowm, (int)i) & 1u;
         // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
-        const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[w][use_n % CULL_RING][0]) + (map ? lo1 : lo0));
+        const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[w][use_n % CULL_RING][0]) + lane_off(map));
         // the cell's normal cone as a 16-bit fraction (0: none)
         const uint32_t q16 = (uint32_t)__builtin_amdgcn_readlane((int)q16v, (int)i);
         ++use_n;
@@ -472,7 +493,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         const uint4* ct = map ? ctab1 : ctab0;
         uint4 rec[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rec[j] = ct[id[j] < 0 ? 0 : id[j]];
+        for (int jj = 0; jj < 4; ++jj) rec[jj] = ct[id[jj] < 0 ? 0 : id[jj]];
         if (pf_heads) { wave_lds_sync(); prefetch_row(); }              // into the slot just read (the ids are in registers)
         CullRegs t;
         uint32_t qid[2][2];                    // the lane's ids as queue-entry fields
@@ -494,7 +515,8 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             qid[p][0] = (e0 ? (uint32_t)id[2 * p] : CULL_NOID) | (map << 31);
             qid[p][1] = e1 ? (uint32_t)id[2 * p + 1] : CULL_NOID;
         }
-        for (uint32_t r = i; r < i_end; ++r) {
+        uint32_t r = i;
+        for (; r < i_end; ++r) {
             // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
             const float4 ra = nxa, rb = nxb;
             load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
@@ -527,7 +549,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
                     any[p] = ~(rej0 & rej1);                                            // (all 64 lanes are active here)
                 }
             }
-            {
+            if (any[0] | any[1]) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     if (any[p]) {
@@ -537,23 +559,26 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
                         cused += (uint32_t)__builtin_popcountll(any[p]);
                     }
                 }
+                // the next ray could add 128 more: finish what is queued first (rare: > 14 candidate pairs per ray over a whole run)
+                if (cused > CULL_QCAP - 128u) { full = true; ++r; break; }
             }
         }
+        r_next = r;
     }
-    // PHASE 2 on the wave's own entries.  They were stored to global memory by this wave and are read back by this wave:
-    // waiting for the stores' acknowledgement (they write through to L2) is all the ordering that takes — no other wave
-    // touches this queue region, and the vector L1 cannot hold a stale line of it (regions are 128-byte aligned, nothing
-    // read them in this launch).  An agent-scope fence here writes back the whole L2 of the XCD: 3.7 ms instead of 0.6.
+    // PHASE 2 on the wave's own entries.  They were stored to global memory by this wave and are read back by this wave, and no
+    // other wave ever touches the region: a wave sees its own stores in program order, so waiting for their acknowledgement is all
+    // the ordering that takes.  An agent-scope fence here writes back the whole L2 of the XCD: 3.7 ms instead of 0.6.
+    // The wait also retires id-row loads of bins this segment did not reach (the ring restarts with the next segment).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t* bk = reinterpret_cast<uint32_t*>(&s_ids[w][0][0]);   // the id ring is dead: 64 result slots of the run
-    wave_lds_sync();
-    bk[lane] = fkey(RAY_MISS);
     wave_lds_sync();
     cull_exact(rays, rtab0, rtab1, qw, cused, gid, lane, bk);
+    ctot += cused;
+    }
     wave_lds_sync();
     if (lane < n_run) out[gid] = funkey(bk[lane]);
     // per-wave counters of THIS launch (plain stores, 16 B per wave; summed on the host by rover_get_cull_info)
-    if (lane == 0u) stats[wave] = make_uint4(cused, n_run, n_both, (uint32_t)__builtin_popcountll(heads));
+    if (lane == 0u) stats[wave] = make_uint4(ctot, n_run, n_both, n_bins);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -577,33 +602,54 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
     return hipGetLastError();
 }
 
-hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
-    if (a.run > CULL_RUNMAX) a.run = CULL_RUNMAX;
-    if (a.run == 0) a.run = 1;
+struct CullGrid { uint32_t run, run_r, split, n_blocks, chs, chr, t8, r8; };
+static CullGrid cull_grid(uint32_t n_sorted, uint32_t n_terrain, uint32_t run) {
+    CullGrid g{};
+    if (run > CULL_RUNMAX) run = CULL_RUNMAX;
+    if (run == 0) run = 1;
+    g.run = run;
     // the sorted list is all terrain rays, then all rock rays: blocks [0, split) are (but for a few rays) terrain
     // The rocks part comes last on every XCD and drains the launch: with runs of 32 there its waves live half as long and the
     // machine empties faster at the end (last workgroup start to kernel end was 70 us of 580) — 0.575 -> 0.570 ms; 16: 0.581
-    const uint32_t run_r = a.run >= 64u ? 32u : a.run;
-    uint32_t split = blocks_for(blocks_for(a.n_terrain, a.run), 4);
-    const uint64_t covered = (uint64_t)split * 4u * a.run;
-    if (covered >= a.n_sorted) { split = blocks_for(blocks_for(a.n_sorted, a.run), 4); a.n_blocks = split; }
-    else a.n_blocks = split + blocks_for(blocks_for(a.n_sorted - (uint32_t)covered, run_r), 4);
+    g.run_r = run >= 64u ? 32u : run;
+    g.split = blocks_for(blocks_for(n_terrain, run), 4);
+    const uint64_t covered = (uint64_t)g.split * 4u * run;
+    if (covered >= n_sorted) { g.split = blocks_for(blocks_for(n_sorted, run), 4); g.n_blocks = g.split; }
+    else g.n_blocks = g.split + blocks_for(blocks_for(n_sorted - (uint32_t)covered, g.run_r), 4);
     // chunks of blocks dealt round robin to the 8 XCDs, per XCD ceil(chunks / 8) chunks of each part.  A chunk is 16 384 rays (64 blocks of
     // 4 runs of 64: a few map rows of bins, which share most of their triangles) when that gives every XCD >= 12 chunks of the part;
     // otherwise one contiguous eighth per XCD (4 096 envs, one call: chunks of 16 small blocks 0.112 ms, contiguous 0.104)
     // (65 536 envs, one call: 4 / 8 / 16 / 32 blocks 0.584-0.596 ms, 64 blocks 0.579-0.581, 256 blocks 0.631; contiguous eighths 0.590-0.597)
-    auto chunk_shift = [](uint32_t blocks, uint32_t run) {
+    auto chunk_shift = [](uint32_t blocks, uint32_t r) {
         uint32_t c = 0;
-        while ((4u * run << c) < 16384u) ++c;                        // blocks per chunk = 2^c
+        while ((4u * r << c) < 16384u) ++c;                          // blocks per chunk = 2^c
         return (blocks >> c) >= 96u ? c : 31u;
     };
-    const uint32_t chs = chunk_shift(split, a.run), chr = chunk_shift(a.n_blocks - split, run_r);
-    const uint32_t t8 = chs == 31u ? blocks_for(split, 8) : blocks_for(blocks_for(split, 1u << chs), 8) << chs;
-    const uint32_t r8 = chr == 31u ? blocks_for(a.n_blocks - split, 8) : blocks_for(blocks_for(a.n_blocks - split, 1u << chr), 8) << chr;
-    hipLaunchKernelGGL(cull_scan_kernel, dim3((t8 + r8) * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
-                       reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
-                       a.kp0, a.kp1, a.run, a.n_blocks, split, t8, r8, chs, chr, run_r, a.queue, reinterpret_cast<const RawTri*>(a.rtab0),
-                       reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats);
+    g.chs = chunk_shift(g.split, run); g.chr = chunk_shift(g.n_blocks - g.split, g.run_r);
+    g.t8 = g.chs == 31u ? blocks_for(g.split, 8) : blocks_for(blocks_for(g.split, 1u << g.chs), 8) << g.chs;
+    g.r8 = g.chr == 31u ? blocks_for(g.n_blocks - g.split, 8) : blocks_for(blocks_for(g.n_blocks - g.split, 1u << g.chr), 8) << g.chr;
+    return g;
+}
+
+// block slots per XCD one launch may cover so that its queue regions (8 XCDs x 4 waves x CULL_QCAP entries per slot) fit `entries`
+static uint32_t cull_slots_per_launch(uint64_t entries) {
+    const uint64_t s = entries / (8ull * 4ull * CULL_QCAP);
+    return (uint32_t)(s < 1 ? 1 : (s > 0x7fffffffull ? 0x7fffffffull : s));
+}
+
+hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
+    const CullGrid g = cull_grid(a.n_sorted, a.n_terrain, a.run);
+    const uint32_t slots = g.t8 + g.r8;                              // block slots per XCD
+    const uint32_t per = cull_slots_per_launch(a.queue_entries);
+    // one launch, unless the queue regions of all slots exceed the budget the queue was sized for (huge batches): then slices
+    // of the slot list, one launch each on the same stream, re-using the regions
+    for (uint32_t j0 = 0; j0 < slots; j0 += per) {
+        const uint32_t n = slots - j0 < per ? slots - j0 : per;
+        hipLaunchKernelGGL(cull_scan_kernel, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
+                           reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
+                           a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
+                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0);
+    }
     return hipGetLastError();
 }
 
@@ -611,17 +657,19 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run) {
     if (run > CULL_RUNMAX) run = CULL_RUNMAX;
     if (run == 0) run = 1;
-    const uint32_t rr = run >= 64u ? 32u : run;                     // the rocks part walks shorter runs (launch_raycast_culled)
+    const uint32_t rr = run >= 64u ? 32u : run;                     // the rocks part walks shorter runs (cull_grid)
     return (uint32_t)(4u * ((n_rays / rr + 4u) / 4u + 3u));
 }
 
-// entries the candidate queue must hold for n_rays rays in runs of `run`: every run owns run x 128 (a ray adds at most 128)
-uint64_t cull_queue_entries(uint64_t n_rays, uint32_t run, uint64_t* n_runs) {
-    if (run > CULL_RUNMAX) run = CULL_RUNMAX;
-    if (run == 0) run = 1;
-    const uint64_t n_waves = (n_rays + run - 1) / run;
-    if (n_runs) *n_runs = n_waves;
-    return n_waves * run * 128u;
+// Entries of the candidate queue: one region of CULL_QCAP entries per wave of a launch, capped by `budget_bytes` (a launch then
+// covers a slice of the block slots; *n_launches says how many a step takes).
+uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches) {
+    const CullGrid g = cull_grid((uint32_t)n_rays, n_terrain, run);
+    const uint32_t slots = g.t8 + g.r8;
+    uint32_t per = cull_slots_per_launch(budget_bytes / sizeof(uint2));
+    if (per > slots) per = slots ? slots : 1u;
+    if (n_launches) *n_launches = slots ? (slots + per - 1u) / per : 1u;
+    return (uint64_t)per * 8u * 4u * CULL_QCAP;
 }
 
 }  // namespace rover

@@ -64,11 +64,12 @@ struct CullArgs {
     const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
     uint32_t kp0, kp1, run, n_blocks;
     float* out;                  // [E*R8] distances
-    uint2* queue;                // candidate queue: one region of run x 128 8-byte entries per run
+    uint2* queue;                // candidate queue: one region of CULL_QCAP 8-byte entries per wave of a launch
+    uint64_t queue_entries;      // its size: a step whose regions would not fit is cast in several launches
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
-uint64_t cull_queue_entries(uint64_t n_rays, uint32_t run, uint64_t* n_runs);
+uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches);
 
 // n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own
 // expansion of a division by a run-time value is ~30 (32-bit) / ~110 (64-bit) dependent instructions per thread.

@@ -355,14 +355,22 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
     eng.close()
     for key in ref:
         np.testing.assert_array_equal(ref1[key], ref[key], err_msg=f"{key} variant 1 vs 2")
-    for run in (0, 7, 64):
+    most = 0
+    for run, queue_mb in ((0, None), (7, None), (64, None), (64, 1)):
         eng = make_engine(scene, distn, n, variant=3, run=run or None)
+        if queue_mb:                                  # a 1 MB queue budget: the step's ray cast is cut into slices that re-use the regions
+            eng.set_option("cull_queue_mb", queue_mb)
         got = hip_step(eng, st)
         ci = eng.cull_info()
         eng.close()
         for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run}")
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run} queue_mb={queue_mb}")
         assert ci["always_candidate_triangles"][0] > 0 and ci["rays_both_tests"] > 0
+        assert ci["launches_per_step"] == (1 if not queue_mb else ci["launches_per_step"]) and (not queue_mb or ci["launches_per_step"] > 4)
+        assert ci["queue_bytes"] <= (queue_mb or 1024) << 20
+        most = max(most, ci["max_pairs_per_run"])
+    # runs that found more candidates than a queue region holds (1 024 entries) were cast in several segments
+    assert most > 1024, most
     assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
