@@ -26,6 +26,8 @@ struct rover_ctx {
     // unit normal (16 B) and the nine fp16 vertex components (20 B)
     int32_t* cull_idx[2]{nullptr, nullptr};
     uint4* cull_ctab[2]{nullptr, nullptr};
+    uint4* cull_ctab_h[2]{nullptr, nullptr};    // the same for the as-shipped fp16 arithmetic's rejection proof (ray_precision 2)
+    uint4* cull_qrow_h[2]{nullptr, nullptr};
     uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint4* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
@@ -34,6 +36,8 @@ struct rover_ctx {
     uint4* d_cull_stats = nullptr;      // per-wave counters of the last culled launch (rover_get_cull_info)
     uint32_t cull_stat_slots = 0;
     int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
+    int64_t cull_always_h[2]{0, 0}, cull_nocone_h[2]{0, 0};
+    double cull_eta_h = 0.06;           // free parameter of the fp16 proof (rover_cull.hip, cull_proof_h); ROVER_CULLH_ETA for experiments
     uint64_t cull_budget = 1ull << 30;  // option "cull_queue_mb": most bytes the queue may take (a step is cast in several launches beyond it)
     uint32_t cull_launches = 1;
     uint32_t cull_run = 0;              // run length the queue was sized for
@@ -155,8 +159,9 @@ static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
     if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
-    // variant 3 (culled): f32 arithmetic only — the as-shipped fp16 mode keeps the binned kernel
-    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1] && c->precision != 2;
+    if (c->variant == 0 && c->precision == 2 && c->have_dist && valid_rays(c) <= 131072u) return 2;      // small batches, as shipped: binned
+    // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
+    const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
     return 3;
 }
@@ -355,6 +360,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 2) ? x : 0; }
+    if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     DeviceGuard guard(cfg->device);
@@ -370,7 +376,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -418,18 +424,18 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     }
     // tables of the culled ray cast (64 lanes x 4 triangles; triangle ids and the map bit share 32 bits of a queue entry)
     int32_t* d_cidx = nullptr;
-    uint4* d_ctab = nullptr;
+    uint4 *d_ctab = nullptr, *d_ctab_h = nullptr;
     uint16_t* d_rtab = nullptr;
-    uint4* d_qrow = nullptr;
+    uint4 *d_qrow = nullptr, *d_qrow_h = nullptr;
     float* d_nz = nullptr;
     uint32_t* d_cnt = nullptr;
-    uint32_t h_cnt[2] = {0, 0};
+    uint32_t h_cnt[4] = {0, 0, 0, 0};
     uint64_t cull_bytes = 0;
     uint32_t *d_order = nullptr, *d_newid = nullptr;
     if (K8 <= 256 && (uint32_t)T < 0x1ffffffu) {
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t);
         uint32_t T_int = 0;
-        auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_rtab); dfree(d_qrow); dfree(d_nz); dfree(d_cnt);
+        auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_nz); dfree(d_cnt);
                             dfree(d_order); dfree(d_newid); dfree(d_table); };
         // internal triangle numbering (spatial partners get ids 2p, 2p + 1, pairs ordered along a Morton curve): cull_numbering()
         std::vector<uint32_t> order, newid((size_t)T);
@@ -448,18 +454,19 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        cull_bytes = b_idx + b_ct + b_rt + n_cells * sizeof(uint4);
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint4);
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
+            (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint4))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint4))) != hipSuccess ||
             (e = hipMalloc((void**)&d_nz, (uint64_t)T_int * sizeof(float))) != hipSuccess ||
-            (e = hipMalloc((void**)&d_cnt, 2 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_order, (uint64_t)T_int * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_newid, (uint64_t)T * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMemcpy(d_order, order.data(), (uint64_t)T_int * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemset(d_cnt, 0, 2 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMemset(d_cnt, 0, 4 * sizeof(uint32_t))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
-                                   d_ctab, d_rtab, d_qrow, d_nz, d_cnt, nullptr)) != hipSuccess ||
+                                   d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
             drop();
@@ -469,10 +476,13 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     cleanup();
     dfree(d_nz); dfree(d_cnt); dfree(d_order); dfree(d_newid);
     c->cull_always[which] = h_cnt[0]; c->cull_nocone[which] = h_cnt[1]; c->cull_tris[which] = T;
+    c->cull_always_h[which] = h_cnt[2]; c->cull_nocone_h[which] = h_cnt[3];
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
+    dfree(c->cull_ctab_h[which]); dfree(c->cull_qrow_h[which]);
     c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_qrow[which] = d_qrow; c->cull_bytes[which] = cull_bytes;
+    c->cull_ctab_h[which] = d_ctab_h; c->cull_qrow_h[which] = d_qrow_h;
     c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, 1.0f / cell};
     c->table_bytes[which] = bytes + cull_bytes;
     c->have_map[which] = true;
@@ -600,8 +610,8 @@ int rover_set_curriculum_level(rover_ctx* c, int32_t level) {
 static int check_ready(rover_ctx* c);
 static int effective_variant(const rover_ctx* c);
 static int check_precision(rover_ctx* c) {
-    if (c->precision == 2 && effective_variant(c) != 2)
-        return fail(c, ROVER_E_STATE, "ray_precision 2 (as shipped, fp16 maths) needs ray-cast variant 2 (K <= 256 on both maps)");
+    if (c->precision == 2 && effective_variant(c) < 2)
+        return fail(c, ROVER_E_STATE, "ray_precision 2 (as shipped, fp16 maths) needs ray-cast variant 2 or 3 (K <= 256 on both maps)");
     return ROVER_OK;
 }
 
@@ -616,8 +626,14 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     CullArgs a{};
     a.rays = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
     a.n_terrain = (uint32_t)c->cfg.num_envs * (uint32_t)c->P;
-    a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1]; a.ctab0 = c->cull_ctab[0]; a.ctab1 = c->cull_ctab[1];
-    a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1]; a.qrow0 = c->cull_qrow[0]; a.qrow1 = c->cull_qrow[1];
+    const bool h = c->precision == 2;     // the as-shipped fp16 arithmetic: its own proof tables, the fp16 exact phase
+    a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1];
+    a.ctab0 = h ? c->cull_ctab_h[0] : c->cull_ctab[0]; a.ctab1 = h ? c->cull_ctab_h[1] : c->cull_ctab[1];
+    a.qrow0 = h ? c->cull_qrow_h[0] : c->cull_qrow[0]; a.qrow1 = h ? c->cull_qrow_h[1] : c->cull_qrow[1];
+    a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1];
+    a.half = h ? 1 : 0;
+    const CullProofH ph = cull_proof_h(c->cull_eta_h);
+    a.c_a_h = ph.c_a; a.tau2_h = ph.tau2;
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.out = c->d_dist_out;
@@ -913,10 +929,10 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
 int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
     if (!c || !out) return ROVER_E_INVALID;
     memset(out, 0, sizeof *out);
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < 2; ++w) {             // (of the proof tables the precision in force uses)
         out->triangles[w] = c->cull_tris[w];
-        out->always_candidate_triangles[w] = c->cull_always[w];
-        out->cells_without_cone[w] = c->cull_nocone[w];
+        out->always_candidate_triangles[w] = c->precision == 2 ? c->cull_always_h[w] : c->cull_always[w];
+        out->cells_without_cone[w] = c->precision == 2 ? c->cull_nocone_h[w] : c->cull_nocone[w];
     }
     out->queue_bytes = c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0;
     out->launches_per_step = c->d_cull_queue ? c->cull_launches : 0;

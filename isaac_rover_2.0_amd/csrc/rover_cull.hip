@@ -39,9 +39,60 @@
 
 namespace rover {
 
-#define CULL_TAU2   1.6e-5f          // (4e-3)^2: guard threshold on the unit normal, folded into r2 = TAU2 * |n_stored|^2
-#define CULL_TAU    4.0e-3
-#define CULL_PAD    0.101            // barycentric padding of the proof (the reference's is fp16(0.1) = 0.09998)
+// Constants of the rejection proof, per arithmetic of the exact phase (H = 0: f32, the header above; H = 1: the reference's
+// as-shipped fp16 arithmetic, derivation below).  Test (A): c_a |h|^2 - (h.d)^2 > r2 with r2 >= c_rho (rho + 1e-4)^2; test (B):
+// |n_dec . d| > tau |n_dec| (tau folded into the stored normal's length: r2 = tau^2 |n_stored|^2); a triangle with
+// |b x c| < sigma |b||c| (or |b||c| < min_bc) is stored as "always a candidate".
+template <int H> struct CullK;
+template <> struct CullK<0> {
+    static constexpr double pad = 0.101, c_rho = 1.19, tau = 4.0e-3, sigma = 0.05, min_bc = 0.0;
+    static constexpr float c_a = 0.995f, tau2 = 1.6e-5f;
+};
+// ---- as-shipped fp16 arithmetic (ray_casting.py:31-59 on Half tensors; u = 2^-11) ------------------------------------------
+// The exact phase then works on b = fl16(v1 - a), c = fl16(v0 - a), g' = fl16(s - a) (|g' - g| <= sqrt(3) u |g|: the ray as if
+// cast from s' = a + g', within 8.5e-4 |g| of s) and the fp16-normalised d (|d|^2 within 4e-3 of 1); the tables are built from
+// those b, c.  First-order error of a computed triple product, e.g. det = fl(fl(fl(N0 d0) + fl(N1 d1)) + fl(N2 d2)) with
+// N_i = fl(fl(b_j c_k) - fl(b_k c_j)):  u [ sum_i |d_i| (|b_j c_k| + |b_k c_j|)  (the two products of a cross component: the
+// permanent of the matrix (|b|, |c|, |d|), <= 1.155 |b||c||d|)  + sum_i |N_i d_i|  (the subtraction)  + sum_i |N_i d_i|  (the three
+// products with d)  + |N0 d0 + N1 d1| + |det|  (the two additions) ]  <= 5.155 u |b||c||d| = 2.53e-3 |b||c| with |d| <= 1.002; the same
+// for nn on (g', c) and mn on (b, g').  Products below 2^-14 round with an absolute error of 2^-25 instead: at most 12 of them,
+// which adds <= 5.4e-4 |b||c| to the bound below once |b||c| >= 1e-3.  So nn, mn, det are within e |g||c|, e |b||g|, e |b||c| of the
+// exact triple products nn*, mn*, det* of (b, c, g', d) with e = 3.07e-3; the tables use e = 3.6e-3.
+// The reference accepts iff fl16(nn/det) >= -fp16(0.1), fl16(mn/det) >= -fp16(0.1),
+// fl16(n + m) <= fp16(1.1) (all finite), which puts Q = (nn b + mn c) / det inside the triangle padded by 0.105 (0.1 (1 + u),
+// 1.1 (1 + u) + u (|n| + |m|) <= 1.1009), i.e. |a + Q - m| <= rho.  With the Cramer identity nn* b + mn* c = det* g' - kn* d:
+// det (a + Q - m) = det* (s' - m) - kn* d + Delta, |Delta| <= e |b||c| (2 |g| + rho), and perpendicular to d:
+// |det*| W' - |Delta| <= (|det*| + e |b||c|) rho, hence |det*| (W' - rho) <= 2 e |b||c| (|h| + 2 rho).
+// Test (A) with c_a = 0.958, c_rho = 1.41 gives W >= rho + 0.061 (|h| + 2 rho) (f32 rounding and |d|^2 != 1 included), i.e.
+// W' - rho >= eta (|h| + 2 rho), eta = 0.06, so |det*| <= 2 e / eta |b||c| = kappa |b||c|, kappa = 0.12.  |det*| = |N* . d| =
+// |N*| |d| |cos|, |N*| = sin(theta) |b||c| (theta: the angle of the triangle at a), so (B) has to establish |cos(N*, d)| > kappa /
+// (0.998 sin(theta)) — a threshold PER TRIANGLE: tau_t = 1.002 (kappa / (0.998 sin(theta)) + 1e-3) on the decoded normal (within
+// 1e-3 of N* / |N*|) and the fp16-normalised d.  A right-angled triangle gets 0.122, a 45 degree one 0.172; triangles below
+// sin(theta) = 0.34 (tau_t > 3 kappa), with |b||c| < 1e-3 or non-finite are stored as "always a candidate".  The record carries
+// F = (tau_t / kappa)^2 as a 12-bit code in the low mantissa bits of the centre's x and y (6 each; rho is computed from the
+// centre AS DECODED, so the bits cost no rigour): r2 (A) = kappa^2 |n_stored|^2 as before, r2 (B) = r2 (A) F.
+// The cone of a cell: with beta the ray's angle from the vertical and q_t = |N*_z| / |N*|, |cos(N*, d)| >= cos(acos q_t + beta),
+// so (B) holds for the whole cell iff beta <= gamma = min_t (acos(tau_t) - acos(q_t)); cells store gamma and rays beta as 16-bit
+// fractions of pi / 2 (the f32 proof's cone compares cosines instead: its tau is one constant).
+// The margins are an order of magnitude coarser than in f32 because every fp16 operation loses 2^-11; they cost candidates
+// (measured: DESIGN.md), never correctness.
+template <> struct CullK<1> {
+    static constexpr double pad = 0.105, sigma = 0.0, min_bc = 1.0e-3, e_fp16 = 3.6e-3;
+};
+// eta is the one free parameter of the fp16 proof (a larger eta loosens (A): more candidates by distance; it tightens nothing but
+// lowers kappa = 2 e / eta and with it (B)'s thresholds: fewer candidates by orientation, more cells with a cone).  Everything
+// else follows: alpha = eta + 1e-3, beta = 1 + 2 alpha, (beta rho + alpha |h|)^2 <= (beta^2 + 2 alpha beta) rho^2 +
+// (alpha^2 + alpha beta / 2) |h|^2, then the |d|^2 and f32-rounding allowances.
+CullProofH cull_proof_h(double eta) {
+    CullProofH k{};
+    const double e = CullK<1>::e_fp16, a = eta + 1.0e-3, b = 1.0 + 2.0 * a;
+    k.kappa = 2.0 * e / eta;
+    k.c_rho = (b * b + 2.0 * a * b) * 1.004 + 0.005;
+    k.c_a = (float)(0.996 * (1.0 - (a * a + 0.5 * a * b)) - 0.0005);
+    k.tau2 = (float)(k.kappa * k.kappa);
+    return k;
+}
+static_assert(0.999 * (CullK<0>::tau - 1.0e-3) * CullK<0>::sigma > 2.0 * 1.0e-6 / 0.02, "f32 cull proof: (B) must contradict (A)");
 #define CULL_RUNMAX 64               // sorted rays per wave (one result slot per lane)
 #define CULL_RING   4                // id rows (one bin each) in flight per wave: global -> LDS loads issued this many bins ahead
 
@@ -53,11 +104,11 @@ __device__ __forceinline__ f2 cvt2(uint32_t d) {
 }
 
 // r2 exactly as phase 1 derives it from the decoded normal (the table builder verifies its encoding with this)
-__device__ __forceinline__ float cull_r2(float nx, float ny, float nz) {
+__device__ __forceinline__ float cull_r2(float nx, float ny, float nz, float tau2) {
     float q = nx * nx;
     q = __builtin_fmaf(ny, ny, q);
     q = __builtin_fmaf(nz, nz, q);
-    return q * CULL_TAU2;
+    return q * tau2;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -113,8 +164,13 @@ __global__ void __launch_bounds__(256) rtab_build_kernel(const int32_t* __restri
     for (int q = 0; q < 10; ++q) rtab[10ull * t + q] = v[q];
 }
 
+template <int H>
 __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restrict__ rtab, uint32_t T, const uint32_t* __restrict__ order,
-                                                         uint4* __restrict__ ctab, float* __restrict__ nz_abs, uint32_t* __restrict__ counts) {
+                                                         uint4* __restrict__ ctab, float* __restrict__ nz_abs, uint32_t* __restrict__ counts,
+                                                         CullProofH ph /* fp16 proof only */) {
+    typedef CullK<H> KK;
+    const double k_tau = H ? ph.kappa : CullK<0>::tau, k_crho = H ? ph.c_rho : CullK<0>::c_rho;
+    const float k_tau2 = H ? ph.tau2 : CullK<0>::tau2;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const _Float16* src = reinterpret_cast<const _Float16*>(rtab) + 10ull * t;
@@ -126,17 +182,21 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
     float nzq = 2.0f;                                                // |N_z| / |N| of the exact normal; 2 = always a candidate (not part of a cell's cone)
     uint16_t zh = 0, nh[3] = {0x7c00u, 0x7c00u, 0x7c00u};            // infinite normal: r2 = +inf, neither test can hold = always a candidate
     if (valid) {
-        // a, b, c exactly as ray_casting.py:34-36 / set_pair compute them (f32), widened
+        // a, b, c exactly as ray_casting.py:34-36 / set_pair (f32) / set_pair_h (each difference rounded to fp16) compute them, widened
         const float af[3] = {v[6], v[7], v[8]};
-        const float bf[3] = {v[3] - v[6], v[4] - v[7], v[5] - v[8]};
-        const float cf[3] = {v[0] - v[6], v[1] - v[7], v[2] - v[8]};
+        float bf[3] = {v[3] - v[6], v[4] - v[7], v[5] - v[8]};
+        float cf[3] = {v[0] - v[6], v[1] - v[7], v[2] - v[8]};
+        if (H) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { bf[k] = (float)(_Float16)bf[k]; cf[k] = (float)(_Float16)cf[k]; }
+        }
         double Q[3][3];                                              // corners of the padded triangle
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double a = af[k], b = bf[k], c = cf[k];
-            Q[0][k] = a - CULL_PAD * b - CULL_PAD * c;
-            Q[1][k] = a + (1.0 + 2.0 * CULL_PAD) * b - CULL_PAD * c;
-            Q[2][k] = a - CULL_PAD * b + (1.0 + 2.0 * CULL_PAD) * c;
+            Q[0][k] = a - KK::pad * b - KK::pad * c;
+            Q[1][k] = a + (1.0 + 2.0 * KK::pad) * b - KK::pad * c;
+            Q[2][k] = a - KK::pad * b + (1.0 + 2.0 * KK::pad) * c;
         }
         auto d2 = [&](int x, int y) {
             double s = 0.0;
@@ -158,6 +218,27 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
 #pragma unroll
         for (int k = 0; k < 3; ++k) m[k] = w0 * Q[0][k] + w1 * Q[1][k] + w2 * Q[2][k];
         mk[0] = (float)m[0]; mk[1] = (float)m[1];
+        // (normal first: the fp16 proof's per-triangle threshold code goes into the centre's low mantissa bits, rho comes after)
+        const double N[3] = {(double)bf[1] * cf[2] - (double)bf[2] * cf[1], (double)bf[2] * cf[0] - (double)bf[0] * cf[2],
+                             (double)bf[0] * cf[1] - (double)bf[1] * cf[0]};
+        const double nN = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+        const double nb = sqrt((double)bf[0] * bf[0] + (double)bf[1] * bf[1] + (double)bf[2] * bf[2]);
+        const double nc = sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]);
+        bool ok = nN > 0.0 && nN >= KK::sigma * nb * nc && nb * nc >= KK::min_bc;      // slivers (fp16: tiny triangles too) stay candidates
+        double tau_true = k_tau;                                     // what |cos(N*, d)| has to exceed (true normal, unit d)
+        if (H && ok) {
+            const double sin_t = nN / (nb * nc);
+            tau_true = k_tau / (0.998 * sin_t);
+            const double tau_t = 1.002 * (tau_true + 1.0e-3);        // on the decoded normal and the fp16-normalised d
+            const double F = (tau_t / k_tau) * (tau_t / k_tau);
+            const double code = ceil((F - 1.0) * 512.0);
+            ok = code >= 0.0 && code <= 4095.0 && tau_t < 0.999;
+            if (ok) {
+                const uint32_t cc = (uint32_t)code;
+                mk[0] = __uint_as_float((__float_as_uint(mk[0]) & ~63u) | (cc & 63u));
+                mk[1] = __uint_as_float((__float_as_uint(mk[1]) & ~63u) | (cc >> 6));
+            }
+        }
         const _Float16 zq = (_Float16)(float)m[2];                   // |z| < 6e4 (the vertices are fp16 values)
         zh = __builtin_bit_cast(uint16_t, zq);
         mk[2] = (float)zq;
@@ -169,15 +250,9 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
             rho2 = s > rho2 ? s : rho2;
         }
         const double rho = sqrt(rho2) + 1.0e-4;
-        const double need = 1.19 * rho * rho;
-        const double N[3] = {(double)bf[1] * cf[2] - (double)bf[2] * cf[1], (double)bf[2] * cf[0] - (double)bf[0] * cf[2],
-                             (double)bf[0] * cf[1] - (double)bf[1] * cf[0]};
-        const double nN = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
-        const double nb = sqrt((double)bf[0] * bf[0] + (double)bf[1] * bf[1] + (double)bf[2] * bf[2]);
-        const double nc = sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]);
-        bool ok = nN > 0.0 && nN >= 0.05 * nb * nc;                  // slivers stay candidates
+        const double need = k_crho * rho * rho;
         if (ok) {
-            double scale = sqrt(need) * 1.002 / CULL_TAU / nN;       // |stored normal| = r / tau
+            double scale = sqrt(need) * 1.002 / k_tau / nN;          // |stored normal| = r / tau
             bool done = false;
             for (int it = 0; it < 8 && !done; ++it, scale *= 1.002) {
                 float dec[3];
@@ -190,15 +265,19 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
                     dec[k] = (float)hn;
                 }
                 if (!fin) break;
-                done = (double)cull_r2(dec[0], dec[1], dec[2]) >= need;
+                done = (double)cull_r2(dec[0], dec[1], dec[2], k_tau2) >= need;
             }
             ok = done;
         }
         if (!ok) nh[0] = nh[1] = nh[2] = 0x7c00u;
-        else nzq = (float)(fabs(N[2]) / nN * (1.0 - 1.0e-6));
+        else if (!H) nzq = (float)(fabs(N[2]) / nN * (1.0 - 1.0e-6));
+        else {      // gamma_t = acos(tau) - acos(q), as a fraction of pi / 2 (<= 0: the cell has no cone)
+            const double g = (acos(fmin(1.0, tau_true * (1.0 + 1.0e-3))) - acos(fmin(1.0, fabs(N[2]) / nN)) - 2.0e-4) / 1.5707963267948966;
+            nzq = g > 0.0 ? (float)(g * (1.0 - 1.0e-6)) : 0.0f;
+        }
     }
     nz_abs[t] = nzq;
-    if (nh[0] == 0x7c00u && order[t] != 0xffffffffu) atomicAdd(counts + 0, 1u);     // always a candidate (rover_get_cull_info); holes of the numbering aside
+    if (counts && nh[0] == 0x7c00u && order[t] != 0xffffffffu) atomicAdd(counts + 0, 1u);     // always a candidate (rover_get_cull_info); holes of the numbering aside
     ctab[t] = make_uint4(__float_as_uint(mk[0]), __float_as_uint(mk[1]), (uint32_t)zh | ((uint32_t)nh[0] << 16),
                          (uint32_t)nh[1] | ((uint32_t)nh[2] << 16));
 }
@@ -267,14 +346,14 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         uint32_t q16 = 0;
         if (q <= 1.0f && q > 0.0f) { q16 = (uint32_t)floorf(q * 65535.0f); q16 = q16 > 0xfffeu ? 0xfffeu : q16; }
         qrow[cell] = make_uint4(q16, 0u, 0u, 0u);
-        if (q16 == 0u) atomicAdd(counts + 1, 1u);                       // no normal cone: its rays run both tests on every pair
+        if (counts && q16 == 0u) atomicAdd(counts + 1, 1u);             // no normal cone: its rays run both tests on every pair
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // the kernels
 // ---------------------------------------------------------------------------------------------------
-struct CullRegs { f2 mx[2], my[2], mz[2], nx[2], ny[2], nz[2], r2[2]; };     // per lane: 4 triangles as 2 packed pairs
+struct CullRegs { f2 mx[2], my[2], mz[2], nx[2], ny[2], nz[2], r2[2], r2b[2]; };     // per lane: 4 triangles as 2 packed pairs (r2b: test (B)'s threshold where it is per triangle)
 
 // LDS traffic between the lanes of ONE wave: the hardware keeps a wave's LDS operations in order; this only stops the
 // compiler from moving them across
@@ -302,6 +381,7 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 // dead (61 VGPRs, still 8 waves per SIMD), so on every SIMD the scan phases of some waves fill the gaps of the exact
 // phases of others — as a second kernel (or on a second stream) the two phases only ran one after the other.
 // ---------------------------------------------------------------------------------------------------
+template <int H>
 __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
                                            const uint2* qw, uint32_t n, uint32_t gid /* per lane: ray id of run position `lane` */,
                                            uint32_t lane, uint32_t* bk) {
@@ -320,20 +400,40 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
         const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
         if (base + 64u < n) en_next = qw[min(base + 64u + lane, n - 1u)];
-        const float qnan = __builtin_nanf("");
-        f2 v[9];
+        float best;
+        if (H) {
+            // the reference's as-shipped fp16 arithmetic (cast_pairs_h: what raycast_binned_h_kernel runs on every triangle); the
+            // ray record holds fp16 values widened to f32 (prep_rays_kernel, precision 2), so the casts below are exact
+            h2 v[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
-            v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
+            for (int q = 0; q < 9; ++q) {
+                const half2v x0 = __builtin_bit_cast(half2v, r0.d[q >> 1]), x1 = __builtin_bit_cast(half2v, r1.d[q >> 1]);
+                v[q] = (q & 1) ? h2{x0.y, x1.y} : h2{x0.x, x1.x};
+            }
+            const _Float16 hnan = (_Float16)__builtin_nanf("");
+            v[6] = h2{id0 == CULL_NOID ? hnan : v[6].x, id1 == CULL_NOID ? hnan : v[6].y};
+            CellRegsH<1> t;
+            set_pair_h(t, 0, v);
+            const uint64_t none[1][2] = {{0, 0}};
+            const _Float16 hsx = (_Float16)ra.x, hsy = (_Float16)ra.y, hsz = (_Float16)ra.z;
+            const _Float16 hdx = (_Float16)rb.x, hdy = (_Float16)rb.y, hdz = (_Float16)rb.z;
+            best = cast_pairs_h<1>(t, h2{hsx, hsx}, h2{hsy, hsy}, h2{hsz, hsz}, h2{hdx, hdx}, h2{hdy, hdy}, h2{hdz, hdz}, none, 0u);
+        } else {
+            const float qnan = __builtin_nanf("");
+            f2 v[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const f2 x0 = cvt2(r0.d[q >> 1]), x1 = cvt2(r1.d[q >> 1]);
+                v[q] = (q & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
+            }
+            // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
+            v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
+            CellRegs<1> t;
+            set_pair(t, 0, v);
+            const uint64_t none[1][2] = {{0, 0}};
+            best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
+                                 f2{rb.z, rb.z}, none, 0u);
         }
-        // an empty slot next to a candidate: a NaN vertex a fails every test (as the NaN padding of the re-packed blocks does)
-        v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
-        CellRegs<1> t;
-        set_pair(t, 0, v);
-        const uint64_t none[1][2] = {{0, 0}};
-        const float best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y},
-                                         f2{rb.z, rb.z}, none, 0u);
         // the ray's running min lives in LDS as an ordered-u32 key: only lanes that HIT something take part (a ray meets 1-3 of
         // its ~16 candidates), so the atomic sees a handful of lanes — cheaper than a segmented wave min over all 64 first
         const uint32_t k = fkey(best);
@@ -384,9 +484,11 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
         const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
-        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h
 
+template <int H>
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
+    const float k_ca = H ? c_a_h : CullK<0>::c_a, k_tau2 = H ? tau2_h : CullK<0>::tau2;      // (f32 proof: compile-time constants)
     // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
     // exposed memory latency per run instead of one per bin); s_bk: the run's 64 running minima as ordered-u32 keys.
     __shared__ int4 s_ids[4][CULL_RING][64];
@@ -508,10 +610,14 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             f2 s = t.nx[p] * t.nx[p];
             s = fma2(t.ny[p], t.ny[p], s);
             s = fma2(t.nz[p], t.nz[p], s);
-            s = s * f2{CULL_TAU2, CULL_TAU2};                  // = cull_r2()
+            s = s * f2{k_tau2, k_tau2};                        // = cull_r2()
             // an empty slot is never a candidate: r2 = -inf (its centre / normal are triangle 0's, finite)
             const bool e0 = id[2 * p] >= 0, e1 = id[2 * p + 1] >= 0;
             t.r2[p] = f2{e0 ? s.x : -__builtin_inff(), e1 ? s.y : -__builtin_inff()};
+            if (H) {    // the fp16 proof: (B)'s threshold is per triangle, r2 F with F = 1 + code / 512 from the centre's low mantissa bits
+                const f2 code = f2{(float)((a.x & 63u) | ((a.y & 63u) << 6)), (float)((b.x & 63u) | ((b.y & 63u) << 6))};
+                t.r2b[p] = t.r2[p] * fma2(code, f2{1.0f / 512.0f, 1.0f / 512.0f}, f2{1.0f, 1.0f});
+            }
             qid[p][0] = (e0 ? (uint32_t)id[2 * p] : CULL_NOID) | (map << 31);
             qid[p][1] = e1 ? (uint32_t)id[2 * p + 1] : CULL_NOID;
         }
@@ -531,7 +637,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
                     const f2 hx = pk_rsub<0>(sxy, t.mx[p]), hy = pk_rsub<1>(sxy, t.my[p]), hz = pk_rsub<0>(szc, t.mz[p]);
                     const f2 hd = pk_fma_s<0>(hz, dzf, pk_fma_s<1>(hy, dxy, pk_mul_s<0>(hx, dxy)));
                     f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
-                    const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));             // (A): 0.995 |h|^2 - (h.d)^2 > r2
+                    const f2 A = fma2(hh, f2{k_ca, k_ca}, -(hd * hd));                   // (A): c_a |h|^2 - (h.d)^2 > r2
                     any[p] = ~(__builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y));
                 }
             } else {
@@ -540,12 +646,13 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
                     const f2 hx = pk_rsub<0>(sxy, t.mx[p]), hy = pk_rsub<1>(sxy, t.my[p]), hz = pk_rsub<0>(szc, t.mz[p]);
                     const f2 hd = pk_fma_s<0>(hz, dzf, pk_fma_s<1>(hy, dxy, pk_mul_s<0>(hx, dxy)));
                     f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
-                    const f2 A = fma2(hh, f2{0.995f, 0.995f}, -(hd * hd));             // (A): 0.995 |h|^2 - (h.d)^2 > r2
+                    const f2 A = fma2(hh, f2{k_ca, k_ca}, -(hd * hd));                   // (A): c_a |h|^2 - (h.d)^2 > r2
                     const f2 Dn = pk_fma_s<0>(t.nz[p], dzf, pk_fma_s<1>(t.ny[p], dxy, pk_mul_s<0>(t.nx[p], dxy)));
                     const f2 B = Dn * Dn;                                               // (B): (n.d)^2 > tau^2 |n|^2 = r2
                     // one ballot per compare (each stays a v_cmp writing an SGPR pair); NaN compares false = stays a candidate
-                    const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > t.r2[p].x);
-                    const uint64_t rej1 = __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y) & __builtin_amdgcn_ballot_w64(B.y > t.r2[p].y);
+                    const f2 rb2 = H ? t.r2b[p] : t.r2[p];
+                    const uint64_t rej0 = __builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(B.x > rb2.x);
+                    const uint64_t rej1 = __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y) & __builtin_amdgcn_ballot_w64(B.y > rb2.y);
                     any[p] = ~(rej0 & rej1);                                            // (all 64 lanes are active here)
                 }
             }
@@ -571,7 +678,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     // The wait also retires id-row loads of bins this segment did not reach (the ring restarts with the next segment).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
-    cull_exact(rays, rtab0, rtab1, qw, cused, gid, lane, bk);
+    cull_exact<H>(rays, rtab0, rtab1, qw, cused, gid, lane, bk);
     ctot += cused;
     }
     wave_lds_sync();
@@ -591,13 +698,17 @@ hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint
     return hipGetLastError();
 }
 
-// T: the caller's triangle count (ids in map_idx); T_int: slots of the internal numbering (order [T_int], newid [T])
+// T: the caller's triangle count (ids in map_idx); T_int: slots of the internal numbering (order [T_int], newid [T]).
+// ctab / qrow: the f32 proof's tables; ctab_h / qrow_h: the as-shipped fp16 arithmetic's (CullK<1>); idx4 and rtab serve both.
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
-                             int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow, float* nz_scratch,
-                             uint32_t* counts /* [2], zeroed: always-candidate triangles, cells without a cone */, hipStream_t s) {
+                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint4* qrow, uint4* qrow_h, float* nz_scratch,
+                             uint32_t* counts /* [4], zeroed: always-candidate triangles, cells without a cone; the same for fp16 */,
+                             CullProofH ph, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
-    hipLaunchKernelGGL(ctab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab, nz_scratch, counts);
+    hipLaunchKernelGGL(ctab_build_kernel<1>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab_h, nz_scratch, counts + 2, ph);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, idx4, qrow_h, counts + 2);
+    hipLaunchKernelGGL(ctab_build_kernel<0>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab, nz_scratch, counts, ph);
     hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, idx4, qrow, counts);
     return hipGetLastError();
 }
@@ -645,10 +756,11 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     // of the slot list, one launch each on the same stream, re-using the regions
     for (uint32_t j0 = 0; j0 < slots; j0 += per) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
-        hipLaunchKernelGGL(cull_scan_kernel, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
+        auto kern = a.half ? cull_scan_kernel<1> : cull_scan_kernel<0>;
+        hipLaunchKernelGGL(kern, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
-                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0);
+                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h);
     }
     return hipGetLastError();
 }

@@ -52,6 +52,10 @@ struct PrepArgs {
     int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
 };
 
+// constants of the culled ray cast's rejection proof for the as-shipped fp16 arithmetic, derived from its one free parameter eta
+struct CullProofH { double kappa, c_rho; float c_a, tau2; };
+CullProofH cull_proof_h(double eta);
+
 // raycast_culled_kernel (rover_cull.hip)
 struct CullArgs {
     const RayRec* rays;
@@ -66,6 +70,8 @@ struct CullArgs {
     float* out;                  // [E*R8] distances
     uint2* queue;                // candidate queue: one region of CULL_QCAP 8-byte entries per wave of a launch
     uint64_t queue_entries;      // its size: a step whose regions would not fit is cast in several launches
+    int half;                    // the exact phase runs the reference's as-shipped fp16 arithmetic (ctab / qrow are then that proof's tables)
+    float c_a_h, tau2_h;         // test constants of that proof (CullProofH)
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
@@ -182,7 +188,8 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
 hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint32_t T, uint32_t V, float2* out, hipStream_t s);
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
-                             int32_t* idx4, uint4* ctab, uint16_t* rtab, uint4* qrow, float* nz_scratch, uint32_t* counts, hipStream_t s);
+                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint4* qrow, uint4* qrow_h, float* nz_scratch,
+                             uint32_t* counts, CullProofH ph, hipStream_t s);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);

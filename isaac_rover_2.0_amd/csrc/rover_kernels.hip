@@ -277,10 +277,19 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         } else {
             neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
         }
-        {   // the ray's normal-cone bound for the culled ray cast (rover_cull.hip): a cell whose triangles all have
-            // |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole; 16-bit fraction rounded up, 0xffff = none
-            const float qm = 3.5e-3f * fabsf(rec.dz) + sqrtf(rec.dx * rec.dx + rec.dy * rec.dy) + 2.0e-5f;
-            const uint32_t qq = (qm < 0.9999f) ? (uint32_t)ceilf(qm * 65535.0f) : 0xffffu;      // NaN -> 0xffff
+        {   // the ray's normal-cone bound for the culled ray cast (rover_cull.hip), a 16-bit fraction rounded up, 0xffff = none.
+            // f32 proof: a cell whose triangles all have |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole.
+            // As-shipped fp16 arithmetic: (B)'s threshold is per triangle, the cell stores the largest angle from the vertical a ray
+            // may have (as a fraction of pi / 2) and the ray its angle beta (d is normalised in fp16 there: re-normalised here).
+            uint32_t qq = 0xffffu;
+            if (a.precision == 2) {
+                const float inv = 1.0f / sqrtf(rec.dx * rec.dx + rec.dy * rec.dy + rec.dz * rec.dz);
+                const float beta = acosf(fminf(1.0f, fabsf(rec.dz) * inv)) * 0.63661977f + 4.0e-5f;      // / (pi / 2), rounded up
+                if (beta < 0.9999f) qq = (uint32_t)ceilf(beta * 65535.0f);                                // NaN -> 0xffff
+            } else {
+                const float qm = 3.5e-3f * fabsf(rec.dz) + sqrtf(rec.dx * rec.dx + rec.dy * rec.dy) + 2.0e-5f;
+                if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                    // NaN -> 0xffff
+            }
             rec.flags |= qq << 16;
         }
         uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->inv_cell, a.cell_rcp, m->X);
@@ -1374,58 +1383,8 @@ __global__ void __launch_bounds__(256) knn_select_kernel(const float* __restrict
 // taken in f32 (IEEE, shared reciprocal) and rounded to fp16, which equals the fp16 quotient (24 >= 2*11 + 2 bits).
 // Bit-identical to the oracle's fp16 mode, which the as-shipped golden fixture pins bit for bit.
 // ---------------------------------------------------------------------------------------------------
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-struct CellRegsH {
-    h2 ax[2], ay[2], az[2], bx[2], by[2], bz[2], cx[2], cy[2], cz[2], nx[2], ny[2], nz[2];
-    __device__ __forceinline__ void poison() {
-        const _Float16 qnan = (_Float16)__builtin_nanf("");
-        const _Float16 zero = (_Float16)0.0f;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            ax[p] = ay[p] = az[p] = h2{qnan, qnan};
-            bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = h2{zero, zero};
-        }
-    }
-};
-
-__device__ __forceinline__ f2 h2_to_f2(h2 v) { return f2{(float)v.x, (float)v.y}; }
-
-// Early out as in cast_pairs, on the fp16 numerators the reference's own arithmetic produces: A = nn det, B = mn det and
-// D = det^2 are EXACT in f32 (11-bit x 11-bit significands), so A < -0.15 D - tiny proves nn/det < -0.1499, whose fp16
-// rounding is < fp16(-0.1); A + B > 1.15 D + tiny proves x + y > 1.1499 for the exact quotients x, y, and then either
-// fp16(fp16(x) + fp16(y)) > fp16(1.1) (|x|, |y| <= 32: the roundings move the sum by < 0.032) or one quotient is < -1.
-// Infinities / NaN from fp16 overflow never pass the test (and the reference rejects them too).
-__device__ __forceinline__ float cast_pairs_h(const CellRegsH& t, h2 sx, h2 sy, h2 sz, h2 dx, h2 dy, h2 dz,
-                                              const uint64_t (&vmask)[2][2], uint32_t pre_bits) {
-    float best = RAY_MISS;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        h2 gx = sx - t.ax[p], gy = sy - t.ay[p], gz = sz - t.az[p];
-        h2 det = t.nx[p] * dx + t.ny[p] * dy + t.nz[p] * dz;
-        h2 gcx = gy * t.cz[p] - gz * t.cy[p], gcy = gz * t.cx[p] - gx * t.cz[p], gcz = gx * t.cy[p] - gy * t.cx[p];
-        h2 nn = gcx * dx + gcy * dy + gcz * dz;
-        h2 bgx = t.by[p] * gz - t.bz[p] * gy, bgy = t.bz[p] * gx - t.bx[p] * gz, bgz = t.bx[p] * gy - t.by[p] * gx;
-        h2 mn = bgx * dx + bgy * dy + bgz * dz;
-        const f2 detf = h2_to_f2(det), nnf = h2_to_f2(nn), mnf = h2_to_f2(mn);
-        if (pre_bits & (1u << p)) {
-            const f2 D = detf * detf, A = nnf * detf, B = mnf * detf, S = A + B;
-            const f2 lo = fma2(f2{-0.15f, -0.15f}, D, f2{-1e-30f, -1e-30f});
-            const f2 hi = fma2(f2{1.15f, 1.15f}, D, f2{1e-30f, 1e-30f});
-            const uint64_t r0 = __builtin_amdgcn_ballot_w64(__builtin_fminf(A.x, B.x) < lo.x) | __builtin_amdgcn_ballot_w64(S.x > hi.x);
-            const uint64_t r1 = __builtin_amdgcn_ballot_w64(__builtin_fminf(A.y, B.y) < lo.y) | __builtin_amdgcn_ballot_w64(S.y > hi.y);
-            if (((~r0 & vmask[p][0]) | (~r1 & vmask[p][1])) == 0) continue;
-        }
-        h2 kn = t.nx[p] * gx + t.ny[p] * gy + t.nz[p] * gz;
-        Quot3 q = div3_ieee(detf, nnf, mnf, h2_to_f2(kn));
-        h2 n = h2{(_Float16)q.n.x, (_Float16)q.n.y}, m = h2{(_Float16)q.m.x, (_Float16)q.m.y}, k = h2{(_Float16)q.k.x, (_Float16)q.k.y};
-        h2 nm = n + m;                                                            // fp16 sum, then compared (ray_casting.py:59)
-        float r0 = accept1((float)n.x, (float)m.x, (float)k.x, detf.x, (float)nm.x);
-        float r1 = accept1((float)n.y, (float)m.y, (float)k.y, detf.y, (float)nm.y);
-        best = __builtin_fminf(best, __builtin_fminf(r0, r1));
-    }
-    return best;
-}
+// (the fp16 (ray, triangle) arithmetic — CellRegsH, set_pair_h, cast_pairs_h — lives in rover_raymath.h: one definition for this
+// kernel and the culled ray cast's exact phase)
 
 __global__ void __launch_bounds__(256) raycast_binned_h_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted,
                                                                uint32_t n_sorted, const _Float16* __restrict__ tab0,
@@ -1440,7 +1399,7 @@ __global__ void __launch_bounds__(256) raycast_binned_h_kernel(const RayRec* __r
     if (i >= n_sorted) return;
     const uint32_t i_end = min(i + run, n_sorted);
     uint32_t cur_cell = 0xffffffffu, cur_map = 0xffffffffu;
-    CellRegsH t;
+    CellRegsH<2> t;
     t.poison();
     uint64_t vmask[2][2] = {{0, 0}, {0, 0}};
     for (; i < i_end; ++i) {
@@ -1461,12 +1420,10 @@ __global__ void __launch_bounds__(256) raycast_binned_h_kernel(const RayRec* __r
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int t0 = 2 * p, t1 = 2 * p + 1;
-                    t.ax[p] = h2{v[6][t0], v[6][t1]}; t.ay[p] = h2{v[7][t0], v[7][t1]}; t.az[p] = h2{v[8][t0], v[8][t1]};
-                    t.bx[p] = h2{v[3][t0], v[3][t1]} - t.ax[p]; t.by[p] = h2{v[4][t0], v[4][t1]} - t.ay[p]; t.bz[p] = h2{v[5][t0], v[5][t1]} - t.az[p];
-                    t.cx[p] = h2{v[0][t0], v[0][t1]} - t.ax[p]; t.cy[p] = h2{v[1][t0], v[1][t1]} - t.ay[p]; t.cz[p] = h2{v[2][t0], v[2][t1]} - t.az[p];
-                    t.nx[p] = t.by[p] * t.cz[p] - t.bz[p] * t.cy[p];
-                    t.ny[p] = t.bz[p] * t.cx[p] - t.bx[p] * t.cz[p];
-                    t.nz[p] = t.bx[p] * t.cy[p] - t.by[p] * t.cx[p];
+                    h2 vv[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) vv[q] = h2{v[q][t0], v[q][t1]};
+                    set_pair_h(t, p, vv);
                 }
             }
 #pragma unroll
@@ -1478,7 +1435,7 @@ __global__ void __launch_bounds__(256) raycast_binned_h_kernel(const RayRec* __r
         // the record holds fp16 values widened to f32 (prep_rays_kernel, precision 2): the casts are exact
         const _Float16 hsx = (_Float16)ra.x, hsy = (_Float16)ra.y, hsz = (_Float16)ra.z;
         const _Float16 hdx = (_Float16)rb.x, hdy = (_Float16)rb.y, hdz = (_Float16)rb.z;
-        float best = cast_pairs_h(t, h2{hsx, hsx}, h2{hsy, hsy}, h2{hsz, hsz}, h2{hdx, hdx}, h2{hdy, hdy}, h2{hdz, hdz}, vmask,
+        float best = cast_pairs_h<2>(t, h2{hsx, hsx}, h2{hsy, hsy}, h2{hsz, hsz}, h2{hdx, hdx}, h2{hdy, hdy}, h2{hdz, hdz}, vmask,
                                   map ? pre_rocks : pre_terrain);
         best = wave_min_to_lane63(best);
         if (lane == 63u) out[gid] = best;

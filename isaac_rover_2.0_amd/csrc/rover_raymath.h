@@ -142,4 +142,76 @@ __device__ __forceinline__ float cast_pairs(const CellRegs<NP>& t, f2 sx, f2 sy,
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same arithmetic as ATen evaluates it on float16 tensors (the reference AS SHIPPED, Camera.dtype = float16): every
+// elementwise op of ray_casting.py:31-59 rounds its result to fp16 (packed fp16 instructions, no contraction); the three
+// quotients are taken in f32 (IEEE, shared reciprocal) and rounded to fp16, which equals the fp16 quotient (24 >= 2 * 11 + 2 bits).
+// Bit-identical to the oracle's fp16 mode, which the as-shipped golden fixtures pin bit for bit.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+template <int NP>
+struct CellRegsH {
+    h2 ax[NP], ay[NP], az[NP], bx[NP], by[NP], bz[NP], cx[NP], cy[NP], cz[NP], nx[NP], ny[NP], nz[NP];
+    __device__ __forceinline__ void poison() {
+        const _Float16 qnan = (_Float16)__builtin_nanf("");
+        const _Float16 zero = (_Float16)0.0f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            ax[p] = ay[p] = az[p] = h2{qnan, qnan};
+            bx[p] = by[p] = bz[p] = cx[p] = cy[p] = cz[p] = nx[p] = ny[p] = nz[p] = h2{zero, zero};
+        }
+    }
+};
+
+__device__ __forceinline__ f2 h2_to_f2(h2 v) { return f2{(float)v.x, (float)v.y}; }
+
+// one packed pair from its nine fp16 vertex components: a = v2, b = v1 - a, c = v0 - a, n = b x c, each op rounded to fp16
+template <int NP>
+__device__ __forceinline__ void set_pair_h(CellRegsH<NP>& t, int p, const h2 (&v)[9]) {
+    t.ax[p] = v[6]; t.ay[p] = v[7]; t.az[p] = v[8];
+    t.bx[p] = v[3] - t.ax[p]; t.by[p] = v[4] - t.ay[p]; t.bz[p] = v[5] - t.az[p];
+    t.cx[p] = v[0] - t.ax[p]; t.cy[p] = v[1] - t.ay[p]; t.cz[p] = v[2] - t.az[p];
+    t.nx[p] = t.by[p] * t.cz[p] - t.bz[p] * t.cy[p];
+    t.ny[p] = t.bz[p] * t.cx[p] - t.bx[p] * t.cz[p];
+    t.nz[p] = t.bx[p] * t.cy[p] - t.by[p] * t.cx[p];
+}
+
+// Early out as in cast_pairs, on the fp16 numerators the reference's own arithmetic produces: A = nn det, B = mn det and
+// D = det^2 are EXACT in f32 (11-bit x 11-bit significands), so A < -0.15 D - tiny proves nn/det < -0.1499, whose fp16
+// rounding is < fp16(-0.1); A + B > 1.15 D + tiny proves x + y > 1.1499 for the exact quotients x, y, and then either
+// fp16(fp16(x) + fp16(y)) > fp16(1.1) (|x|, |y| <= 32: the roundings move the sum by < 0.032) or one quotient is < -1.
+// Infinities / NaN from fp16 overflow never pass the test (and the reference rejects them too).
+template <int NP>
+__device__ __forceinline__ float cast_pairs_h(const CellRegsH<NP>& t, h2 sx, h2 sy, h2 sz, h2 dx, h2 dy, h2 dz,
+                                              const uint64_t (&vmask)[NP][2], uint32_t pre_bits) {
+    float best = RAY_MISS;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        h2 gx = sx - t.ax[p], gy = sy - t.ay[p], gz = sz - t.az[p];
+        h2 det = t.nx[p] * dx + t.ny[p] * dy + t.nz[p] * dz;
+        h2 gcx = gy * t.cz[p] - gz * t.cy[p], gcy = gz * t.cx[p] - gx * t.cz[p], gcz = gx * t.cy[p] - gy * t.cx[p];
+        h2 nn = gcx * dx + gcy * dy + gcz * dz;
+        h2 bgx = t.by[p] * gz - t.bz[p] * gy, bgy = t.bz[p] * gx - t.bx[p] * gz, bgz = t.bx[p] * gy - t.by[p] * gx;
+        h2 mn = bgx * dx + bgy * dy + bgz * dz;
+        const f2 detf = h2_to_f2(det), nnf = h2_to_f2(nn), mnf = h2_to_f2(mn);
+        if (pre_bits & (1u << p)) {
+            const f2 D = detf * detf, A = nnf * detf, B = mnf * detf, S = A + B;
+            const f2 lo = fma2(f2{-0.15f, -0.15f}, D, f2{-1e-30f, -1e-30f});
+            const f2 hi = fma2(f2{1.15f, 1.15f}, D, f2{1e-30f, 1e-30f});
+            const uint64_t r0 = __builtin_amdgcn_ballot_w64(__builtin_fminf(A.x, B.x) < lo.x) | __builtin_amdgcn_ballot_w64(S.x > hi.x);
+            const uint64_t r1 = __builtin_amdgcn_ballot_w64(__builtin_fminf(A.y, B.y) < lo.y) | __builtin_amdgcn_ballot_w64(S.y > hi.y);
+            if (((~r0 & vmask[p][0]) | (~r1 & vmask[p][1])) == 0) continue;
+        }
+        h2 kn = t.nx[p] * gx + t.ny[p] * gy + t.nz[p] * gz;
+        Quot3 q = div3_ieee(detf, nnf, mnf, h2_to_f2(kn));
+        h2 n = h2{(_Float16)q.n.x, (_Float16)q.n.y}, m = h2{(_Float16)q.m.x, (_Float16)q.m.y}, k = h2{(_Float16)q.k.x, (_Float16)q.k.y};
+        h2 nm = n + m;                                                            // fp16 sum, then compared (ray_casting.py:59)
+        float r0 = accept1((float)n.x, (float)m.x, (float)k.x, detf.x, (float)nm.x);
+        float r1 = accept1((float)n.y, (float)m.y, (float)k.y, detf.y, (float)nm.y);
+        best = __builtin_fminf(best, __builtin_fminf(r0, r1));
+    }
+    return best;
+}
+
 }  // namespace rover

@@ -36,8 +36,8 @@ def test_exact_ties_follow_the_reference(name, precision, variant):
     """The lattice fixture (exact threshold / det-guard / degenerate-triangle hits, see tests/test_oracle_golden.py):
     on its rounding-free envs the HIP ray casts equal the reference bit for bit, in both kernels."""
     from hip_helpers import hip_step, make_engine
-    if precision == "fp16_as_shipped" and variant != 2:
-        pytest.skip("the as-shipped fp16 maths exist in the binned kernel only")
+    if precision == "fp16_as_shipped" and variant == 1:
+        pytest.skip("the env-order kernel has no as-shipped fp16 arithmetic")
     fx = load_golden(name)
     scene = scene_for(fx)
     st = states_of(fx)
@@ -136,19 +136,22 @@ def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
     eng.close()
 
 
+@pytest.mark.parametrize("variant", [3, 2])
 @pytest.mark.parametrize("name", STEP_FIXTURES_AS_SHIPPED)
-def test_as_shipped_fp16_mode_is_bit_identical_to_the_reference(name):
+def test_as_shipped_fp16_mode_is_bit_identical_to_the_reference(name, variant):
     """ray_precision 2: the reference AS SHIPPED (Camera.dtype = float16).  Ray distances, wheel / body distances, the
     collision mask, done flags and the heightmap part of obs are bit-identical to the golden vectors captured from the
-    unmodified reference (9 / 37 / 120 / native 1634 rays); reward differs by sin/cos/atan2 ulps only."""
+    unmodified reference (9 / 37 / 120 / native 1634 rays, K = 200, the irregular mesh); reward differs by sin/cos/atan2 ulps
+    only.  Variant 3: the culled ray cast with the fp16 proof tables and the fp16 exact phase; variant 2: every triangle."""
     from hip_helpers import hip_step, make_engine
     from oracle import oracle as orc
     fx16 = load_golden(name)
     scene = scene_for(fx16)
     st = states_of(fx16)
     distn = (fx16["distribution"], fx16["sparse_idx"], fx16["dense_idx"])
-    eng = make_engine(scene, distn, st["pos"].shape[0])
+    eng = make_engine(scene, distn, st["pos"].shape[0], variant=variant)
     eng.set_option("ray_precision", 2)
+    assert eng.info().raycast_variant == variant
     got = hip_step(eng, st)
     for k in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf", "progress_buf", "extras_collision_penalty"):
         np.testing.assert_array_equal(got[k], fx16["out_" + k], err_msg=k)
@@ -163,7 +166,7 @@ def test_as_shipped_fp16_mode_is_bit_identical_to_the_reference(name):
     st2 = synth.make_states(2048, 12.8, seed=77)
     t, r = _oracle_maps(scene)
     want = orc.step(t, r, st2, *distn, precision="fp16_as_shipped")
-    eng2 = make_engine(scene, distn, 2048)
+    eng2 = make_engine(scene, distn, 2048, variant=variant)
     eng2.set_option("ray_precision", 2)
     got2 = hip_step(eng2, st2)
     for k in ("ray_dist", "wheel_dist", "body_dist"):
@@ -262,19 +265,23 @@ def test_culled_raycast_changes_no_bit(k, cells):
     st["pos"][2900:2950] *= 1.0e4                                                 # far outside the map
     st["pos"][2950:2960] = float("nan")
     st["pos"][2960:2970, 2] += 500.0                                              # high above the terrain
-    eng = make_engine(scene, distn, n, variant=2)
-    eng.set_option("raycast_early_out", 0)
-    ref = hip_step(eng, st)
-    eng.close()
-    for run in (0, 7, 64):                           # auto / odd / longest runs of sorted rays per wave
-        eng = make_engine(scene, distn, n, variant=3, run=run or None)
-        got = hip_step(eng, st)
-        got2 = hip_step(eng, st)                     # and again on the same engine (queue regions are reused)
+    for precision in (0, 2):                         # f32 arithmetic / the reference's as-shipped fp16 arithmetic
+        eng = make_engine(scene, distn, n, variant=2)
+        eng.set_option("ray_precision", precision)
+        eng.set_option("raycast_early_out", 0)
+        ref = hip_step(eng, st)
         eng.close()
-        for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run}")
-            np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} run={run} (second step)")
-    assert (ref["ray_dist"] < 11.0).mean() > 0.3
+        for run in (0, 7, 64):                       # auto / odd / longest runs of sorted rays per wave
+            eng = make_engine(scene, distn, n, variant=3, run=run or None)
+            eng.set_option("ray_precision", precision)
+            assert eng.info().raycast_variant == 3
+            got = hip_step(eng, st)
+            got2 = hip_step(eng, st)                 # and again on the same engine (queue regions are reused)
+            eng.close()
+            for key in ref:
+                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run} precision={precision}")
+                np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} run={run} precision={precision} (second step)")
+        assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
 @pytest.mark.parametrize("name,precision", [("step_irregular_p37_fp32", 0), ("step_irregular_native_fp32", 0),
@@ -305,7 +312,7 @@ def test_irregular_mesh_and_k200_all_variants(name, precision):
             ci = eng.cull_info()
             assert ci["rays"] == st["pos"].shape[0] * (distn[0].shape[0] + 26)
             if "irregular" in name:                   # the paths a regular grid mesh never takes are taken here
-                assert ci["always_candidate_triangles"][0] > 0 and ci["cells_without_cone"][0] > 0
+                assert ci["always_candidate_triangles"][0] > 0 and (ci["cells_without_cone"][0] > 0 or precision == 2)
                 assert ci["rays_both_tests"] > 0 and ci["candidate_pairs"] > 0
         eng.close()
     assert 2 in outs and (3 in outs or precision == 2)
@@ -346,32 +353,37 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
     st["pos"][2900:2950] *= 1.0e4
     st["pos"][2950:2960] = float("nan")
     st["pos"][2960:2970, 2] += 500.0
-    eng = make_engine(scene, distn, n, variant=2)
-    eng.set_option("raycast_early_out", 0)
-    ref = hip_step(eng, st)
-    eng.close()
-    eng = make_engine(scene, distn, n, variant=1)
-    ref1 = hip_step(eng, st)
-    eng.close()
-    for key in ref:
-        np.testing.assert_array_equal(ref1[key], ref[key], err_msg=f"{key} variant 1 vs 2")
-    most = 0
-    for run, queue_mb in ((0, None), (7, None), (64, None), (64, 1)):
-        eng = make_engine(scene, distn, n, variant=3, run=run or None)
-        if queue_mb:                                  # a 1 MB queue budget: the step's ray cast is cut into slices that re-use the regions
-            eng.set_option("cull_queue_mb", queue_mb)
-        got = hip_step(eng, st)
-        ci = eng.cull_info()
+    for precision in (0, 2):                          # f32 arithmetic / the reference's as-shipped fp16 arithmetic
+        eng = make_engine(scene, distn, n, variant=2)
+        eng.set_option("ray_precision", precision)
+        eng.set_option("raycast_early_out", 0)
+        ref = hip_step(eng, st)
         eng.close()
-        for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run} queue_mb={queue_mb}")
-        assert ci["always_candidate_triangles"][0] > 0 and ci["rays_both_tests"] > 0
-        assert ci["launches_per_step"] == (1 if not queue_mb else ci["launches_per_step"]) and (not queue_mb or ci["launches_per_step"] > 4)
-        assert ci["queue_bytes"] <= (queue_mb or 1024) << 20
-        most = max(most, ci["max_pairs_per_run"])
-    # runs that found more candidates than a queue region holds (1 024 entries) were cast in several segments
-    assert most > 1024, most
-    assert (ref["ray_dist"] < 11.0).mean() > 0.3
+        if precision == 0:
+            eng = make_engine(scene, distn, n, variant=1)
+            ref1 = hip_step(eng, st)
+            eng.close()
+            for key in ref:
+                np.testing.assert_array_equal(ref1[key], ref[key], err_msg=f"{key} variant 1 vs 2")
+        most = 0
+        for run, queue_mb in ((0, None), (7, None), (64, None), (64, 1)):
+            eng = make_engine(scene, distn, n, variant=3, run=run or None)
+            eng.set_option("ray_precision", precision)
+            if queue_mb:                              # a 1 MB queue budget: the step's ray cast is cut into slices that re-use the regions
+                eng.set_option("cull_queue_mb", queue_mb)
+            assert eng.info().raycast_variant == 3
+            got = hip_step(eng, st)
+            ci = eng.cull_info()
+            eng.close()
+            for key in ref:
+                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} run={run} queue_mb={queue_mb} precision={precision}")
+            assert ci["always_candidate_triangles"][0] > 0 and ci["rays_both_tests"] > 0
+            assert ci["launches_per_step"] == (1 if not queue_mb else ci["launches_per_step"]) and (not queue_mb or ci["launches_per_step"] > 4)
+            assert ci["queue_bytes"] <= (queue_mb or 1024) << 20
+            most = max(most, ci["max_pairs_per_run"])
+        # runs that found more candidates than a queue region holds (1 024 entries) were cast in several segments
+        assert most > 1024, most
+        assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
 def test_auto_variant_and_run_selection():
@@ -388,7 +400,7 @@ def test_auto_variant_and_run_selection():
     big = make_engine(scene, distn, 4096, variant=None)
     assert big.info().raycast_variant == 3
     big.set_option("ray_precision", 2)
-    assert big.info().raycast_variant == 2
+    assert big.info().raycast_variant == 3            # the culled kernel runs the as-shipped arithmetic too (its own proof tables)
     big.set_option("ray_precision", 0)
     st = synth.make_states(4096, 6.4, seed=3)
     a = hip_step(big, st)                                   # auto run length

@@ -58,7 +58,7 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
     P = distn[0].shape[0]
     engs = {}
     for name, (variant, early, prec) in {"culled": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
-                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2)}.items():
+                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2)}.items():
         e = _lib.Engine(E, device=0)
         e.set_scene(scene, distn)
         e.set_option("raycast_variant", variant); e.set_option("raycast_early_out", early); e.set_option("ray_precision", prec)
@@ -79,7 +79,7 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
             st["pos"][:, 0] = torch.from_numpy(x).float(); st["pos"][:, 1] = torch.from_numpy(y).float()
             st["pos"][:, 2] = torch.from_numpy(zf(x, y)).float() + 0.3
         outs = run_engines(engs, st, P)
-        compare(outs, (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly")),
+        compare(outs, (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"), ("h_culled", "h_noearly")),
                 f"irregular seed={seed} K={k} round={r}")
         ci = engs["culled"].cull_info()
         irr_total += E * (P + 26)
@@ -90,14 +90,14 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
     for e in engs.values():
         e.close()
 if irr_rounds > 0:
-    print(f"irregular soak ok: {irr_total / 1e6:.1f} M rays x 5 comparisons on irregular meshes, all bit-identical", flush=True)
+    print(f"irregular soak ok: {irr_total / 1e6:.1f} M rays x 6 comparisons on irregular meshes, all bit-identical", flush=True)
 
 for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"), (16, 128, "9")):
     scene = synth.make_scene(n_cells=cells, k=k, n_stones=max(8, cells * cells // 400), device="cuda")
     distn = synth.ray_distribution(dist_name)
     engs = {}
     for name, (variant, early, prec) in {"culled": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
-                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2)}.items():
+                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2)}.items():
         e = _lib.Engine(E, device=0)
         e.set_scene(scene, distn)
         e.set_option("raycast_variant", variant); e.set_option("raycast_early_out", early); e.set_option("ray_precision", prec)
@@ -122,7 +122,8 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
             e.step(sin, e.make_out(obs, **bufs), increment_progress=False)
             torch.cuda.synchronize()
             outs[name] = (bufs["ray_dist"], bufs["wheel_dist"], bufs["body_dist"], bufs["rock_collision"], bufs["reset"])
-        for a, b in (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly")):
+        for a, b in (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"),
+                     ("h_culled", "h_noearly")):
             for x, y, what in zip(outs[a], outs[b], ("ray", "wheel", "body", "coll", "reset")):
                 same = torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all())
                 if not same:
@@ -133,4 +134,4 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
         print(f"K={k} round {r}: ok, terrain hit rate {hit:.3f}", flush=True)
     for e in engs.values():
         e.close()
-print(f"soak ok: {total / 1e6:.1f} M rays x 5 comparisons, all bit-identical")
+print(f"soak ok: {total / 1e6:.1f} M rays x 6 comparisons, all bit-identical")
