@@ -253,16 +253,17 @@ ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers
  *        (needs K <= 256 on both maps); 3 = culled: the sorted rays of 2, but a conservative bounding-sphere + normal test
- *        (12 B per triangle, built at rover_set_knn_map) first proves for most (ray, triangle) pairs that ray_casting.py:59
- *        rejects them, and only the remaining candidates get the exact arithmetic (csrc/rover_cull.hip; f32 arithmetic only).
- *        All give bit-identical results; auto picks 3 (2 when ray_precision = 2) when a step casts more than 131 072 rays
- *        (below that the binning passes cost more than they save: 1).
+ *        (16 B per triangle, built at rover_set_knn_map) first proves for most (ray, triangle) pairs that ray_casting.py:59
+ *        rejects them, and only the remaining candidates get the exact arithmetic (csrc/rover_cull.hip) — in f32 or, with
+ *        ray_precision = 2, in the reference's as-shipped fp16 arithmetic (its own, wider proof margins).
+ *        All give bit-identical results; auto picks 3 when a step casts more than 131 072 rays (below that the binning passes
+ *        cost more than they save: 1, or 2 with ray_precision = 2).
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
  *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
  *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.
  *        2 = AS SHIPPED: (1) plus every operation of ray_casting.py:31-59 rounded to fp16 the way ATen's Half kernels do,
  *        and fp16 collision thresholds (rover.py:667-668).  Bit-identical to the as-shipped reference on ray origins,
- *        distances, collision mask and done flags (runs ray-cast variant 2).
+ *        distances, collision mask and done flags (ray-cast variants 2 and 3).
  * name = "bin_low_bits": width of the low digit of the ray bucket sort, 8..12 (default 10).
  * name = "raycast_early_out": 1 (default) = the binned kernel drops a whole packed pair of triangles per lane (the far half
  *        of a cell's K-nearest list; on the rocks map also the near half) when a conservative test on the numerators shows that
