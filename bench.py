@@ -45,8 +45,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
-CLOCK_GHZ = 2.4              # max shader clock
-VALU_CYCLES_PER_INST = 4     # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.01 quad-cycles (profiles/README.md)
+CLOCK_GHZ = 2.4              # max shader clock (rocm-smi shows 2.38 GHz while the step loop runs, tools/clock_probe.sh)
 
 
 def parse(argv=None):
@@ -280,6 +279,14 @@ def _sync():
     torch.cuda.synchronize()
 
 
+def _lib_version():
+    try:
+        from isaac_rover_amd import _lib
+        return _lib.version()
+    except Exception:
+        return ""
+
+
 def _gpu_event():
     """A timing event on the current stream, or None without a GPU (the CPU stand-in of tests/test_host_logic.py)."""
     import torch
@@ -299,9 +306,11 @@ def _profile_entry(fname, key):
         return None
 
 
-def roofline(args, E, n_rays, prof, info):
-    """The ray-cast kernel's roofline object.  Live: HIP-event time per launch.  From profiles/: VALU instructions and HBM
-    bytes per launch of the same workload (rocprofv3 --pmc, tools/collect_profiles.sh), see profiles/README.md."""
+def roofline(args, E, n_rays, prof, info, lib_version=""):
+    """The ray-cast kernel's roofline object.  Live: HIP-event time per launch.  From profiles/: per launch of the same workload the
+    VALU work in SIMD cycles (PMC instruction counts by kind x MEASURED cycles per instruction, profiles/issue_rates.json) and the HBM
+    bytes (rocprofv3 --pmc, tools/collect_profiles.sh); formulas in profiles/README.md.  `profile_stale`: the counts were taken on a
+    library built from other sources than the one running (rover_version() carries a hash of its sources)."""
     ray_ms = prof.raycast_ms / max(prof.launches, 1)
     t = ray_ms * 1e-3
     key = f"E{E}_P{args.rays}_K{args.k}_C{args.cells}" + ("" if args.ray_precision == "fp32" else "_" + args.ray_precision) \
@@ -313,19 +322,27 @@ def roofline(args, E, n_rays, prof, info):
     achieved = frac = insts_per_ray = None
     if valu and t > 0:
         insts = float(valu["valu_insts_per_launch"])
-        achieved = insts * VALU_CYCLES_PER_INST / t / 1e9
-        frac = achieved / peak
         insts_per_ray = insts / rays
+        cyc = valu.get("valu_simd_cycles_per_launch")
+        if cyc:
+            achieved = float(cyc) / t / 1e9
+            frac = achieved / peak
     traffic = traf.get("hbm_bytes_per_launch") if traf else None
     algo = 18.0 * prof.pairs_per_launch            # 18 B per (ray, triangle), no reuse credited
     algo_gbs = algo / t / 1e9 if t > 0 else None
     hbm = None
     if traffic and t > 0:
         hbm = {"traffic": traffic, "GBps": traffic / t / 1e9, "frac_of_8TBps": traffic / t / 1e9 / HBM_PEAK_GBS}
-    valu_obj = {"achieved": achieved, "peak": peak, "unit": "G VALU-issue cycles/s (1024 SIMDs x 2.4 GHz)", "frac": frac,
-                "valu_insts_per_ray": insts_per_ray}
-    # The bound is whichever resource the kernel uses the larger fraction of (both from profiles/ counters at the live time):
-    # the binned kernel (variant 2) is VALU-issue bound, the culled kernel (variant 3) moves its cull table at HBM rate.
+    valu_obj = {"achieved": achieved, "peak": peak, "unit": "G VALU-busy SIMD cycles/s (peak: 1024 SIMDs x 2.4 GHz)", "frac": frac,
+                "valu_insts_per_ray": insts_per_ray,
+                "cycles_per_inst": (float(valu["valu_simd_cycles_per_launch"]) / float(valu["valu_insts_per_launch"])
+                                    if valu and valu.get("valu_simd_cycles_per_launch") else None),
+                "issue_rates": valu.get("issue_rates_cycles") if valu else None}
+    profiled_lib = (valu or traf or {}).get("lib")
+    stale = bool(profiled_lib) and bool(lib_version) and profiled_lib != lib_version
+    if (valu or traf) and not profiled_lib:
+        stale = True                               # an entry from before the library carried a source hash
+    # The bound is whichever resource the kernel uses the larger fraction of (both from profiles/ counters at the live time)
     hbm_bound = hbm is not None and (frac is None or hbm["frac_of_8TBps"] >= frac)
     if hbm_bound:
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
@@ -335,11 +352,13 @@ def roofline(args, E, n_rays, prof, info):
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
                  "reuse_factor": (algo / traffic) if traffic else None,
-                 "note": "achieved (bound = hbm) = PMC-measured HBM bytes per launch (profiles/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, "
-                         "gfx950 correction) / live HIP-event time per launch; valu.frac = SQ_INSTS_VALU per launch (profiles/valu.json) "
-                         "x 4 cycles / (1024 SIMDs x 2.4 GHz x the same time); algorithmic_equiv_GBps = SURVEY 8(d)'s no-reuse byte "
-                         "model (18 B per (ray, triangle) pair), which the kernel beats by not touching provably rejected triangles: "
-                         "reuse_factor = model bytes / measured bytes; formulas in profiles/README.md"})
+                 "profile_key": key, "profile_lib": profiled_lib, "lib": lib_version, "profile_stale": stale,
+                 "note": "hbm: PMC-measured HBM bytes per launch (profiles/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) / live "
+                         "HIP-event time per launch; valu.frac = VALU-busy SIMD cycles per launch (profiles/valu.json: PMC instruction counts by "
+                         "kind x the measured cycles per instruction of profiles/issue_rates.json — 4.11 for packed f32 / compares / conversions, "
+                         "2.20 for 32-bit integer ops, 8 waves per SIMD) / (1024 SIMDs x 2.4 GHz x the same time); algorithmic_equiv_GBps = SURVEY "
+                         "8(d)'s no-reuse byte model (18 B per (ray, triangle) pair), which the kernel beats by not touching provably "
+                         "rejected triangles: reuse_factor = model bytes / measured bytes; formulas in profiles/README.md"})
     return head
 
 
@@ -558,7 +577,8 @@ def run_rank(args):
                        "table_bytes": int(info.table_bytes[0] + info.table_bytes[1])},
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": dist.get_backend() if world > 1 else None,
-            "roofline": roofline(args, E, n_rays, prof, info),
+            "roofline": roofline(args, E, n_rays, prof, info, _lib_version()),
+            "lib": _lib_version(),
         }
         if info.raycast_variant == 3:
             ci = eng.cull_info()

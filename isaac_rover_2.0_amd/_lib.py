@@ -144,6 +144,21 @@ def load():
     return _lib
 
 
+def version() -> str:
+    """rover_version(): "rover_step <ver> (gfx950) src-<12 hex>": the hash of the sources the loaded library was built from."""
+    return load().rover_version().decode()
+
+
+def source_hash() -> str:
+    """The same hash computed from the source files in the tree (what a fresh build.sh would embed)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_cull.hip", "rover_mlp.hip", "rover_internal.h", "rover_raymath.h"):
+        h.update(open(os.path.join(_CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_CSRC), "..", "include", "rover_step.h"), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -27,9 +27,9 @@ struct rover_ctx {
     int32_t* cull_idx[2]{nullptr, nullptr};
     uint4* cull_ctab[2]{nullptr, nullptr};
     uint4* cull_ctab_h[2]{nullptr, nullptr};    // the same for the as-shipped fp16 arithmetic's rejection proof (ray_precision 2)
-    uint4* cull_qrow_h[2]{nullptr, nullptr};
+    uint32_t* cull_qrow_h[2]{nullptr, nullptr};
     uint16_t* cull_rtab[2]{nullptr, nullptr};
-    uint4* cull_qrow[2]{nullptr, nullptr};
+    uint32_t* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
@@ -341,7 +341,10 @@ static void cull_numbering(const std::vector<float2>& cen, std::vector<uint32_t>
 
 extern "C" {
 
-const char* rover_version(void) { return "rover_step 0.1 (gfx950)"; }
+#ifndef ROVER_SRC_HASH
+#define ROVER_SRC_HASH "unknown"
+#endif
+const char* rover_version(void) { return "rover_step 0.3 (gfx950) src-" ROVER_SRC_HASH; }
 
 const char* rover_last_error(const rover_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -426,7 +429,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     int32_t* d_cidx = nullptr;
     uint4 *d_ctab = nullptr, *d_ctab_h = nullptr;
     uint16_t* d_rtab = nullptr;
-    uint4 *d_qrow = nullptr, *d_qrow_h = nullptr;
+    uint32_t *d_qrow = nullptr, *d_qrow_h = nullptr;
     float* d_nz = nullptr;
     uint32_t* d_cnt = nullptr;
     uint32_t h_cnt[4] = {0, 0, 0, 0};
@@ -454,10 +457,10 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint4);
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t);
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
-            (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint4))) != hipSuccess ||
-            (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint4))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_nz, (uint64_t)T_int * sizeof(float))) != hipSuccess ||
             (e = hipMalloc((void**)&d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_order, (uint64_t)T_int * sizeof(uint32_t))) != hipSuccess ||
@@ -629,7 +632,6 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     const bool h = c->precision == 2;     // the as-shipped fp16 arithmetic: its own proof tables, the fp16 exact phase
     a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1];
     a.ctab0 = h ? c->cull_ctab_h[0] : c->cull_ctab[0]; a.ctab1 = h ? c->cull_ctab_h[1] : c->cull_ctab[1];
-    a.qrow0 = h ? c->cull_qrow_h[0] : c->cull_qrow[0]; a.qrow1 = h ? c->cull_qrow_h[1] : c->cull_qrow[1];
     a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1];
     a.half = h ? 1 : 0;
     const CullProofH ph = cull_proof_h(c->cull_eta_h);
@@ -664,6 +666,10 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     if (variant >= 2) p.bin_out = c->d_bins;
     p.precision = c->precision;
     p.cell_rcp = c->cell_rcp;
+    if (variant == 3) {     // the cells' normal cones of the proof in force: prep_rays_kernel leaves the per-ray verdict in the ray record
+        const bool h = c->precision == 2;
+        p.qrow0 = h ? c->cull_qrow_h[0] : c->cull_qrow[0]; p.qrow1 = h ? c->cull_qrow_h[1] : c->cull_qrow[1];
+    }
     HIP_TRY(c, launch_prep(p, s));
     if (variant >= 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,

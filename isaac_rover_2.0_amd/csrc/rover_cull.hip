@@ -283,10 +283,12 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
 }
 
 // one workgroup per cell: the cell's K ids (internal numbering) sorted ascending, paired and dealt to the lanes;
-// qrow[cell] = {q16, 0, 0, 0}: q = min |N_z| / |N| over the cell's triangles as a 16-bit fraction rounded down (0 = none)
+// qrow[cell] = q16: the cell's normal cone as a 16-bit fraction rounded down (0 = none) — f32 proof: q = min |N_z| / |N| over the
+// cell's triangles; fp16 proof: the largest angle from the vertical a ray may have, over pi / 2.  prep_rays_kernel compares it with
+// the ray's own bound and leaves the verdict in the ray record (flags bit 2)
 __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restrict__ map_idx, uint32_t K, uint32_t K8, uint32_t T,
                                                          const uint32_t* __restrict__ newid, const float* __restrict__ nz_abs,
-                                                         int32_t* __restrict__ idx4, uint4* __restrict__ qrow,
+                                                         int32_t* __restrict__ idx4, uint32_t* __restrict__ qrow,
                                                          uint32_t* __restrict__ counts) {
     __shared__ uint32_t key[256];
     __shared__ float qmin[256];
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         const float q = qmin[0];
         uint32_t q16 = 0;
         if (q <= 1.0f && q > 0.0f) { q16 = (uint32_t)floorf(q * 65535.0f); q16 = q16 > 0xfffeu ? 0xfffeu : q16; }
-        qrow[cell] = make_uint4(q16, 0u, 0u, 0u);
+        qrow[cell] = q16;
         if (counts && q16 == 0u) atomicAdd(counts + 1, 1u);             // no normal cone: its rays run both tests on every pair
     }
 }
@@ -483,7 +485,7 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
-        const uint4 *__restrict__ qrow0, const uint4 *__restrict__ qrow1, uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
+        uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
         const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h
 
 template <int H>
@@ -542,17 +544,20 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     while (r_next < n_run) {
     // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
     // id rows ahead.
-    const uint32_t key = rays[gid].cell | (rays[gid].flags << 31);                     // cell | map << 31
+    const uint32_t rflags = rays[gid].flags;
+    const uint32_t key = rays[gid].cell | (rflags << 31);                              // cell | map << 31
+    // bit i: the normal cone of ray i's cell covers the ray (prep_rays_kernel decided, flags bit 2): test (B) holds for every
+    // triangle of the cell, the scan runs test (A) only
+    const uint64_t conemask = __builtin_amdgcn_ballot_w64((rflags & 4u) != 0u);
+    if (r_next == 0u) n_both += (uint32_t)__builtin_popcountll(~conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
     const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
     // bit i: ray i starts a new (map, cell) bin
     const uint64_t heads = __builtin_amdgcn_ballot_w64(lane < n_run && (lane == 0u || key != prev));
     // Per ray, for all 64 at once: the byte offset of its bin's id row in its map's table with the map in bit 0 (rows are
-    // multiples of 16 bytes; tables stay below 4 GB, rover_set_knn_map checks) and the bin's normal cone (the cell's q as a 16-bit
-    // fraction, 0 = none) — a bin then costs one v_readlane for its row and one for its cone, and these two registers and the ray
-    // ids are all the per-run state a lane carries through the scan.
+    // multiples of 16 bytes; tables stay below 4 GB, rover_set_knn_map checks) — a bin then costs one v_readlane for its row, and
+    // this register and the ray ids are all the per-run state a lane carries through the scan.
     const uint32_t kmap = key >> 31, kcell = key & 0x7fffffffu;
     const uint32_t rowm = (kcell * (((kmap ? kp01 >> 16 : kp01) & 0xffffu) >> 2) * 16u) | kmap;
-    const uint32_t q16v = (kmap ? qrow1 : qrow0)[kcell].x;
     uint64_t hm = (heads | (1ull << r_next)) & (~0ull << r_next);        // bins of the segment (its first ray opens one)
     n_bins += (uint32_t)__builtin_popcountll(hm);
     uint64_t pf_heads = hm;                    // bins whose row is not requested yet
@@ -588,15 +593,12 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
         const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[w][use_n % CULL_RING][0]) + lane_off(map));
-        // the cell's normal cone as a 16-bit fraction (0: none)
-        const uint32_t q16 = (uint32_t)__builtin_amdgcn_readlane((int)q16v, (int)i);
         ++use_n;
         const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
         const uint4* ct = map ? ctab1 : ctab0;
         uint4 rec[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) rec[jj] = ct[id[jj] < 0 ? 0 : id[jj]];
-        if (pf_heads) { wave_lds_sync(); prefetch_row(); }              // into the slot just read (the ids are in registers)
         CullRegs t;
         uint32_t qid[2][2];                    // the lane's ids as queue-entry fields
 #pragma unroll
@@ -621,6 +623,12 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             qid[p][0] = (e0 ? (uint32_t)id[2 * p] : CULL_NOID) | (map << 31);
             qid[p][1] = e1 ? (uint32_t)id[2 * p + 1] : CULL_NOID;
         }
+        // The next row request goes out AFTER the records above were unpacked: the compiler waits for them with s_waitcnt vmcnt(0)
+        // (vector memory operations retire in order), and issued before the gathers' data are used, the request — an HBM round trip —
+        // would be waited for right there, in every bin.  Here nothing waits for it before the next bin's start.
+        // (an empty asm that consumes what the unpacking produced pins the order: the compiler otherwise sinks the unpacking below the request)
+        asm volatile("" :: "v"(t.mx[0]), "v"(t.mx[1]), "v"(t.nz[0]), "v"(t.nz[1]), "v"(t.r2[0]), "v"(t.r2[1]) : "memory");
+        if (pf_heads) { wave_lds_sync(); prefetch_row(); }              // into the slot just read (the ids are in registers)
         uint32_t r = i;
         for (; r < i_end; ++r) {
             // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
@@ -628,9 +636,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
             const sgpr2 sxy = sgpr_pair(ra.x, ra.y), szc = sgpr_pair(ra.z, ra.w), dxy = sgpr_pair(rb.x, rb.y), dzf = sgpr_pair(rb.z, rb.w);
             uint64_t any[2];
-            // the ray's cone bound (prep_rays_kernel, flags bits 16..31) against the cell's: (B) holds for every triangle
-            const bool cone = q16 >= (__float_as_uint(rb.w) >> 16);
-            n_both += cone ? 0u : 1u;
+            const bool cone = (conemask >> r) & 1ull;                                   // (B) holds for every triangle of the cell
             if (cone) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -702,7 +708,7 @@ hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint
 // ctab / qrow: the f32 proof's tables; ctab_h / qrow_h: the as-shipped fp16 arithmetic's (CullK<1>); idx4 and rtab serve both.
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
-                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint4* qrow, uint4* qrow_h, float* nz_scratch,
+                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float* nz_scratch,
                              uint32_t* counts /* [4], zeroed: always-candidate triangles, cells without a cone; the same for fp16 */,
                              CullProofH ph, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
@@ -758,7 +764,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
         auto kern = a.half ? cull_scan_kernel<1> : cull_scan_kernel<0>;
         hipLaunchKernelGGL(kern, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
-                           reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1, a.qrow0, a.qrow1,
+                           reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
                            reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h);
     }

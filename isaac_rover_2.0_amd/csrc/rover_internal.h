@@ -10,7 +10,8 @@ struct RayRec {
     float sx, sy, sz;    // origin
     uint32_t cell;       // ix * Y + iy into the map the flags select
     float dx, dy, dz;    // -normalize(direction), ray_casting.py:31
-    uint32_t flags;      // bit0: rocks map, bit1: valid; bits 16..31: the ray's normal-cone bound (rover_cull.hip), 0xffff = none
+    uint32_t flags;      // bit0: rocks map, bit1: valid, bit2: the cell's normal cone covers the ray (culled ray cast: test (A) only);
+                         // bits 16..31: the ray's normal-cone bound (rover_cull.hip), 0xffff = none
 };
 static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
 
@@ -50,6 +51,7 @@ struct PrepArgs {
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
     int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
+    const uint32_t *qrow0, *qrow1; // optional [cell]: the normal cone of every cell of the terrain / rocks map (culled ray cast)
 };
 
 // constants of the culled ray cast's rejection proof for the as-shipped fp16 arithmetic, derived from its one free parameter eta
@@ -64,7 +66,6 @@ struct CullArgs {
     uint32_t n_terrain;          // the first n_terrain sorted rays are terrain rays (bins are (map, cell): terrain first)
     const int32_t *idx0, *idx1;  // [cell][K8/4][4] triangle ids of the cell (-1 = empty slot)
     const uint4 *ctab0, *ctab1;  // [T] 16 B: bounding-sphere centre + scaled unit normal per triangle (phase 1)
-    const uint4 *qrow0, *qrow1;  // [cell] {q16, 0, 0, 0}: the cell's normal cone (min |N_z| / |N| as a 16-bit fraction)
     const uint16_t *rtab0, *rtab1; // [T] 20 B: the triangle's nine fp16 vertex components (exact arithmetic, phase 2)
     uint32_t kp0, kp1, run, n_blocks;
     float* out;                  // [E*R8] distances
@@ -188,7 +189,7 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
 hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint32_t T, uint32_t V, float2* out, hipStream_t s);
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
-                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint4* qrow, uint4* qrow_h, float* nz_scratch,
+                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float* nz_scratch,
                              uint32_t* counts, CullProofH ph, hipStream_t s);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,

@@ -10,6 +10,8 @@ ap.add_argument("--out", required=True)
 ap.add_argument("--tag", required=True)
 ap.add_argument("--workload-key", default="", help="e.g. E65536_P37_K200_C600: also write traffic.json / valu.json entries "
                                                      "(read by bench.py's roofline object) for the ray-cast kernel")
+ap.add_argument("--lib", default="", help="rover_version() of the profiled library (its source hash is stored with the entries)")
+ap.add_argument("--merge-into", default="", help="directory holding valu.json / traffic.json to update with this key's entries")
 a = ap.parse_args()
 os.makedirs(a.out, exist_ok=True)
 pmc = {}
@@ -60,12 +62,41 @@ if pmc and a.workload_key:
                               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes); bytes = "
                                         "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction); cross-check TCC_MISS_sum*128 B = "
                                         f"{c['TCC_MISS_sum']['mean'] * 128.0:.4g}", "source": src}}
-        v = {a.workload_key: {"valu_insts_per_launch": c["SQ_INSTS_VALU"]["mean"],
+        # VALU time per launch from MEASURED issue rates (profiles/issue_rates.json, tools/issue_rates.hip: cycles one SIMD needs per
+        # wave64 instruction when 8 waves share it) and the kind counters (profiles/counter_calibration.txt: a packed instruction counts
+        # once, in the counter of its kind).  In the ray-cast kernels every f32 add / mul / fma is a packed one (the ISA holds no plain
+        # v_add / v_mul / v_fma_f32); conversions, compares, lane reads and selects run at the packed rate too; 32-bit integer / logic
+        # instructions at the full rate.
+        here = os.path.dirname(os.path.abspath(__file__))
+        rates = json.load(open(os.path.join(here, "..", "profiles", "issue_rates.json")))["rates"]
+        r_pk = max(rates[k + "@8"]["cycles_per_inst"] for k in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"))
+        r_cvt, r_int, r_oth = rates["v_cvt_f32_f16@8"]["cycles_per_inst"], rates["v_and_b32@8"]["cycles_per_inst"], rates["v_cmp_gt_f32@8"]["cycles_per_inst"]
+        kinds = {n: c.get("SQ_INSTS_VALU_" + n, {}).get("mean") for n in ("ADD_F32", "MUL_F32", "FMA_F32", "CVT", "INT32", "TRANS_F32")}
+        simd_cycles = None
+        if all(v is not None for v in kinds.values()):
+            arith = kinds["ADD_F32"] + kinds["MUL_F32"] + kinds["FMA_F32"]
+            other = c["SQ_INSTS_VALU"]["mean"] - arith - kinds["CVT"] - kinds["INT32"]
+            simd_cycles = arith * r_pk + kinds["CVT"] * r_cvt + kinds["INT32"] * r_int + max(other, 0.0) * r_oth
+        lib = a.lib
+        v = {a.workload_key: {"valu_insts_per_launch": c["SQ_INSTS_VALU"]["mean"], "valu_kind_counts_per_launch": kinds,
+                              "valu_simd_cycles_per_launch": simd_cycles,
+                              "issue_rates_cycles": {"packed_f32": r_pk, "cvt": r_cvt, "int32": r_int, "other": r_oth},
                               "valu_active_quadcycles_per_launch": c["SQ_ACTIVE_INST_VALU"]["mean"],
                               "wave_quadcycles_per_launch": c["SQ_WAVE_CYCLES"]["mean"], "salu_insts_per_launch": c["SQ_INSTS_SALU"]["mean"],
-                              "kernel": k.split("(")[0], "source": src,
-                              "method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES "
-                                        "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY, mean over the launches of the pass"}}
-        json.dump(t, open(os.path.join(a.out, "traffic_entry.json"), "w"), indent=1)
-        json.dump(v, open(os.path.join(a.out, "valu_entry.json"), "w"), indent=1)
+                              "kernel": k.split("(")[0], "source": src, "lib": lib,
+                              "method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU ... and SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 / _CVT / _INT32 "
+                                        "(separate passes), mean over the launches of a pass; valu_simd_cycles = sum over kinds of count x the measured "
+                                        "cycles per instruction of profiles/issue_rates.json (8 waves per SIMD)"}}
+        t[a.workload_key]["lib"] = lib
+        json.dump(t, open(os.path.join(a.out, f"traffic_entry_{a.workload_key}.json"), "w"), indent=1)
+        json.dump(v, open(os.path.join(a.out, f"valu_entry_{a.workload_key}.json"), "w"), indent=1)
+        if a.merge_into:
+            for name, ent in (("traffic.json", t), ("valu.json", v)):
+                path = os.path.join(a.merge_into, name)
+                try:
+                    cur = json.load(open(path))
+                except (OSError, ValueError):
+                    cur = {}
+                cur.update(ent)
+                json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
 print("wrote", os.listdir(a.out))
