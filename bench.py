@@ -584,6 +584,7 @@ def run_rank(args):
             ci = eng.cull_info()
             line["cull"] = {"candidate_pairs_per_ray": ci["pairs_per_ray"], "rays_with_both_tests": ci["rays_both_tests"] / max(ci["rays"], 1),
                             "rays_per_bin": ci["rays"] / max(ci["bins"], 1), "max_pairs_per_run": ci["max_pairs_per_run"],
+                            "rays_far_skipped": ci["rays_far_skipped"] / max(ci["rays"], 1),
                             "always_candidate_triangles": ci["always_candidate_triangles"], "cells_without_cone": ci["cells_without_cone"],
                             "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"]}
         if world > 1:

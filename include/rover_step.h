@@ -304,6 +304,7 @@ typedef struct {
     uint64_t max_pairs_per_run;    /* most queue entries any one run of sorted rays produced */
     uint64_t queue_bytes;          /* size of the candidate queue allocation */
     uint64_t launches_per_step;    /* 1, unless the queue budget ("cull_queue_mb") forces a step's ray cast into slices */
+    uint64_t rays_far_skipped;     /* rays whose scan skipped the farther half of their cell's triangles (proved clear as a group) */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -28,6 +28,8 @@ struct rover_ctx {
     uint4* cull_ctab[2]{nullptr, nullptr};
     uint4* cull_ctab_h[2]{nullptr, nullptr};    // the same for the as-shipped fp16 arithmetic's rejection proof (ray_precision 2)
     uint32_t* cull_qrow_h[2]{nullptr, nullptr};
+    float4* cull_far[2]{nullptr, nullptr};      // [cell][2] far-pair bounds (f32 proof / fp16 proof)
+    float4* cull_far_h[2]{nullptr, nullptr};
     uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint32_t* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
@@ -379,7 +381,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); dfree(c->cull_far[w]); dfree(c->cull_far_h[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -430,6 +432,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint4 *d_ctab = nullptr, *d_ctab_h = nullptr;
     uint16_t* d_rtab = nullptr;
     uint32_t *d_qrow = nullptr, *d_qrow_h = nullptr;
+    float4 *d_far = nullptr, *d_far_h = nullptr;
     float* d_nz = nullptr;
     uint32_t* d_cnt = nullptr;
     uint32_t h_cnt[4] = {0, 0, 0, 0};
@@ -438,7 +441,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     if (K8 <= 256 && (uint32_t)T < 0x1ffffffu) {
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t);
         uint32_t T_int = 0;
-        auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_nz); dfree(d_cnt);
+        auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_far); dfree(d_far_h); dfree(d_nz); dfree(d_cnt);
                             dfree(d_order); dfree(d_newid); dfree(d_table); };
         // internal triangle numbering (spatial partners get ids 2p, 2p + 1, pairs ordered along a Morton curve): cull_numbering()
         std::vector<uint32_t> order, newid((size_t)T);
@@ -457,10 +460,11 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t);
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 32u;
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_far, n_cells * 32u)) != hipSuccess || (e = hipMalloc((void**)&d_far_h, n_cells * 32u)) != hipSuccess ||
             (e = hipMalloc((void**)&d_nz, (uint64_t)T_int * sizeof(float))) != hipSuccess ||
             (e = hipMalloc((void**)&d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_order, (uint64_t)T_int * sizeof(uint32_t))) != hipSuccess ||
@@ -469,7 +473,8 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemset(d_cnt, 0, 4 * sizeof(uint32_t))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
-                                   d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), nullptr)) != hipSuccess ||
+                                   d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
+                                   shift_x, shift_y, nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
             drop();
@@ -483,7 +488,8 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
-    dfree(c->cull_ctab_h[which]); dfree(c->cull_qrow_h[which]);
+    dfree(c->cull_ctab_h[which]); dfree(c->cull_qrow_h[which]); dfree(c->cull_far[which]); dfree(c->cull_far_h[which]);
+    c->cull_far[which] = d_far; c->cull_far_h[which] = d_far_h;
     c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_qrow[which] = d_qrow; c->cull_bytes[which] = cull_bytes;
     c->cull_ctab_h[which] = d_ctab_h; c->cull_qrow_h[which] = d_qrow_h;
     c->map[which] = KnnDev{d_table, X, Y, K, (int32_t)K8, cell, shift_x, shift_y, 1.0f / cell};
@@ -636,6 +642,8 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.half = h ? 1 : 0;
     const CullProofH ph = cull_proof_h(c->cull_eta_h);
     a.c_a_h = ph.c_a; a.tau2_h = ph.tau2;
+    a.far0 = h ? c->cull_far_h[0] : c->cull_far[0]; a.far1 = h ? c->cull_far_h[1] : c->cull_far[1];
+    a.k2_far = cull_far_k2(a.half, ph);
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.out = c->d_dist_out;
@@ -948,7 +956,7 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
     std::vector<uint4> h(c->cull_stat_slots);
     HIP_TRY(c, hipMemcpy(h.data(), c->d_cull_stats, h.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (const uint4& v : h) {
-        out->candidate_pairs += v.x; out->rays += v.y; out->rays_both_tests += v.z; out->bins += v.w;
+        out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z; out->bins += v.w;
         out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
     }
     return ROVER_OK;

@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(256) ctab_build_kernel(const uint16_t* __restr
 // the ray's own bound and leaves the verdict in the ray record (flags bit 2)
 __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restrict__ map_idx, uint32_t K, uint32_t K8, uint32_t T,
                                                          const uint32_t* __restrict__ newid, const float* __restrict__ nz_abs,
-                                                         int32_t* __restrict__ idx4, uint32_t* __restrict__ qrow,
+                                                         const uint16_t* __restrict__ rtab, uint32_t Y, float cell_size, float shift_x,
+                                                         float shift_y, int32_t* __restrict__ idx4, uint32_t* __restrict__ qrow,
                                                          uint32_t* __restrict__ counts) {
     __shared__ uint32_t key[256];
     __shared__ float qmin[256];
@@ -337,9 +338,38 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         n_pairs += wsum[0][w2];
     }
     // (a `second` sits right behind its `first`: the same pair index; across a wave boundary pf already counts that first)
-    if (present) {
-        const uint32_t m = first ? pf : (second ? pf - 1u : n_pairs + (ps >> 1)), e = first ? 0u : (second ? 1u : (ps & 1u));
-        if (m < (K8 >> 1)) row[(m % L) * 4u + 2u * (m / L) + e] = (int32_t)id;
+    const uint32_t m = first ? pf : (second ? pf - 1u : n_pairs + (ps >> 1)), e = first ? 0u : (second ? 1u : (ps & 1u));
+    // Near and far.  A lane holds two pairs: slot 0 takes the L pairs NEAREST to the cell's centre (by the nearer centroid of a
+    // pair), slot 1 the others — the farther half of a K = 200 list.  A ray of the cell passes close to the centre, so most rays
+    // can be shown to clear every far triangle at once (far_build_kernel, cull_scan_kernel) and skip slot 1 altogether.  The choice
+    // is a matter of speed only: whatever the split, the far bound is computed from the triangles that ended up in slot 1.
+    __shared__ float pkey[128];
+    __shared__ uint8_t pfar[128];
+    if (tid < 128u) { pkey[tid] = __builtin_inff(); pfar[tid] = 0; }
+    __syncthreads();
+    if (present && m < 128u) {
+        const _Float16* v = reinterpret_cast<const _Float16*>(rtab) + 10ull * id;
+        const float cx = ((float)v[0] + (float)v[3] + (float)v[6]) * (1.0f / 3.0f), cy = ((float)v[1] + (float)v[4] + (float)v[7]) * (1.0f / 3.0f);
+        const float ccx = (float)(cell / Y) * cell_size + shift_x, ccy = (float)(cell % Y) * cell_size + shift_y;
+        float d = sqrtf((cx - ccx) * (cx - ccx) + (cy - ccy) * (cy - ccy));
+        if (!(d == d)) d = 0.0f;                                            // a broken triangle: near (it is always a candidate anyway)
+        atomicMin(reinterpret_cast<uint32_t*>(&pkey[m]), __float_as_uint(d));   // non-negative floats order like their bits
+    }
+    __syncthreads();
+    const uint32_t np_total = n_pairs + ((wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3] + 1u) >> 1);
+    const uint32_t n_far = np_total > L ? min(np_total - L, L) : 0u;
+    if (tid < np_total && tid < 128u) {                                     // rank of pair `tid` among the pairs, farthest first (ties: larger index first)
+        const float kd = pkey[tid];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < np_total && q < 128u; ++q) rank += (pkey[q] > kd || (pkey[q] == kd && q > tid)) ? 1u : 0u;
+        pfar[tid] = rank < n_far ? 1u : 0u;
+    }
+    __syncthreads();
+    if (present && m < 128u) {
+        const uint32_t far = pfar[m];
+        uint32_t pos = 0;                                                   // pairs of the same set in front of this one (id order)
+        for (uint32_t q = 0; q < m; ++q) pos += pfar[q] == far ? 1u : 0u;
+        if (pos < L) row[pos * 4u + 2u * far + e] = (int32_t)id;
     }
     __syncthreads();
     if (tid < K8) idx4[(uint64_t)cell * K8 + tid] = row[tid];
@@ -350,6 +380,45 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
         qrow[cell] = q16;
         if (counts && q16 == 0u) atomicAdd(counts + 1, 1u);             // no normal cone: its rays run both tests on every pair
     }
+}
+
+// One wave per cell: the bound of its FAR pairs (slot 1 of every lane), for one proof's tables.  For a ray with origin s and unit
+// direction at angle beta from the vertical and a triangle with decoded centre m, r2:  c_a |h|^2 - (h.d)^2 = c_a W^2 - (dd - c_a) a^2
+// (W: distance from m to the ray's line, a: the axial part of h, dd >= |d|^2), W >= cos(beta) (dist_xy(m, C) - e), e = dist_xy(s, C) +
+// |s_z - m_z| tan(beta) (the line's offset from the cell's centre C at the height of m), |h| <= hmax.  So test (A) holds for EVERY
+// far triangle if  min_t (dist_xy(m_t, C) - k1 sqrt(r2_t))  >  e_max + k2 hmax  with k1 = 1 / (0.9 sqrt(c_a)), k2 = sqrt(dd - c_a) k1 and
+// cos(beta) >= 0.9.  The record holds the left side G (-inf if a far triangle is always a candidate, +inf if slot 1 is empty), the z
+// range of the far centres, the largest dist_xy(m_t, C) and C.
+struct FarRec { float G, z0, z1, rho_out, cx, cy, pad0, pad1; };
+__global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__ idx4, const uint4* __restrict__ ctab, uint64_t n_cells, uint32_t K8,
+                                                        uint32_t Y, float cell_size, float shift_x, float shift_y, float k1, float tau2,
+                                                        FarRec* __restrict__ out) {
+    const uint64_t cell = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u, L = K8 >> 2;
+    if (cell >= n_cells) return;
+    const float ccx = (float)(cell / Y) * cell_size + shift_x, ccy = (float)(cell % Y) * cell_size + shift_y;
+    float G = __builtin_inff(), z0 = __builtin_inff(), z1 = -__builtin_inff(), ro = 0.0f;
+    if (lane < L) {
+        const int4 id4 = idx4[cell * L + lane];
+        const int32_t ids[2] = {id4.z, id4.w};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (ids[j] < 0) continue;
+            const uint4 r = ctab[ids[j]];
+            const f2 zn = cvt2(r.z), w = cvt2(r.w);
+            const float mx = __uint_as_float(r.x), my = __uint_as_float(r.y), mz = zn.x;
+            const float r2 = cull_r2(zn.y, w.x, w.y, tau2);
+            const float dxy = sqrtf((mx - ccx) * (mx - ccx) + (my - ccy) * (my - ccy));
+            float g = (dxy - k1 * sqrtf(r2) * 1.00001f) * 0.99999f - 1.0e-6f;
+            if (!(g == g) || !(r2 < 3.0e38f)) g = -__builtin_inff();        // always a candidate / broken: never skipped
+            G = fminf(G, g); z0 = fminf(z0, mz); z1 = fmaxf(z1, mz); ro = fmaxf(ro, dxy);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        G = fminf(G, __shfl_xor(G, off)); z0 = fminf(z0, __shfl_xor(z0, off)); z1 = fmaxf(z1, __shfl_xor(z1, off)); ro = fmaxf(ro, __shfl_xor(ro, off));
+    }
+    if (lane == 0u) out[cell] = FarRec{G, z0, z1, ro, ccx, ccy, 0.0f, 0.0f};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,7 +555,7 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
         uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
-        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h, const float4 *__restrict__ far0, const float4 *__restrict__ far1, float k2_far
 
 template <int H>
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
@@ -535,7 +604,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
     wave_lds_sync();
     bk[lane] = fkey(RAY_MISS);                 // 11.0 where a ray has no candidate at all (a culled triangle contributes exactly that)
-    uint32_t ctot = 0, n_both = 0, n_bins = 0; // queue entries / rays that ran both tests / bins walked (rover_get_cull_info)
+    uint32_t ctot = 0, n_both = 0, n_bins = 0, n_fskip = 0; // queue entries / rays that ran both tests / bins walked / rays that skipped the far pairs (rover_get_cull_info)
     uint32_t r_next = 0;                       // first ray of the run that is not scanned yet
     // One SEGMENT = scan rays [r_next, ...) until the run ends or the queue region could overflow with one more ray, then the exact
     // arithmetic on the entries.  Nearly every run is one segment (a run of 64 terrain rays queues ~500 entries).  Everything a
@@ -544,8 +613,13 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     while (r_next < n_run) {
     // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
     // id rows ahead.
-    const uint32_t rflags = rays[gid].flags;
-    const uint32_t key = rays[gid].cell | (rflags << 31);                              // cell | map << 31
+    // (through an opaque copy of the ray id: everything below is invariant across segments, and hoisted out of this loop by the
+    //  compiler it would stay in registers through the scan AND the exact phase — 76 VGPRs instead of 62)
+    uint32_t gid_s = gid;
+    asm volatile("" : "+v"(gid_s));
+    const float4 rsa = reinterpret_cast<const float4*>(rays + gid_s)[0], rsb = reinterpret_cast<const float4*>(rays + gid_s)[1];
+    const uint32_t rflags = __float_as_uint(rsb.w);
+    const uint32_t key = __float_as_uint(rsa.w) | (rflags << 31);                      // cell | map << 31
     // bit i: the normal cone of ray i's cell covers the ray (prep_rays_kernel decided, flags bit 2): test (B) holds for every
     // triangle of the cell, the scan runs test (A) only
     const uint64_t conemask = __builtin_amdgcn_ballot_w64((rflags & 4u) != 0u);
@@ -558,6 +632,22 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     // this register and the ray ids are all the per-run state a lane carries through the scan.
     const uint32_t kmap = key >> 31, kcell = key & 0x7fffffffu;
     const uint32_t rowm = (kcell * (((kmap ? kp01 >> 16 : kp01) & 0xffffu) >> 2) * 16u) | kmap;
+    // bit i: ray i clears every FAR triangle of its cell (slot 1 of every lane) at once — far_build_kernel has the derivation —
+    // so on the cone path its scan skips slot 1 altogether; each lane decides for its own ray
+    uint64_t farskip = 0;          // (f32 proof only: with the fp16 proof's c_a the bound rarely holds, and its kernel has no registers to spare)
+    if (!H) {
+        const float4* fr = (kmap ? far1 : far0) + 2ull * kcell;
+        const float4 fa = fr[0], fb = fr[1];                                  // {G, z0, z1, rho_out}, {Cx, Cy, -, -}
+        // (hardware square roots, 1 ulp, and no division — the inequality is multiplied through by |d_z| — the margins are 1e-4)
+        const float ox = rsa.x - fb.x, oy = rsa.y - fb.y, o = __builtin_amdgcn_sqrtf(ox * ox + oy * oy);
+        const float dzm = fmaxf(fabsf(rsa.z - fa.y), fabsf(rsa.z - fa.z));
+        const float dxy2 = rsb.x * rsb.x + rsb.y * rsb.y, adz = fabsf(rsb.z);
+        const bool steep = adz * adz >= 0.81f * (dxy2 + adz * adz) * 1.0001f;  // cos(beta) >= 0.9
+        const float e_adz = o * adz + dzm * __builtin_amdgcn_sqrtf(dxy2) * 1.0001f;                      // e_max |d_z|
+        const float hmax = __builtin_amdgcn_sqrtf((o + fa.w) * (o + fa.w) + dzm * dzm) * 1.00001f;
+        farskip = __builtin_amdgcn_ballot_w64(steep && (fa.x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * hmax * adz) * 1.0001f);
+    }
+    if (r_next == 0u) n_fskip += (uint32_t)__builtin_popcountll(farskip & conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
     uint64_t hm = (heads | (1ull << r_next)) & (~0ull << r_next);        // bins of the segment (its first ray opens one)
     n_bins += (uint32_t)__builtin_popcountll(hm);
     uint64_t pf_heads = hm;                    // bins whose row is not requested yet
@@ -638,14 +728,15 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
             uint64_t any[2];
             const bool cone = (conemask >> r) & 1ull;                                   // (B) holds for every triangle of the cell
             if (cone) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                auto test_a = [&](int p) {                                                  // (A): c_a |h|^2 - (h.d)^2 > r2
                     const f2 hx = pk_rsub<0>(sxy, t.mx[p]), hy = pk_rsub<1>(sxy, t.my[p]), hz = pk_rsub<0>(szc, t.mz[p]);
                     const f2 hd = pk_fma_s<0>(hz, dzf, pk_fma_s<1>(hy, dxy, pk_mul_s<0>(hx, dxy)));
                     f2 hh = hx * hx; hh = fma2(hy, hy, hh); hh = fma2(hz, hz, hh);
-                    const f2 A = fma2(hh, f2{k_ca, k_ca}, -(hd * hd));                   // (A): c_a |h|^2 - (h.d)^2 > r2
-                    any[p] = ~(__builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y));
-                }
+                    const f2 A = fma2(hh, f2{k_ca, k_ca}, -(hd * hd));
+                    return ~(__builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y));
+                };
+                any[0] = test_a(0);
+                any[1] = ((farskip >> r) & 1ull) ? 0ull : test_a(1);                         // every far triangle cleared: slot 1 skipped
             } else {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -690,7 +781,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     wave_lds_sync();
     if (lane < n_run) out[gid] = funkey(bk[lane]);
     // per-wave counters of THIS launch (plain stores, 16 B per wave; summed on the host by rover_get_cull_info)
-    if (lane == 0u) stats[wave] = make_uint4(ctot, n_run, n_both, n_bins);
+    if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both, n_bins);
     }
 }
 
@@ -704,18 +795,40 @@ hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint
     return hipGetLastError();
 }
 
+// the far-skip constants of a proof: k1 (folded into the far records) and k2 (the scan kernel's), from its c_a and the largest |d|^2
+static void cull_far_consts(double c_a, double dd, float* k1, float* k2) {
+    const double ca = c_a - 1.0e-5;
+    *k1 = (float)(1.00001 / (0.9 * sqrt(ca)));
+    *k2 = (float)(1.00001 * sqrt(dd + 1.0e-5 - ca) / (0.9 * sqrt(ca)));
+}
+float cull_far_k2(int half, CullProofH ph) {
+    float k1, k2;
+    if (half) cull_far_consts(ph.c_a, 1.004, &k1, &k2); else cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    return k2;
+}
+
 // T: the caller's triangle count (ids in map_idx); T_int: slots of the internal numbering (order [T_int], newid [T]).
-// ctab / qrow: the f32 proof's tables; ctab_h / qrow_h: the as-shipped fp16 arithmetic's (CullK<1>); idx4 and rtab serve both.
+// ctab / qrow / far: the f32 proof's tables; ctab_h / qrow_h / far_h: the as-shipped fp16 arithmetic's (CullK<1>); idx4 and rtab serve both.
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
-                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float* nz_scratch,
+                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
+                             float4* far_h, float* nz_scratch,
                              uint32_t* counts /* [4], zeroed: always-candidate triangles, cells without a cone; the same for fp16 */,
-                             CullProofH ph, hipStream_t s) {
+                             CullProofH ph, uint32_t Y, float cell_size, float shift_x, float shift_y, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
     hipLaunchKernelGGL(ctab_build_kernel<1>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab_h, nz_scratch, counts + 2, ph);
-    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, idx4, qrow_h, counts + 2);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, rtab, Y, cell_size,
+                       shift_x, shift_y, idx4, qrow_h, counts + 2);
     hipLaunchKernelGGL(ctab_build_kernel<0>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab, nz_scratch, counts, ph);
-    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, idx4, qrow, counts);
+    hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, rtab, Y, cell_size,
+                       shift_x, shift_y, idx4, qrow, counts);
+    float k1, k2;
+    cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab, n_cells, K8, Y,
+                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, reinterpret_cast<FarRec*>(far));
+    cull_far_consts(ph.c_a, 1.004, &k1, &k2);
+    hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab_h, n_cells, K8, Y,
+                       cell_size, shift_x, shift_y, k1, ph.tau2, reinterpret_cast<FarRec*>(far_h));
     return hipGetLastError();
 }
 
@@ -766,7 +879,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
-                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h);
+                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h, a.far0, a.far1, a.k2_far);
     }
     return hipGetLastError();
 }

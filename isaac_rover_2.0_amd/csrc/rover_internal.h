@@ -73,6 +73,8 @@ struct CullArgs {
     uint64_t queue_entries;      // its size: a step whose regions would not fit is cast in several launches
     int half;                    // the exact phase runs the reference's as-shipped fp16 arithmetic (ctab / qrow are then that proof's tables)
     float c_a_h, tau2_h;         // test constants of that proof (CullProofH)
+    const float4 *far0, *far1;   // [cell][2]: the bound of the cell's far pairs (FarRec, rover_cull.hip) for the proof in force
+    float k2_far;                // and the ray-side constant of the far skip
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
@@ -189,8 +191,10 @@ hipError_t launch_raycast_binned(const RayRec* rays, const uint32_t* sorted, uin
 hipError_t launch_tri_centroids(const int32_t* tris, const uint16_t* verts, uint32_t T, uint32_t V, float2* out, hipStream_t s);
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
-                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float* nz_scratch,
-                             uint32_t* counts, CullProofH ph, hipStream_t s);
+                             int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
+                             float4* far_h, float* nz_scratch, uint32_t* counts, CullProofH ph, uint32_t Y, float cell_size, float shift_x,
+                             float shift_y, hipStream_t s);
+float cull_far_k2(int half, CullProofH ph);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);
