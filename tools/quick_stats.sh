@@ -9,9 +9,9 @@ import csv, glob, json
 f = sorted(glob.glob("/tmp/quick_stats/**/*kernel_stats.csv", recursive=True))[-1]
 tot = 0.0
 for r in csv.DictReader(open(f)):
-    if int(r["Calls"]) < 50 or not r["Name"].startswith("rover::"): continue
+    if int(r["Calls"]) < 50 or "rover::" not in r["Name"]: continue
     us = float(r["AverageNs"]) / 1000; tot += us
-    print(f'{r["Name"].split("(")[0][:44]:46s}{r["Calls"]:>6s}{us:9.1f}')
+    print(f'{r["Name"].split("(")[0].replace("void ", "")[:44]:46s}{r["Calls"]:>6s}{us:9.1f}')
 print("sum", round(tot, 1))
 d = json.loads(open("/tmp/quick_stats/bench.json").read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"])
