@@ -674,10 +674,6 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     if (variant >= 2) p.bin_out = c->d_bins;
     p.precision = c->precision;
     p.cell_rcp = c->cell_rcp;
-    if (variant == 3) {     // the cells' normal cones of the proof in force: prep_rays_kernel leaves the per-ray verdict in the ray record
-        const bool h = c->precision == 2;
-        p.qrow0 = h ? c->cull_qrow_h[0] : c->cull_qrow[0]; p.qrow1 = h ? c->cull_qrow_h[1] : c->cull_qrow[1];
-    }
     HIP_TRY(c, launch_prep(p, s));
     if (variant >= 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,

@@ -389,10 +389,10 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
 // far triangle if  min_t (dist_xy(m_t, C) - k1 sqrt(r2_t))  >  e_max + k2 hmax  with k1 = 1 / (0.9 sqrt(c_a)), k2 = sqrt(dd - c_a) k1 and
 // cos(beta) >= 0.9.  The record holds the left side G (-inf if a far triangle is always a candidate, +inf if slot 1 is empty), the z
 // range of the far centres, the largest dist_xy(m_t, C) and C.
-struct FarRec { float G, z0, z1, rho_out, cx, cy, pad0, pad1; };
+struct FarRec { float G, z0, z1, rho_out, cx, cy; uint32_t q16, pad1; };    // q16: the cell's normal cone (qrow), here so that the scan's prologue needs one gather
 __global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__ idx4, const uint4* __restrict__ ctab, uint64_t n_cells, uint32_t K8,
                                                         uint32_t Y, float cell_size, float shift_x, float shift_y, float k1, float tau2,
-                                                        FarRec* __restrict__ out) {
+                                                        const uint32_t* __restrict__ qrow, FarRec* __restrict__ out) {
     const uint64_t cell = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u, L = K8 >> 2;
     if (cell >= n_cells) return;
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__
     for (int off = 32; off > 0; off >>= 1) {
         G = fminf(G, __shfl_xor(G, off)); z0 = fminf(z0, __shfl_xor(z0, off)); z1 = fmaxf(z1, __shfl_xor(z1, off)); ro = fmaxf(ro, __shfl_xor(ro, off));
     }
-    if (lane == 0u) out[cell] = FarRec{G, z0, z1, ro, ccx, ccy, 0.0f, 0.0f};
+    if (lane == 0u) out[cell] = FarRec{G, z0, z1, ro, ccx, ccy, qrow[cell], 0u};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -620,10 +620,6 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid_s)[0], rsb = reinterpret_cast<const float4*>(rays + gid_s)[1];
     const uint32_t rflags = __float_as_uint(rsb.w);
     const uint32_t key = __float_as_uint(rsa.w) | (rflags << 31);                      // cell | map << 31
-    // bit i: the normal cone of ray i's cell covers the ray (prep_rays_kernel decided, flags bit 2): test (B) holds for every
-    // triangle of the cell, the scan runs test (A) only
-    const uint64_t conemask = __builtin_amdgcn_ballot_w64((rflags & 4u) != 0u);
-    if (r_next == 0u) n_both += (uint32_t)__builtin_popcountll(~conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
     const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
     // bit i: ray i starts a new (map, cell) bin
     const uint64_t heads = __builtin_amdgcn_ballot_w64(lane < n_run && (lane == 0u || key != prev));
@@ -634,10 +630,18 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const uint32_t rowm = (kcell * (((kmap ? kp01 >> 16 : kp01) & 0xffffu) >> 2) * 16u) | kmap;
     // bit i: ray i clears every FAR triangle of its cell (slot 1 of every lane) at once — far_build_kernel has the derivation —
     // so on the cone path its scan skips slot 1 altogether; each lane decides for its own ray
-    uint64_t farskip = 0;          // (f32 proof only: with the fp16 proof's c_a the bound rarely holds, and its kernel has no registers to spare)
+    // The cell's record (far_build_kernel): the bound of its far pairs and its normal cone, ONE gather per lane.
+    // conemask bit i: the cone of ray i's cell covers the ray (the ray's own bound: flags bits 16..31) — test (B) holds for every triangle
+    // of the cell, the scan runs test (A) only.  farskip bit i: ray i clears every FAR triangle of its cell (slot 1 of every lane) at
+    // once, so on the cone path its scan skips slot 1 altogether (f32 proof only: with the fp16 proof's c_a the bound rarely holds,
+    // and its kernel has no registers to spare).
+    const float4* fr = (kmap ? far1 : far0) + 2ull * kcell;
+    const float4 fb = fr[1];                                                  // {Cx, Cy, q16, -}
+    const uint64_t conemask = __builtin_amdgcn_ballot_w64(__float_as_uint(fb.z) >= (rflags >> 16));
+    if (r_next == 0u) n_both += (uint32_t)__builtin_popcountll(~conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
+    uint64_t farskip = 0;
     if (!H) {
-        const float4* fr = (kmap ? far1 : far0) + 2ull * kcell;
-        const float4 fa = fr[0], fb = fr[1];                                  // {G, z0, z1, rho_out}, {Cx, Cy, -, -}
+        const float4 fa = fr[0];                                              // {G, z0, z1, rho_out}
         // (hardware square roots, 1 ulp, and no division — the inequality is multiplied through by |d_z| — the margins are 1e-4)
         const float ox = rsa.x - fb.x, oy = rsa.y - fb.y, o = __builtin_amdgcn_sqrtf(ox * ox + oy * oy);
         const float dzm = fmaxf(fabsf(rsa.z - fa.y), fabsf(rsa.z - fa.z));
@@ -825,10 +829,10 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
     float k1, k2;
     cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab, n_cells, K8, Y,
-                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, reinterpret_cast<FarRec*>(far));
+                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, qrow, reinterpret_cast<FarRec*>(far));
     cull_far_consts(ph.c_a, 1.004, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab_h, n_cells, K8, Y,
-                       cell_size, shift_x, shift_y, k1, ph.tau2, reinterpret_cast<FarRec*>(far_h));
+                       cell_size, shift_x, shift_y, k1, ph.tau2, qrow_h, reinterpret_cast<FarRec*>(far_h));
     return hipGetLastError();
 }
 

@@ -10,8 +10,7 @@ struct RayRec {
     float sx, sy, sz;    // origin
     uint32_t cell;       // ix * Y + iy into the map the flags select
     float dx, dy, dz;    // -normalize(direction), ray_casting.py:31
-    uint32_t flags;      // bit0: rocks map, bit1: valid, bit2: the cell's normal cone covers the ray (culled ray cast: test (A) only);
-                         // bits 16..31: the ray's normal-cone bound (rover_cull.hip), 0xffff = none
+    uint32_t flags;      // bit0: rocks map, bit1: valid; bits 16..31: the ray's normal-cone bound (rover_cull.hip), 0xffff = none
 };
 static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
 
@@ -51,7 +50,7 @@ struct PrepArgs {
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
     int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
-    const uint32_t *qrow0, *qrow1; // optional [cell]: the normal cone of every cell of the terrain / rocks map (culled ray cast)
+
 };
 
 // constants of the culled ray cast's rejection proof for the as-shipped fp16 arithmetic, derived from its one free parameter eta

@@ -297,9 +297,7 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
         rec.cell = ix * (uint32_t)m->Y + iy;
         bin = ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell;
-        // culled ray cast: does the cell's normal cone cover this ray?  (then its scan runs test (A) only on the cell's triangles)
-        const uint32_t* qr = (rec.flags & 1u) ? a.qrow1 : a.qrow0;
-        if (qr && qr[rec.cell] >= (rec.flags >> 16)) rec.flags |= 4u;
+
     }
     if (a.bin_out && live) a.bin_out[gid] = bin;              // key of the bucket sort; 0xffffffff for padding slots
     // The wave's 64 records are 2 KB in a row: transposed through LDS, each of the two stores writes 1 KB contiguously
