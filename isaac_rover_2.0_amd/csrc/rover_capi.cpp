@@ -174,9 +174,9 @@ static int effective_variant(const rover_ctx* c) {
 static uint32_t effective_run(const rover_ctx* c) {
     if (c->run) return c->run;
     const uint64_t r = valid_rays(c) / 65536u;
-    // the culled ray cast: one workgroup of the exact kernel per run, so short runs only add launches
-    // (65 536 envs: 16 -> 0.874 ms, 32 -> 0.807, 64 -> 0.801; 4 096 envs: 4 -> 0.115, 16 -> 0.100, 32 -> 0.102)
-    if (effective_variant(c) == 3) return r < 24 ? 16u : (r < 48 ? 32u : 64u);        // powers of two: 63 instead of 64 cost 6 %
+    // the culled ray cast (round 3, one call each: 4 096 envs run 4 / 8 / 16 / 32 -> 0.155 / 0.151 / 0.161 / 0.173 ms per step;
+    // 8 192 envs 0.246 / 0.227 / 0.236 / 0.249; 16 384 envs 0.407 / 0.335 / 0.331 / 0.343): small batches want many short-lived waves
+    if (effective_variant(c) == 3) return r < 12 ? 8u : (r < 24 ? 16u : (r < 48 ? 32u : 64u));        // powers of two: 63 instead of 64 cost 6 %
     return (uint32_t)(r < 4 ? 4 : (r > 32 ? 32 : r));
 }
 
