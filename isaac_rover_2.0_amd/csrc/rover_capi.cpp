@@ -82,6 +82,8 @@ struct rover_ctx {
     uint32_t run = 0;                   // option "raycast_run": 0 = auto (effective_run)
     uint32_t early_out = 1;             // option "raycast_early_out": conservative whole-pair rejection (bit-identical results)
     int32_t cell_rcp = 0;               // option "cell_index_mode": 0 cpu_div (x / 0.1), 1 cuda_rcp (x * (1 / 0.1))
+    float* d_mlp_scratch = nullptr;     // partial sums of the split-k small-batch encoder path (rover_mlp_chain_forward)
+    size_t mlp_scratch_floats = 0;
     uint64_t workspace_bytes = 0;
     bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
     bool rays_valid = false;
@@ -390,7 +392,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
-    dfree(c->d_cull_queue); dfree(c->d_cull_stats);
+    dfree(c->d_cull_queue); dfree(c->d_cull_stats); dfree(c->d_mlp_scratch);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -1120,6 +1122,20 @@ int rover_mlp_chain_forward(rover_ctx* c, const float* x, int64_t x_stride, int3
     if (y_stride < a.n[n_layers - 1]) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: y_stride %lld < width %d", (long long)y_stride, a.n[n_layers - 1]);
     if (M == 0) return ROVER_OK;
     USE_DEVICE(c);
+    if (chain_wants_splitk(a)) {
+        // small batches: first layer split along k through a scratch buffer (grown here when a larger batch comes: not inside a
+        // stream capture — size the first call before capturing)
+        const size_t need = chain_splitk_scratch_floats(a.M, a.K0, a.n[0]);
+        if (need > c->mlp_scratch_floats) {
+            HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));          // kernels still reading the old buffer
+            dfree(c->d_mlp_scratch);
+            c->mlp_scratch_floats = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->d_mlp_scratch, need * sizeof(float)));
+            c->mlp_scratch_floats = need;
+        }
+        HIP_TRY(c, launch_chain_splitk(a, c->d_mlp_scratch, (hipStream_t)stream));
+        return ROVER_OK;
+    }
     hipError_t e = launch_chain(a, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: net outside the built tile shapes (<= 96 -> <= 64, or <= 256 -> <= 160 -> <= 128 -> <= 16 with hidden activations none / LeakyReLU / ReLU)");
     HIP_TRY(c, e);

@@ -176,6 +176,10 @@ struct ChainArgs {
     float* y; int64_t y_stride;            // [M, n_last] rows at y_stride floats
 };
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
+// small batches: a 2-layer chain with its first layer split along k (rover_mlp.hip); scratch holds chain_splitk_scratch_floats() floats
+bool chain_wants_splitk(const ChainArgs& a);
+size_t chain_splitk_scratch_floats(int M, int K0, int n0);
+hipError_t launch_chain_splitk(const ChainArgs& a, float* scratch, hipStream_t s);
 
 hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                          uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s);

@@ -394,17 +394,224 @@ __global__ void __launch_bounds__(512, 4) chain16_kernel(ChainArgs a) {       //
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small batches (round 3): a 2-layer chain (an Encoder, learning/model.py:122-150) with its first layer SPLIT ALONG K.
+// Below ~16 k rows the chain kernel above is latency-bound, not throughput-bound: M / 128 workgroups each walk the whole k range of
+// layer 1 (35 slabs of 32 for the 1 112-wide dense slice, ~1.3 us each) one after the other — 0.16-0.18 ms for the actor forward from
+// 512 to 8 192 rows alike.  Here one wave takes 16 rows and ONE chunk of the k range (grid = row tiles x S chunks, every SIMD of the
+// chip busy from a few thousand rows on) and streams both MFMA operands straight from memory in the transposed product's own layout
+// (lane (m, g) needs 16 contiguous bytes of x row m and of weight row 16 t + m per 16 k: no LDS, no barrier); the partial sums go to a
+// scratch [S][M][TN * 16], and a second small kernel adds them in a fixed order (deterministic), applies bias + activation and runs
+// the narrow second layer with plain FMAs.
+// ---------------------------------------------------------------------------------------------------
+template <int TN, int RT>                  // RT row tiles of 16 rows per wave: a weight operand, once loaded, multiplies RT x operands
+__global__ void __launch_bounds__(64) splitk_layer1_kernel(const float* __restrict__ x, int64_t x_stride, int M, int K, const float* __restrict__ w,
+                                                           int N, int chunk /* multiple of 16 */, float* __restrict__ part) {
+    const uint32_t lane = threadIdx.x, m = lane & 15u, g = lane >> 4;
+    const uint32_t sidx = blockIdx.y;
+    const uint32_t k_lo = sidx * (uint32_t)chunk, k_hi = min((uint32_t)K, k_lo + (uint32_t)chunk);
+    f32x4 acc[RT][TN];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) c16_zero(acc[q]);
+    auto load4 = [&](const float* __restrict__ p, uint32_t k, bool ok) {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (ok) {
+            if (k + 4u <= k_hi) v = *reinterpret_cast<const f32x4u*>(p + k);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (k + e < k_hi) v[e] = p[k + e];
+            }
+        }
+        return v;
+    };
+    uint32_t row[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) row[q] = (blockIdx.x * RT + q) * 16u + m;
+    // four 16-k steps per trip: all their loads (4 x (RT + TN) x 16 bytes per lane) are issued before the first MFMA — a wave has
+    // only ~5 steps to do and nothing else to hide a round trip per step behind (1-2 waves per SIMD: registers are free)
+    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += 64u) {
+        f32x4 xb[4][RT], wa[4][TN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + 16u * u + 4u * g;
+#pragma unroll
+            for (int q = 0; q < RT; ++q) xb[u][q] = load4(x + (size_t)row[q] * x_stride, k, row[q] < (uint32_t)M && k < k_hi);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const uint32_t n = 16u * t + m;
+                wa[u][t] = load4(w + (size_t)n * K, k, n < (uint32_t)N && k < k_hi);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int q = 0; q < RT; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u][t][j], xb[u][q][j], acc[q][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        if (row[q] >= (uint32_t)M) continue;
+        float* __restrict__ o = part + ((size_t)sidx * M + row[q]) * (TN * 16u);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) *reinterpret_cast<f32x4*>(o + 16u * t + 4u * g) = acc[q][t];
+    }
+}
+
+// 16 rows per workgroup: h = act1(sum_s part[s] + b1) and W2 (transposed) in LDS, then y = act2(W2 h + b2): thread (o = tid % 64,
+// q = tid / 64) computes output o of rows q, q + 4, q + 8, q + 12 — W2 reads of a wave are consecutive words, h reads broadcasts
+template <int TN>
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restrict__ part, int S, int M, const float* __restrict__ b1, int n1,
+                                                            int act1, const float* __restrict__ w2, const float* __restrict__ b2, int n2,
+                                                            int act2, float* __restrict__ y, int64_t y_stride) {
+    constexpr uint32_t NP = TN * 16u;
+    __shared__ float h[16][NP + 1];
+    __shared__ float w2s[NP][65];                                    // [k][o], n2 <= 64
+    const uint32_t row0 = blockIdx.x * 16u, tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)n2 * (uint32_t)n1; i += 256u) w2s[i % (uint32_t)n1][i / (uint32_t)n1] = w2[i];
+    for (uint32_t i = tid; i < 16u * NP; i += 256u) {
+        const uint32_t r = i / NP, n = i % NP, row = row0 + r;
+        float v = 0.0f;
+        if (row < (uint32_t)M && n < (uint32_t)n1) {
+            float p[16];                                             // S <= 16: all partial loads in flight, then a fixed summation order
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) p[sidx] = sidx < S ? part[((size_t)sidx * M + row) * NP + n] : 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) v += p[sidx];
+            v = mlp_act(v + (b1 ? b1[n] : 0.0f), act1);
+        }
+        h[r][n] = v;
+    }
+    __syncthreads();
+    const uint32_t o = tid & 63u, q = tid >> 6;
+    if (o >= (uint32_t)n2) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < n1; ++k) {
+        const float wv = w2s[k][o];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wv, h[q + 4u * j][k], acc[j]);
+    }
+    const float bo = b2 ? b2[o] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t row = row0 + q + 4u * j;
+        if (row < (uint32_t)M) y[(size_t)row * y_stride + o] = mlp_act(acc[j] + bo, act2);
+    }
+}
+
+// chunks of the k range so that (row tiles / RT) x chunks ~ one wave per SIMD of the chip (1 024), at least 64 k per chunk
+static int splitk_chunks(int M, int K, int* chunk, int* rt) {
+    *rt = M >= 2048 ? 2 : 1;
+    const int tiles = (M + 16 * *rt - 1) / (16 * *rt);
+    int S = (1024 + tiles - 1) / tiles;
+    const int s_max = (K + 63) / 64;
+    if (S > s_max) S = s_max;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    const int c = ((K + S - 1) / S + 15) / 16 * 16;
+    *chunk = c;
+    return (K + c - 1) / c;
+}
+size_t chain_splitk_scratch_floats(int M, int K0, int n0) {
+    int chunk, rt;
+    const int S = splitk_chunks(M, K0, &chunk, &rt);
+    return (size_t)S * (size_t)M * (size_t)(n0 <= 80 ? 80 : 96);
+}
+// (the same nets at every batch size: what the large-batch 2-layer kernel is built for, <= 96 -> <= 64)
+bool chain_wants_splitk(const ChainArgs& a) { return a.n_layers == 2 && a.M < 16384 && a.K0 >= 128 && a.n[0] <= 96 && a.n[1] <= 64; }
+
+template <int TN>
+static void launch_splitk_tn(const ChainArgs& a, float* scratch, hipStream_t s) {
+    int chunk, rt;
+    const int S = splitk_chunks(a.M, a.K0, &chunk, &rt);
+    const dim3 g1((uint32_t)((a.M + 16 * rt - 1) / (16 * rt)), (uint32_t)S), g2((uint32_t)((a.M + 15) / 16));
+    if (rt == 2) hipLaunchKernelGGL((splitk_layer1_kernel<TN, 2>), g1, dim3(64), 0, s, a.x, a.x_stride, a.M, a.K0, a.w[0], a.n[0], chunk, scratch);
+    else hipLaunchKernelGGL((splitk_layer1_kernel<TN, 1>), g1, dim3(64), 0, s, a.x, a.x_stride, a.M, a.K0, a.w[0], a.n[0], chunk, scratch);
+    hipLaunchKernelGGL((splitk_finish_kernel<TN>), g2, dim3(256), 0, s, scratch, S, a.M, a.b[0], a.n[0], a.act[0], a.w[1], a.b[1], a.n[1],
+                       a.act[1], a.y, a.y_stride);
+}
+hipError_t launch_chain_splitk(const ChainArgs& a, float* scratch, hipStream_t s) {
+    if (a.n[0] <= 80) launch_splitk_tn<5>(a, scratch, s); else launch_splitk_tn<6>(a, scratch, s);
+    return hipGetLastError();
+}
+
+// Small batches, the MLP with its head (124 -> 256 -> 160 -> 128 -> 2): 16 rows per workgroup, its EIGHT waves split every layer's
+// OUTPUT tiles between them and hand the activations on through LDS (16 rows x <= 256 floats, ping-pong).  No weight staging and no
+// barrier inside a layer: a wave streams the weight rows of its own tiles from L2 in the MFMA's operand layout, the x operand is one
+// ds_read_b128 per 16 k.  chain16_kernel walks ~42 barrier-synchronised slab steps per 128 rows (67 us whatever the batch); here a
+// layer is <= 2 tiles x 16 steps per wave (25 us at 512 rows, 30 us at 4 096).
+#define MS_PITCH 260
+__global__ void __launch_bounds__(512) mlp_small_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float buf[2][16][MS_PITCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, m = lane & 15u, g = lane >> 4;
+    const uint32_t row0 = blockIdx.x * 16u;
+    // the 16 input rows, zero-padded to a multiple of 16 columns
+    const uint32_t kp0 = ((uint32_t)a.K0 + 15u) & ~15u;
+    for (uint32_t i = tid; i < 16u * kp0; i += 512u) {
+        const uint32_t r = i / kp0, k = i % kp0, row = row0 + r;
+        buf[0][r][k] = (row < (uint32_t)a.M && k < (uint32_t)a.K0) ? a.x[(size_t)row * a.x_stride + k] : 0.0f;
+    }
+    __syncthreads();
+    uint32_t cur = 0, K = (uint32_t)a.K0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        const uint32_t N = (uint32_t)a.n[l], n_tiles = (N + 15u) >> 4, kp = (K + 15u) & ~15u;
+        const float* __restrict__ w = a.w[l];
+        const bool last = l == a.n_layers - 1;
+        for (uint32_t t = wave; t < n_tiles; t += 8u) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const uint32_t n = 16u * t + m;                          // the weight row this lane supplies
+            const float* __restrict__ wr = w + (size_t)n * K;
+            for (uint32_t k0 = 0; k0 < kp; k0 += 16u) {
+                const uint32_t k = k0 + 4u * g;
+                f32x4 wa = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (n < N) {
+                    if (k + 4u <= K) wa = *reinterpret_cast<const f32x4u*>(wr + k);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (k + e < K) wa[e] = wr[k + e];
+                    }
+                }
+                const f32x4 xb = *reinterpret_cast<const f32x4*>(&buf[cur][m][k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[j], acc, 0, 0, 0);
+            }
+            // lane (m, g) holds features 16 t + 4 g + r of batch row m; features past N are written as zeros: they are the padding
+            // columns the next layer's 16-wide k steps read
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t f = 16u * t + 4u * g + (uint32_t)r;
+                const float v = f < N ? mlp_act(acc[r] + (a.b[l] ? a.b[l][f] : 0.0f), a.act[l]) : 0.0f;
+                if (last) { if (f < N && row0 + m < (uint32_t)a.M) a.y[(size_t)(row0 + m) * a.y_stride + f] = v; }
+                else buf[cur ^ 1u][m][f] = v;
+            }
+        }
+        if (!last) {
+            __syncthreads();
+            cur ^= 1u;
+            K = N;
+        }
+    }
+}
+
 // tile shapes instantiated: the reference's encoder (<= 80 -> <= 64, or <= 96 -> <= 64) and MLP (<= 256 -> <= 160 -> <= 128 -> <= 16,
 // hidden activations none / LeakyReLU / ReLU); anything else: hipErrorInvalidValue (the caller runs layer by layer)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
-    const dim3 grid((uint32_t)((a.M + 127) / 128));
     auto cheap = [](int act) { return act == 0 || act == 1 || act == 3; };
+    // (the same nets at every batch size: what the large-batch kernel is built for)
+    const bool mlp4 = a.n_layers == 4 && a.n[0] <= 256 && a.n[1] <= 160 && a.n[2] <= 128 && a.n[3] <= 16 && cheap(a.act[0]) && cheap(a.act[1]) &&
+                      cheap(a.act[2]);
+    if (mlp4 && a.M < 16384 && a.K0 <= 256) {
+        hipLaunchKernelGGL(mlp_small_kernel, dim3((uint32_t)((a.M + 15) / 16)), dim3(512), 0, s, a);      // small batches: latency, not throughput
+        return hipGetLastError();
+    }
+    const dim3 grid((uint32_t)((a.M + 127) / 128));
     if (a.n_layers == 2 && a.n[0] <= 80 && a.n[1] <= 64) {
         hipLaunchKernelGGL((chain16_kernel<5, 4, 0, 0>), grid, dim3(512), 0, s, a);
     } else if (a.n_layers == 2 && a.n[0] <= 96 && a.n[1] <= 64) {
         hipLaunchKernelGGL((chain16_kernel<6, 4, 0, 0>), grid, dim3(512), 0, s, a);
-    } else if (a.n_layers == 4 && a.n[0] <= 256 && a.n[1] <= 160 && a.n[2] <= 128 && a.n[3] <= 16 && cheap(a.act[0]) && cheap(a.act[1]) &&
-               cheap(a.act[2])) {
+    } else if (mlp4) {
         hipLaunchKernelGGL((chain16_kernel<16, 10, 8, 1>), grid, dim3(512), 0, s, a);
     } else {
         return hipErrorInvalidValue;

@@ -70,7 +70,7 @@ class HeightmapNet:
         cat = self._buf("cat", e, p + 2 * ef)
         cat[:, 0:p] = states[:, 0:p]
         if fused is None:
-            fused = e >= 16384
+            fused = True          # encoders: one fused kernel from 16 384 rows, a split-k pair below (the library decides); MLP + head: one kernel
         for enc, lo, n, col in ((self.encoder0, p, ns, p), (self.encoder1, p + ns, nd, p + ef)):
             x = states[:, lo:lo + n]
             if fused and n > 0 and self.engine.chain_fits(enc):
