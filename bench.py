@@ -550,6 +550,9 @@ def run_rank(args):
         alt = {"mode": "overlapped" if not overlap else "sync_gather", "value": E_global * args.steps / e2,
                "ms_per_step": 1e3 * e2 / args.steps, "gather_check": ok2, "per_rank": pr2}
     eng.set_profiling(False)
+    # the kernel the line reports is the kernel that ran: the library has no silent change of ray-cast variant, and this guards it
+    if eng.info().raycast_variant != info.raycast_variant:
+        raise SystemExit(f"bench.py: ray-cast variant changed during the run ({info.raycast_variant} -> {eng.info().raycast_variant})")
 
     rc = 0
     if rank == 0:
