@@ -557,7 +557,9 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
         uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
         const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h, const float4 *__restrict__ far0, const float4 *__restrict__ far1, float k2_far
 
-template <int H>
+// LAZY: the far pairs of a bin (slot 1) are gathered and unpacked only if one of its rays tests them — a second, dependent round of
+// gathers in the bins that do, half the set-up in the bins that do not (most of them when a bin holds few rays).
+template <int H, int LAZY>
 __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float k_ca = H ? c_a_h : CullK<0>::c_a, k_tau2 = H ? tau2_h : CullK<0>::tau2;      // (f32 proof: compile-time constants)
     // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
@@ -690,13 +692,20 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         ++use_n;
         const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
         const uint4* ct = map ? ctab1 : ctab0;
+        // does any ray of this bin test the FAR pairs (slot 1)?  (off the cone path always, on it unless its far-skip bit is set)
+        const uint64_t binmask = (i_end >= 64u ? ~0ull : ((1ull << i_end) - 1ull)) & (~0ull << i);
+        const bool need1 = !LAZY || (~(farskip & conemask) & binmask) != 0ull;
         uint4 rec[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) rec[jj] = ct[id[jj] < 0 ? 0 : id[jj]];
+        for (int jj = 0; jj < (LAZY ? 2 : 4); ++jj) rec[jj] = ct[id[jj] < 0 ? 0 : id[jj]];
         CullRegs t;
         uint32_t qid[2][2];                    // the lane's ids as queue-entry fields
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            if (LAZY && p == 1) {
+                if (!need1) break;                                  // (nothing below reads slot 1 then: every ray of the bin skips it)
+                rec[2] = ct[id[2] < 0 ? 0 : id[2]]; rec[3] = ct[id[3] < 0 ? 0 : id[3]];
+            }
             const uint4 a = rec[2 * p], b = rec[2 * p + 1];
             const f2 za = cvt2(a.z), zb = cvt2(b.z), wa = cvt2(a.w), wb = cvt2(b.w);
             t.mx[p] = f2{__uint_as_float(a.x), __uint_as_float(b.x)};
@@ -879,7 +888,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     // of the slot list, one launch each on the same stream, re-using the regions
     for (uint32_t j0 = 0; j0 < slots; j0 += per) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
-        auto kern = a.half ? cull_scan_kernel<1> : cull_scan_kernel<0>;
+        auto kern = a.half ? cull_scan_kernel<1, 0> : (a.lazy_far ? cull_scan_kernel<0, 1> : cull_scan_kernel<0, 0>);
         hipLaunchKernelGGL(kern, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,

@@ -74,6 +74,7 @@ struct CullArgs {
     float c_a_h, tau2_h;         // test constants of that proof (CullProofH)
     const float4 *far0, *far1;   // [cell][2]: the bound of the cell's far pairs (FarRec, rover_cull.hip) for the proof in force
     float k2_far;                // and the ray-side constant of the far skip
+    int lazy_far;                // set up a bin's far pairs only when one of its rays tests them (few rays per bin)
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
