@@ -371,6 +371,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
+    if (const char* v = getenv("ROVER_BIN_LOW_BITS")) { int b = atoi(v); if (b >= 8 && b <= 12) c->low_bits = (uint32_t)b; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     DeviceGuard guard(cfg->device);
     e = guard.err;

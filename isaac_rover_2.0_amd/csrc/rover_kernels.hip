@@ -13,7 +13,7 @@
 //
 // Kernels (one step = the ten launches marked *):
 //   repack_knn_kernel        init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8], near/far halves per lane
-// * prep_env_kernel          1 thread / env: quat -> euler, heading, every sin/cos of the pose and joint chain
+// * prep_env_kernel          1 thread / (env, part): quat -> euler, heading, every sin/cos of the pose and joint chain
 // * prep_rays_kernel         1 thread / (env, ray slot): ray origin, unit direction, cell id, bin key               (A4, A6)
 // * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell) without global atomics
 // * raycast_binned_kernel    1 wave / run of sorted rays, 4 triangles per lane in registers, conservative early out  (A4, A5) <- roofline kernel
@@ -164,40 +164,42 @@ __constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
 //   chunk 1, 2     sin/cos of -roll, -pitch | -yaw, 0, 0 (Trig6)
 //   chunk 3 + 2w   wheel w: sin/cos(-steer), sin/cos(susX)       chunk 4 + 2w: sin/cos(susY), 0, 0   (rock_detect.py:248-272)
 #define ENV_CHUNKS 15
-// One thread per env; loads first, stores last (the compiler may not move a load above a store it cannot prove disjoint).
+// One thread per (env, part): part 0 (blockIdx.y) the pose — quaternion -> euler, heading, the body trig — parts 1..3 two wheels each.
+// (One thread per env did all ~36 sin / cos / atan2 calls in a row with a single wave on each SIMD: 10.4 us, nearly all of it
+//  dependent arithmetic; as four waves of a third of the work each the same instructions overlap.)  Loads first, stores last
+// (the compiler may not move a load above a store it cannot prove disjoint).
 __global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.E) return;
     float4* r = reinterpret_cast<float4*>(a.env_rec) + e;      // chunk k of this env: r[k * E]
     const size_t E = a.E;
-    const float q[4] = {a.quat[4ull * e], a.quat[4ull * e + 1], a.quat[4ull * e + 2], a.quat[4ull * e + 3]};
-    const float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
+    if (blockIdx.y == 0u) {
+        const float q[4] = {a.quat[4ull * e], a.quat[4ull * e + 1], a.quat[4ull * e + 2], a.quat[4ull * e + 3]};
+        const float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
+        float roll, pitch, yaw;
+        quat_to_euler(q, roll, pitch, yaw);
+        float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
+        float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
+        Trig6 t = euler_trig(roll, pitch, yaw);
+        a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
+        a.heading[e] = hd;
+        r[0] = make_float4(roll, pitch, yaw, hd);
+        r[1 * E] = make_float4(t.sx, t.cx, t.sy, t.cy);
+        r[2 * E] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
+        return;
+    }
     const float* j = a.joints + 13ull * e;
     const float j0 = j[0], j1 = j[1], j2 = j[2], j4 = j[4], j6 = j[6], j7 = j[7], j8 = j[8];
-    float roll, pitch, yaw;
-    quat_to_euler(q, roll, pitch, yaw);
-    float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
-    float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
-    Trig6 t = euler_trig(roll, pitch, yaw);
-    float o[36];
 #pragma unroll
     for (int w = 0; w < 6; ++w) {
+        if ((uint32_t)(w >> 1) + 1u != blockIdx.y) continue;
         float steer = (w == 0) ? j4 : (w == 1) ? j6 : (w == 4) ? -j7 : (w == 5) ? j8 : 0.0f;            // :248
         float susY = (w == 0 || w == 2) ? -j0 : (w == 1 || w == 3) ? j1 : 0.0f;                          // :263
         float susX = (w >= 4) ? -j2 : 0.0f;                                                              // :264
-        o[6 * w + 0] = sinf(-steer); o[6 * w + 1] = cosf(-steer);
-        o[6 * w + 2] = sinf(susX);   o[6 * w + 3] = cosf(susX);
-        o[6 * w + 4] = sinf(susY);   o[6 * w + 5] = cosf(susY);
-    }
-    a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
-    a.heading[e] = hd;
-    r[0] = make_float4(roll, pitch, yaw, hd);
-    r[1 * E] = make_float4(t.sx, t.cx, t.sy, t.cy);
-    r[2 * E] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
-#pragma unroll
-    for (int w = 0; w < 6; ++w) {
-        r[(3 + 2 * w) * E] = make_float4(o[6 * w], o[6 * w + 1], o[6 * w + 2], o[6 * w + 3]);
-        r[(4 + 2 * w) * E] = make_float4(o[6 * w + 4], o[6 * w + 5], 0.0f, 0.0f);
+        const float4 c0 = make_float4(sinf(-steer), cosf(-steer), sinf(susX), cosf(susX));
+        const float4 c1 = make_float4(sinf(susY), cosf(susY), 0.0f, 0.0f);
+        r[(3 + 2 * w) * E] = c0;
+        r[(4 + 2 * w) * E] = c1;
     }
 }
 
@@ -1022,6 +1024,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __rest
 #define BKT_ITEMS 16
 #define BKT_TILE (256 * BKT_ITEMS)
 #define BKT_MAX 4096            // max coarse buckets, and max 2^low_bits
+#define BKT_STAGE 8192u         // entries of a bucket that bucket_sort_kernel orders in LDS before writing them out
 
 __global__ void __launch_bounds__(256) bucket_hist_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
                                                           uint32_t n_buckets, uint32_t n_blocks, uint32_t* __restrict__ counts) {
@@ -1086,16 +1089,52 @@ __global__ void __launch_bounds__(64 * RSCAN_WAVES) bucket_rowscan_kernel(uint32
     if (w == 0 && ph == 0u && kin) bucket_tot[k] = carry;
 }
 
-// every block turns the bucket totals into bucket start offsets in LDS (n_buckets <= 4096: 16 values per thread);
-// block 0 also publishes them (plus the grand total) for bucket_sort_kernel
+// PACKED: an entry is one dword, low bin bits << (32 - low_bits) | slot — all bucket_sort_kernel reads of a pair — when the slot
+// ids leave room for them (n_slots <= 2^(32 - low_bits): 65 536 envs x 64 slots with 1 024 bins per bucket just fit); half the
+// scatter's writes and half the sort's reads.  Otherwise (bin, slot) as two dwords.
+template <bool PACKED> struct BktEntry;
+template <> struct BktEntry<false> {
+    typedef uint2 T;
+    static __device__ __forceinline__ T make(uint32_t bin, uint32_t slot, uint32_t) { return make_uint2(bin, slot); }
+    static __device__ __forceinline__ T none() { return make_uint2(0u, 0xffffffffu); }
+    static __device__ __forceinline__ uint32_t lo(T v, uint32_t low_bits) { return v.x & ((1u << low_bits) - 1u); }
+    static __device__ __forceinline__ uint32_t slot(T v, uint32_t) { return v.y; }
+};
+template <> struct BktEntry<true> {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T make(uint32_t bin, uint32_t slot, uint32_t low_bits) { return (bin << (32u - low_bits)) | slot; }
+    static __device__ __forceinline__ T none() { return 0xffffffffu; }
+    static __device__ __forceinline__ uint32_t lo(T v, uint32_t low_bits) { return v >> (32u - low_bits); }
+    static __device__ __forceinline__ uint32_t slot(T v, uint32_t low_bits) { return v & (0xffffffffu >> low_bits); }
+};
+
+// Every block turns the bucket totals into bucket start offsets in LDS (n_buckets <= 4096: 16 values per thread); block 0 also
+// publishes them (plus the grand total) for bucket_sort_kernel.  The block's 4 096 entries are first ordered by bucket in LDS
+// (rank from one LDS atomic per entry, local start from a scan of the block's bucket counts) next to their global positions, then
+// written out in that order: neighbouring lanes then write neighbouring entries of a bucket's run (~6 per bucket and block) and the
+// run leaves as one or two write transactions instead of one per entry.
+template <bool PACKED>
 __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
                                                              uint32_t n_buckets, uint32_t n_blocks, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ bucket_tot, uint32_t* __restrict__ bucket_base,
-                                                             uint2* __restrict__ pairs) {
-    __shared__ uint32_t cur[BKT_MAX];
+                                                             uint2* __restrict__ pairs2) {
+    typedef BktEntry<PACKED> En;
+    typename En::T* __restrict__ pairs = reinterpret_cast<typename En::T*>(pairs2);
+    extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2 n_buckets + BKT_TILE (1 + dwords per entry) dwords
+    uint32_t* const cur = bkt_lds;               // global position of this block's first entry in each bucket
+    uint32_t* const cnt = cur + n_buckets;       // this block's entries per bucket -> their local start
+    uint32_t* const s_dst = cnt + n_buckets;
+    typename En::T* const s_val = reinterpret_cast<typename En::T*>(s_dst + BKT_TILE + (n_buckets & 1u));      // (8-byte aligned)
     __shared__ uint32_t wl[4];
+    const uint32_t per = (n_buckets + 255u) >> 8, first = threadIdx.x * per;
+    const uint32_t base = blockIdx.x * BKT_TILE;
+    uint32_t bv[BKT_ITEMS], rk[BKT_ITEMS];                    // the block's 16 loads per thread go out first: their latency passes
+#pragma unroll                                               // under the bucket-offset scan below
+    for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
+        const uint32_t i = base + it * 256u + threadIdx.x;
+        bv[it] = i < n_slots ? bins[i] : 0xffffffffu;
+    }
     {
-        const uint32_t per = (n_buckets + 255u) >> 8, first = threadIdx.x * per;
         uint32_t sum = 0;
         for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_buckets) ? bucket_tot[first + j] : 0u;
         uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
@@ -1103,6 +1142,7 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
             const uint32_t i = first + j;
             if (i < n_buckets) {
                 cur[i] = run + offsets[(size_t)blockIdx.x * n_buckets + i];
+                cnt[i] = 0u;
                 if (blockIdx.x == 0) bucket_base[i] = run;
                 run += bucket_tot[i];
             }
@@ -1110,25 +1150,42 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
         if (blockIdx.x == 0 && threadIdx.x == 0) bucket_base[n_buckets] = total;
     }
     __syncthreads();
-    const uint32_t base = blockIdx.x * BKT_TILE;
-    uint32_t bv[BKT_ITEMS];                                   // all 16 loads in flight before the first atomic
+#pragma unroll
+    for (uint32_t it = 0; it < BKT_ITEMS; ++it) rk[it] = bv[it] != 0xffffffffu ? atomicAdd(&cnt[bv[it] >> low_bits], 1u) : 0u;
+    __syncthreads();
+    uint32_t n_here;
+    {
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_buckets) ? cnt[first + j] : 0u;
+        uint32_t run = block_exclusive_scan<4>(sum, wl, n_here);
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t i = first + j;
+            if (i < n_buckets) { const uint32_t c = cnt[i]; cnt[i] = run; run += c; }
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
-        const uint32_t i = base + it * 256u + threadIdx.x;
-        bv[it] = i < n_slots ? bins[i] : 0xffffffffu;
+        if (bv[it] != 0xffffffffu) {
+            const uint32_t b = bv[it] >> low_bits, l = cnt[b] + rk[it];
+            s_dst[l] = cur[b] + rk[it];
+            s_val[l] = En::make(bv[it], base + it * 256u + threadIdx.x, low_bits);
+        }
     }
-#pragma unroll
-    for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
-        const uint32_t i = base + it * 256u + threadIdx.x;
-        if (bv[it] != 0xffffffffu) pairs[atomicAdd(&cur[bv[it] >> low_bits], 1u)] = make_uint2(bv[it], i);
-    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_here; k += 256u) pairs[s_dst[k]] = s_val[k];
 }
 
-__global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ bucket_base,
+template <bool PACKED>
+__global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restrict__ pairs2, const uint32_t* __restrict__ bucket_base,
                                                           uint32_t low_bits, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t h[BKT_MAX];
+    typedef BktEntry<PACKED> En;
+    const typename En::T* __restrict__ pairs = reinterpret_cast<const typename En::T*>(pairs2);
+    extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2^low_bits + BKT_STAGE dwords
     __shared__ uint32_t wl[4];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x, nl = 1u << low_bits, mask = nl - 1u;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, nl = 1u << low_bits;
+    uint32_t* const h = bkt_lds;
+    uint32_t* const stage = bkt_lds + nl;
     const uint32_t s0 = bucket_base[b], s1 = bucket_base[b + 1u];
     if (s1 <= s0) return;
     for (uint32_t i = tid; i < nl; i += 256) h[i] = 0;
@@ -1140,13 +1197,13 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
         uint32_t slot[64], br[64];                                   // br = low bin bits | rank << 12
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            uint2 pv[8];
+            typename En::T pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u; pv[j] = k < s1 ? pairs[k] : make_uint2(0u, 0xffffffffu); }
+            for (int j = 0; j < 8; ++j) { const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u; pv[j] = k < s1 ? pairs[k] : En::none(); }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u, lo = pv[j].x & mask;
-                slot[8 * g + j] = pv[j].y;
+                const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u, lo = En::lo(pv[j], low_bits);
+                slot[8 * g + j] = En::slot(pv[j], low_bits);
                 br[8 * g + j] = k < s1 ? (lo | (atomicAdd(&h[lo], 1u) << 12)) : 0u;
             }
         }
@@ -1157,6 +1214,18 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
         uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
         for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
         __syncthreads();
+        // through LDS: a wave's 64 positions are anywhere in the bucket's 24-48 KB of output, 64 partial-line writes per store
+        // instruction (4.1 M L2 write transactions a launch); staged, the bucket leaves in whole lines
+        if (s1 - s0 <= BKT_STAGE) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const uint32_t k = s0 + tid + (uint32_t)i * 256u;
+                if (k < s1) stage[h[br[i] & 0xfffu] + (br[i] >> 12)] = slot[i];
+            }
+            __syncthreads();
+            for (uint32_t k = tid; k < s1 - s0; k += 256u) sorted[s0 + k] = stage[k];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             const uint32_t k = s0 + tid + (uint32_t)i * 256u;
@@ -1166,11 +1235,11 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
     }
     // eight loads in flight per thread before their atomics: the kernel waits on memory 93 % of the time otherwise
     for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
-        uint32_t bx[8];
+        typename En::T bx[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; bx[j] = k < s1 ? pairs[k].x : 0xffffffffu; }
+        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; bx[j] = k < s1 ? pairs[k] : En::none(); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * 256u < s1) atomicAdd(&h[bx[j] & mask], 1u);
+        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * 256u < s1) atomicAdd(&h[En::lo(bx[j], low_bits)], 1u);
     }
     __syncthreads();
     // exclusive scan of h[0..nl): each thread owns nl/256 consecutive entries (nl >= 256)
@@ -1181,11 +1250,12 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restric
     for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
     __syncthreads();
     for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
-        uint2 pv[8];
+        typename En::T pv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; pv[j] = k < s1 ? pairs[k] : make_uint2(0u, 0u); }
+        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; pv[j] = k < s1 ? pairs[k] : En::none(); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * 256u < s1) sorted[s0 + atomicAdd(&h[pv[j].x & mask], 1u)] = pv[j].y;
+        for (int j = 0; j < 8; ++j)
+            if (k0 + (uint32_t)j * 256u < s1) sorted[s0 + atomicAdd(&h[En::lo(pv[j], low_bits)], 1u)] = En::slot(pv[j], low_bits);
     }
 }
 
@@ -1457,7 +1527,7 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
     uint64_t n = (uint64_t)a.E * a.R8;
-    hipLaunchKernelGGL(prep_env_kernel, dim3(blocks_for(a.E, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(prep_env_kernel, dim3(blocks_for(a.E, 256), 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -1482,9 +1552,16 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
     uint32_t* bucket_base = block_sums + BKT_MAX;      // [BKT_MAX + 1]
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table);
     hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(blocks_for(n_buckets, 16)), dim3(64 * RSCAN_WAVES), 0, s, table, n_blocks, n_buckets, bucket_tot);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table,
-                       bucket_tot, bucket_base, pairs);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(256), 0, s, pairs, bucket_base, low_bits, sorted);
+    const uint32_t sort_lds = ((1u << low_bits) + BKT_STAGE) * 4u;
+    if ((uint64_t)n_slots <= (1ull << (32u - low_bits))) {          // slot ids leave room for the low bin bits: one dword per entry
+        hipLaunchKernelGGL(bucket_scatter_kernel<true>, dim3(n_blocks), dim3(256), (2u * n_buckets + 2u * BKT_TILE + 2u) * 4u, s, bins, n_slots,
+                           low_bits, n_buckets, n_blocks, table, bucket_tot, bucket_base, pairs);
+        hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3(n_buckets), dim3(256), sort_lds, s, pairs, bucket_base, low_bits, sorted);
+    } else {
+        hipLaunchKernelGGL(bucket_scatter_kernel<false>, dim3(n_blocks), dim3(256), (2u * n_buckets + 3u * BKT_TILE + 2u) * 4u, s, bins, n_slots,
+                           low_bits, n_buckets, n_blocks, table, bucket_tot, bucket_base, pairs);
+        hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(n_buckets), dim3(256), sort_lds, s, pairs, bucket_base, low_bits, sorted);
+    }
     return hipGetLastError();
 }
 

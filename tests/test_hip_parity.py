@@ -386,6 +386,30 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
         assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
+def test_ray_sort_entry_layouts_agree():
+    """The bucket sort keeps an entry in one dword (low bin bits | slot) while the slot ids leave room, else in two: 20 480
+    envs x 64 slots with 4 096 bins per bucket (bin_low_bits 12) take the two-dword layout, the default the packed one; the
+    sorted kernels' results must equal the env-order kernel's either way."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 20480
+    scene = synth.make_scene(n_cells=96, k=24, n_stones=12)
+    distn = synth.ray_distribution("37")
+    st = synth.make_states(n, 9.6, seed=77)
+    eng = make_engine(scene, distn, n, variant=1)
+    ref = hip_step(eng, st)
+    eng.close()
+    for variant in (3, 2):
+        for low_bits in (None, 12, 8):
+            eng = make_engine(scene, distn, n, variant=variant)
+            if low_bits:
+                eng.set_option("bin_low_bits", low_bits)
+            got = hip_step(eng, st)
+            eng.close()
+            for key in ref:
+                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} bin_low_bits={low_bits}")
+
+
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the culled kernel above (the binned one
     whenever the as-shipped fp16 maths are asked for); K8 > 256 always falls back to the env-order kernel."""
