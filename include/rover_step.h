@@ -309,7 +309,9 @@ typedef struct {
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with
  * hipEvents on the caller's stream (ring of 256 pairs).  rover_get_profile synchronises those events and
- * returns the summed ray-cast time and launch count since the last rover_set_profiling(ctx, 1). */
+ * returns the summed ray-cast time and the number of TIMED launches since the last rover_set_profiling(ctx, n > 0).
+ * enable = n > 1 times every n-th launch only (the first one included): an event pair costs the stream ~12 us around
+ * the kernel it brackets (two 6 us bubbles on MI355X), which a caller timing its own steps may not want in each of them. */
 typedef struct { double raycast_ms; int32_t launches; uint64_t pairs_per_launch; } rover_profile;
 ROVER_API int rover_set_profiling(rover_ctx *ctx, int32_t enable);
 ROVER_API int rover_get_profile(rover_ctx *ctx, rover_profile *out);

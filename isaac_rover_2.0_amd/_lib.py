@@ -448,8 +448,9 @@ class Engine:
     def set_option(self, name, value):
         self._check(self.lib.rover_set_option(self._h, name.encode(), int(value)), "rover_set_option")
 
-    def set_profiling(self, enable=True):
-        self._check(self.lib.rover_set_profiling(self._h, 1 if enable else 0), "rover_set_profiling")
+    def set_profiling(self, enable=True, every=1):
+        """Bracket the ray-cast launch of every `every`-th step with hipEvents (get_profile() sums them)."""
+        self._check(self.lib.rover_set_profiling(self._h, max(1, int(every)) if enable else 0), "rover_set_profiling")
 
     def get_profile(self):
         p = Profile()

@@ -90,6 +90,8 @@ struct rover_ctx {
     bool rays_valid = false;
     // in-situ ray-cast timing (rover_set_profiling)
     bool profiling = false;
+    int32_t prof_every = 1;             // time every prof_every-th ray-cast launch (an event pair costs ~12 us of stream time)
+    int32_t prof_seen = 0;              // launches since profiling was switched on
     std::vector<hipEvent_t> ev0, ev1;
     int32_t prof_launches = 0;
     double prof_ms = 0.0;
@@ -687,7 +689,8 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     if (variant >= 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
                                    c->d_block_sums, c->d_sorted, s));
-    if (c->profiling) {
+    const bool timed = c->profiling && (c->prof_seen++ % c->prof_every) == 0;
+    if (timed) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
     }
@@ -699,7 +702,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     else
         HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
                                   (uint32_t)c->map[1].K8, c->d_dist_out, s));
-    if (c->profiling) {
+    if (timed) {
         HIP_TRY(c, hipEventRecord(c->ev1[c->prof_pending], s));
         ++c->prof_pending;
         ++c->prof_launches;
@@ -1215,7 +1218,7 @@ int rover_set_profiling(rover_ctx* c, int32_t enable) {
     }
     if (c->prof_pending) (void)prof_drain(c);
     c->profiling = enable != 0;
-    if (enable) { c->prof_ms = 0.0; c->prof_launches = 0; }
+    if (enable) { c->prof_ms = 0.0; c->prof_launches = 0; c->prof_seen = 0; c->prof_every = enable > 1 ? enable : 1; }
     return ROVER_OK;
 }
 

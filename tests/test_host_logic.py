@@ -231,7 +231,7 @@ class FakeEngine:
         sout["reset"].copy_(flags)
         sout["done_u8"].copy_(flags)
     def reset_envs(self, *a, **k): pass
-    def set_profiling(self, on): self.steps0 = self.steps
+    def set_profiling(self, on, every=1): self.steps0 = self.steps
     def get_profile(self):
         n = self.steps - self.steps0
         return types.SimpleNamespace(raycast_ms=1.0 * n, launches=n, pairs_per_launch=self.n * 63 * 200)
