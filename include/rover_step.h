@@ -273,7 +273,7 @@ ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_
  *        vectors (captured from the reference on CPU) pin.  1 = cuda_rcp: multiplication by 1.0f / 0.1f = 10.0f, what ATen's
  *        CUDA kernel does ("a * reciprocal(b)" for a CPU-scalar divisor) — the device the reference actually runs on.  The
  *        two differ only for coordinates within an ulp of a .5 tie of the cell grid (tests/test_oracle_golden.py).
- * name = "cull_queue_mb": most MiB the candidate queue of the culled ray cast may take (default 1024).  A wave of a launch owns a
+ * name = "cull_queue_mb": most MiB the candidate queue of the culled ray cast may take (default 1536).  A wave of a launch owns a
  *        region of 1 024 entries (8 KB; a run that finds more finishes them and scans on), so a launch needs 8 KB per run of 64
  *        sorted rays: 712 MB at 65 536 envs x 63 rays.  Past the budget a step's ray cast is cut into several launches that
  *        re-use the regions (each extra launch costs ~25 us); an allocation failure is an error (ROVER_E_NOMEM), never a

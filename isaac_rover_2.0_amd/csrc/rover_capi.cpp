@@ -40,7 +40,7 @@ struct rover_ctx {
     int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
     int64_t cull_always_h[2]{0, 0}, cull_nocone_h[2]{0, 0};
     double cull_eta_h = 0.06;           // free parameter of the fp16 proof (rover_cull.hip, cull_proof_h); ROVER_CULLH_ETA for experiments
-    uint64_t cull_budget = 1ull << 30;  // option "cull_queue_mb": most bytes the queue may take (a step is cast in several launches beyond it)
+    uint64_t cull_budget = 1536ull << 20;  // option "cull_queue_mb": most bytes the queue may take (a step is cast in several launches beyond it)
     uint32_t cull_launches = 1;
     int cull_lazy = -1;                 // ROVER_CULL_LAZY: -1 auto, 0 / 1 force (experiments)
     uint32_t cull_run = 0;              // run length the queue was sized for
