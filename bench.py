@@ -592,7 +592,8 @@ def run_rank(args):
                             "rays_per_bin": ci["rays"] / max(ci["bins"], 1), "max_pairs_per_run": ci["max_pairs_per_run"],
                             "rays_far_skipped": ci["rays_far_skipped"] / max(ci["rays"], 1),
                             "always_candidate_triangles": ci["always_candidate_triangles"], "cells_without_cone": ci["cells_without_cone"],
-                            "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"]}
+                            "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"],
+                            "cells_with_far_bound": ci["cells_with_far_bound"], "far_records_on_demand": bool(ci["far_records_on_demand"])}
         if world > 1:
             line["gather_check"] = ok
             line["per_rank"] = per_rank          # [rank]: ms per step of that rank; ms per step its compute stream waited for a transfer (rank 0 = the root's receive time that was not hidden)

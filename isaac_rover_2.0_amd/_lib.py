@@ -61,7 +61,8 @@ class Info(C.Structure):
 class CullInfo(C.Structure):
     _fields_ = [("triangles", C.c_int64 * 2), ("always_candidate_triangles", C.c_int64 * 2), ("cells_without_cone", C.c_int64 * 2),
                 ("rays", C.c_uint64), ("candidate_pairs", C.c_uint64), ("rays_both_tests", C.c_uint64), ("bins", C.c_uint64),
-                ("max_pairs_per_run", C.c_uint64), ("queue_bytes", C.c_uint64), ("launches_per_step", C.c_uint64), ("rays_far_skipped", C.c_uint64)]
+                ("max_pairs_per_run", C.c_uint64), ("queue_bytes", C.c_uint64), ("launches_per_step", C.c_uint64), ("rays_far_skipped", C.c_uint64),
+                ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64)]
 
 
 class ResetIO(C.Structure):
@@ -274,7 +275,7 @@ class Engine:
         """Diagnostics of the culled ray cast (rover_get_cull_info) as a dict; synchronises the device."""
         i = CullInfo()
         self._check(self.lib.rover_get_cull_info(self._h, C.byref(i)), "rover_get_cull_info")
-        d = {k: (list(getattr(i, k)) if k in ("triangles", "always_candidate_triangles", "cells_without_cone") else int(getattr(i, k)))
+        d = {k: (list(getattr(i, k)) if k in ("triangles", "always_candidate_triangles", "cells_without_cone", "cells_with_far_bound") else int(getattr(i, k)))
              for k, _ in CullInfo._fields_}
         d["pairs_per_ray"] = d["candidate_pairs"] / d["rays"] if d["rays"] else 0.0
         return d

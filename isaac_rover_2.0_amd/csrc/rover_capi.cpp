@@ -39,6 +39,7 @@ struct rover_ctx {
     uint32_t cull_stat_slots = 0;
     int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
     int64_t cull_always_h[2]{0, 0}, cull_nocone_h[2]{0, 0};
+    int64_t cull_farok[2]{0, 0}, cull_cells[2]{0, 0};      // cells whose far bound can hold for a usual ray (far_build_kernel) / cells
     double cull_eta_h = 0.06;           // free parameter of the fp16 proof (rover_cull.hip, cull_proof_h); ROVER_CULLH_ETA for experiments
     uint64_t cull_budget = 1536ull << 20;  // option "cull_queue_mb": most bytes the queue may take (a step is cast in several launches beyond it)
     uint32_t cull_launches = 1;
@@ -442,7 +443,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     float4 *d_far = nullptr, *d_far_h = nullptr;
     float* d_nz = nullptr;
     uint32_t* d_cnt = nullptr;
-    uint32_t h_cnt[4] = {0, 0, 0, 0};
+    uint32_t h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t cull_bytes = 0;
     uint32_t *d_order = nullptr, *d_newid = nullptr;
     if (K8 <= 256 && (uint32_t)T < 0x1ffffffu) {
@@ -473,12 +474,12 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_far, n_cells * 32u)) != hipSuccess || (e = hipMalloc((void**)&d_far_h, n_cells * 32u)) != hipSuccess ||
             (e = hipMalloc((void**)&d_nz, (uint64_t)T_int * sizeof(float))) != hipSuccess ||
-            (e = hipMalloc((void**)&d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&d_cnt, 8 * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_order, (uint64_t)T_int * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_newid, (uint64_t)T * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMemcpy(d_order, order.data(), (uint64_t)T_int * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemset(d_cnt, 0, 4 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMemset(d_cnt, 0, 8 * sizeof(uint32_t))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
                                    d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
                                    shift_x, shift_y, nullptr)) != hipSuccess ||
@@ -492,6 +493,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     dfree(d_nz); dfree(d_cnt); dfree(d_order); dfree(d_newid);
     c->cull_always[which] = h_cnt[0]; c->cull_nocone[which] = h_cnt[1]; c->cull_tris[which] = T;
     c->cull_always_h[which] = h_cnt[2]; c->cull_nocone_h[which] = h_cnt[3];
+    c->cull_farok[which] = h_cnt[4]; c->cull_cells[which] = (int64_t)n_cells;
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
@@ -654,7 +656,11 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     // few rays per (map, cell) bin: most bins have no ray that tests the far pairs, and setting them up lazily halves a bin's set-up
     // (32 768 envs x 63 rays 69.7 -> 76 M env-steps/s, 4 096 envs 26.9 -> 30 M; with 146 rays per env a bin holds 14 rays, nearly every
     // bin needs its far pairs and the second, dependent gather costs 3 %: eager there)
-    a.lazy_far = (c->cull_lazy < 0 ? (26 + c->P < 100) : c->cull_lazy != 0) ? 1 : 0;
+    // The kernel that fetches a bin's far records only when a ray needs them pays where most bins skip them: small ray sets (few rays
+    // per bin) on a terrain map whose cells mostly have a useful far bound (a regular grid: all of them; an irregular mesh with
+    // triangles that span many cells: few — there the second, dependent round of gathers cost 3 %).
+    const bool lazy_auto = 26 + c->P < 100 && 2 * c->cull_farok[0] >= c->cull_cells[0];
+    a.lazy_far = (c->cull_lazy < 0 ? lazy_auto : c->cull_lazy != 0) ? 1 : 0;
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.out = c->d_dist_out;
@@ -956,6 +962,8 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
         out->always_candidate_triangles[w] = c->precision == 2 ? c->cull_always_h[w] : c->cull_always[w];
         out->cells_without_cone[w] = c->precision == 2 ? c->cull_nocone_h[w] : c->cull_nocone[w];
     }
+    for (int w = 0; w < 2; ++w) out->cells_with_far_bound[w] = c->cull_farok[w];
+    out->far_records_on_demand = (c->have_dist && c->have_map[0] && c->precision != 2) ? (uint64_t)cull_args(c, 0).lazy_far : 0;
     out->queue_bytes = c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0;
     out->launches_per_step = c->d_cull_queue ? c->cull_launches : 0;
     if (!c->d_cull_stats || c->last_variant != 3) return ROVER_OK;

@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
 struct FarRec { float G, z0, z1, rho_out, cx, cy; uint32_t q16, pad1; };    // q16: the cell's normal cone (qrow), here so that the scan's prologue needs one gather
 __global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__ idx4, const uint4* __restrict__ ctab, uint64_t n_cells, uint32_t K8,
                                                         uint32_t Y, float cell_size, float shift_x, float shift_y, float k1, float tau2,
-                                                        const uint32_t* __restrict__ qrow, FarRec* __restrict__ out) {
+                                                        const uint32_t* __restrict__ qrow, FarRec* __restrict__ out,
+                                                        uint32_t* __restrict__ n_useful /* cells whose bound can hold for a usual ray, or null */) {
     const uint64_t cell = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u, L = K8 >> 2;
     if (cell >= n_cells) return;
@@ -418,7 +419,13 @@ __global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__
     for (int off = 32; off > 0; off >>= 1) {
         G = fminf(G, __shfl_xor(G, off)); z0 = fminf(z0, __shfl_xor(z0, off)); z1 = fmaxf(z1, __shfl_xor(z1, off)); ro = fmaxf(ro, __shfl_xor(ro, off));
     }
-    if (lane == 0u) out[cell] = FarRec{G, z0, z1, ro, ccx, ccy, qrow[cell], 0u};
+    if (lane == 0u) {
+        out[cell] = FarRec{G, z0, z1, ro, ccx, ccy, qrow[cell], 0u};
+        // A ray's side of the inequality is its line's offset from the cell's centre at the far centres' height — 0.1-0.15 m for a
+        // heightmap ray of a rover on gentle ground — plus k2 hmax: cells with G under 0.2 m hardly ever skip (rover_capi.cpp: cull_args
+        // picks the kernel that fetches the far records with the near ones when most cells are like that)
+        if (n_useful && G >= 0.2f) atomicAdd(n_useful, 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -826,7 +833,7 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
                              int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
                              float4* far_h, float* nz_scratch,
-                             uint32_t* counts /* [4], zeroed: always-candidate triangles, cells without a cone; the same for fp16 */,
+                             uint32_t* counts /* [5], zeroed: always-candidate triangles, cells without a cone; the same for fp16; cells with a useful far bound */,
                              CullProofH ph, uint32_t Y, float cell_size, float shift_x, float shift_y, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
     hipLaunchKernelGGL(ctab_build_kernel<1>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab_h, nz_scratch, counts + 2, ph);
@@ -838,10 +845,10 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
     float k1, k2;
     cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab, n_cells, K8, Y,
-                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, qrow, reinterpret_cast<FarRec*>(far));
+                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, qrow, reinterpret_cast<FarRec*>(far), counts + 4);
     cull_far_consts(ph.c_a, 1.004, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab_h, n_cells, K8, Y,
-                       cell_size, shift_x, shift_y, k1, ph.tau2, qrow_h, reinterpret_cast<FarRec*>(far_h));
+                       cell_size, shift_x, shift_y, k1, ph.tau2, qrow_h, reinterpret_cast<FarRec*>(far_h), (uint32_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -1,5 +1,7 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against (a) golden vectors captured from the
 reference and (b) the CPU oracle on the same seeded inputs.  Tolerances: conftest.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -366,8 +368,17 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
             for key in ref:
                 np.testing.assert_array_equal(ref1[key], ref[key], err_msg=f"{key} variant 1 vs 2")
         most = 0
-        for run, queue_mb in ((0, None), (7, None), (64, None), (64, 1)):
-            eng = make_engine(scene, distn, n, variant=3, run=run or None)
+        # (lazy: the scan kernel that fetches a bin's far records on demand — chosen by the library for small ray sets on meshes whose
+        #  cells mostly have a far bound, which this one is not; forced here through the experiment variable, read at rover_create)
+        for run, queue_mb, lazy in ((0, None, None), (7, None, "1"), (64, None, "1"), (64, None, "0"), (64, 1, None)):
+            if lazy is not None:
+                os.environ["ROVER_CULL_LAZY"] = lazy
+            try:
+                eng = make_engine(scene, distn, n, variant=3, run=run or None)
+            finally:
+                os.environ.pop("ROVER_CULL_LAZY", None)
+            if lazy is not None and precision == 0:
+                assert eng.cull_info()["far_records_on_demand"] == int(lazy)
             eng.set_option("ray_precision", precision)
             if queue_mb:                              # a 1 MB queue budget: the step's ray cast is cut into slices that re-use the regions
                 eng.set_option("cull_queue_mb", queue_mb)
