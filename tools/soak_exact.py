@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from isaac_rover_amd import _lib, synth
 
+print("library:", _lib.version(), flush=True)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 irr_rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 E = 32768
