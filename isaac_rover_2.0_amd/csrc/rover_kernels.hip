@@ -1026,23 +1026,25 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __rest
 #define BKT_MAX 4096            // max coarse buckets, and max 2^low_bits
 #define BKT_STAGE 8192u         // entries of a bucket that bucket_sort_kernel orders in LDS before writing them out
 
-__global__ void __launch_bounds__(256) bucket_hist_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
+// NT threads take a tile of NT x 16 slots: 256 (4 096 slots), or 1 024 for big ray sets (launch_bin_rays)
+template <int NT>
+__global__ void __launch_bounds__(NT) bucket_hist_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
                                                           uint32_t n_buckets, uint32_t n_blocks, uint32_t* __restrict__ counts) {
     __shared__ uint32_t h[BKT_MAX];
-    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) h[i] = 0;
+    for (uint32_t i = threadIdx.x; i < n_buckets; i += NT) h[i] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * BKT_TILE;
+    const uint32_t base = blockIdx.x * (NT * BKT_ITEMS);
     uint32_t bv[BKT_ITEMS];                                   // all 16 loads in flight before the first atomic (the kernel is latency-bound)
 #pragma unroll
     for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
-        const uint32_t i = base + it * 256u + threadIdx.x;
+        const uint32_t i = base + it * NT + threadIdx.x;
         bv[it] = i < n_slots ? bins[i] : 0xffffffffu;
     }
 #pragma unroll
     for (uint32_t it = 0; it < BKT_ITEMS; ++it)
         if (bv[it] != 0xffffffffu) atomicAdd(&h[bv[it] >> low_bits], 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) counts[(size_t)blockIdx.x * n_buckets + i] = h[i];   // [block][bucket]: coalesced
+    for (uint32_t i = threadIdx.x; i < n_buckets; i += NT) counts[(size_t)blockIdx.x * n_buckets + i] = h[i];   // [block][bucket]: coalesced
 }
 
 // counts[bucket][block] -> exclusive prefix inside every bucket row (one workgroup per bucket) + the row total
@@ -1113,31 +1115,31 @@ template <> struct BktEntry<true> {
 // (rank from one LDS atomic per entry, local start from a scan of the block's bucket counts) next to their global positions, then
 // written out in that order: neighbouring lanes then write neighbouring entries of a bucket's run (~6 per bucket and block) and the
 // run leaves as one or two write transactions instead of one per entry.
-template <bool PACKED>
-__global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
+template <bool PACKED, int NT>
+__global__ void __launch_bounds__(NT) bucket_scatter_kernel(const uint32_t* __restrict__ bins, uint32_t n_slots, uint32_t low_bits,
                                                              uint32_t n_buckets, uint32_t n_blocks, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ bucket_tot, uint32_t* __restrict__ bucket_base,
                                                              uint2* __restrict__ pairs2) {
     typedef BktEntry<PACKED> En;
     typename En::T* __restrict__ pairs = reinterpret_cast<typename En::T*>(pairs2);
-    extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2 n_buckets + BKT_TILE (1 + dwords per entry) dwords
+    extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2 n_buckets + (NT * BKT_ITEMS) (1 + dwords per entry) dwords
     uint32_t* const cur = bkt_lds;               // global position of this block's first entry in each bucket
     uint32_t* const cnt = cur + n_buckets;       // this block's entries per bucket -> their local start
     uint32_t* const s_dst = cnt + n_buckets;
-    typename En::T* const s_val = reinterpret_cast<typename En::T*>(s_dst + BKT_TILE + (n_buckets & 1u));      // (8-byte aligned)
-    __shared__ uint32_t wl[4];
-    const uint32_t per = (n_buckets + 255u) >> 8, first = threadIdx.x * per;
-    const uint32_t base = blockIdx.x * BKT_TILE;
+    typename En::T* const s_val = reinterpret_cast<typename En::T*>(s_dst + (NT * BKT_ITEMS) + (n_buckets & 1u));      // (8-byte aligned)
+    __shared__ uint32_t wl[NT / 64];
+    const uint32_t per = (n_buckets + NT - 1u) / NT, first = threadIdx.x * per;
+    const uint32_t base = blockIdx.x * (NT * BKT_ITEMS);
     uint32_t bv[BKT_ITEMS], rk[BKT_ITEMS];                    // the block's 16 loads per thread go out first: their latency passes
 #pragma unroll                                               // under the bucket-offset scan below
     for (uint32_t it = 0; it < BKT_ITEMS; ++it) {
-        const uint32_t i = base + it * 256u + threadIdx.x;
+        const uint32_t i = base + it * NT + threadIdx.x;
         bv[it] = i < n_slots ? bins[i] : 0xffffffffu;
     }
     {
         uint32_t sum = 0;
         for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_buckets) ? bucket_tot[first + j] : 0u;
-        uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
+        uint32_t total, run = block_exclusive_scan<NT / 64>(sum, wl, total);
         for (uint32_t j = 0; j < per; ++j) {
             const uint32_t i = first + j;
             if (i < n_buckets) {
@@ -1157,7 +1159,7 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
     {
         uint32_t sum = 0;
         for (uint32_t j = 0; j < per; ++j) sum += (first + j < n_buckets) ? cnt[first + j] : 0u;
-        uint32_t run = block_exclusive_scan<4>(sum, wl, n_here);
+        uint32_t run = block_exclusive_scan<NT / 64>(sum, wl, n_here);
         for (uint32_t j = 0; j < per; ++j) {
             const uint32_t i = first + j;
             if (i < n_buckets) { const uint32_t c = cnt[i]; cnt[i] = run; run += c; }
@@ -1169,11 +1171,11 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(const uint32_t* __r
         if (bv[it] != 0xffffffffu) {
             const uint32_t b = bv[it] >> low_bits, l = cnt[b] + rk[it];
             s_dst[l] = cur[b] + rk[it];
-            s_val[l] = En::make(bv[it], base + it * 256u + threadIdx.x, low_bits);
+            s_val[l] = En::make(bv[it], base + it * NT + threadIdx.x, low_bits);
         }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_here; k += 256u) pairs[s_dst[k]] = s_val[k];
+    for (uint32_t k = threadIdx.x; k < n_here; k += NT) pairs[s_dst[k]] = s_val[k];
 }
 
 template <bool PACKED>
@@ -1546,22 +1548,36 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
                            uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, hipStream_t s) {
     const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
     if (low_bits < 8u || low_bits > 12u || n_buckets > BKT_MAX) return hipErrorInvalidValue;
-    const uint32_t n_blocks = blocks_for(n_slots, BKT_TILE);
-    (void)n_valid;
+    // tile of the first two passes: 4 096 slots per 256-thread block; from 2 M slots 16 384 per 1 024-thread block — a (block, bucket)
+    // run of the scatter is then ~23 entries instead of ~6 (its partial-line writes were 9 of its 21 us at 65 536 envs) and the count
+    // table a quarter of the rows; small batches keep the small tile (more blocks than CUs matter more there)
+    const bool big = n_slots >= (2u << 20);
+    const bool packed = (uint64_t)n_slots <= (1ull << (32u - low_bits));          // slot ids leave room for the low bin bits: one dword per entry
+    const uint32_t nt = big ? (packed ? 1024u : 512u) : 256u, tile = nt * BKT_ITEMS;      // (two-dword entries: 12 bytes of LDS per slot, 8 192 slots)
+    const uint32_t n_blocks = blocks_for(n_slots, tile);
     uint32_t* bucket_tot = block_sums;                 // [BKT_MAX]
     uint32_t* bucket_base = block_sums + BKT_MAX;      // [BKT_MAX + 1]
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3(n_blocks), dim3(256), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table);
-    hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(blocks_for(n_buckets, 16)), dim3(64 * RSCAN_WAVES), 0, s, table, n_blocks, n_buckets, bucket_tot);
-    const uint32_t sort_lds = ((1u << low_bits) + BKT_STAGE) * 4u;
-    if ((uint64_t)n_slots <= (1ull << (32u - low_bits))) {          // slot ids leave room for the low bin bits: one dword per entry
-        hipLaunchKernelGGL(bucket_scatter_kernel<true>, dim3(n_blocks), dim3(256), (2u * n_buckets + 2u * BKT_TILE + 2u) * 4u, s, bins, n_slots,
-                           low_bits, n_buckets, n_blocks, table, bucket_tot, bucket_base, pairs);
-        hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3(n_buckets), dim3(256), sort_lds, s, pairs, bucket_base, low_bits, sorted);
-    } else {
-        hipLaunchKernelGGL(bucket_scatter_kernel<false>, dim3(n_blocks), dim3(256), (2u * n_buckets + 3u * BKT_TILE + 2u) * 4u, s, bins, n_slots,
-                           low_bits, n_buckets, n_blocks, table, bucket_tot, bucket_base, pairs);
-        hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(n_buckets), dim3(256), sort_lds, s, pairs, bucket_base, low_bits, sorted);
+    const uint32_t scatter_lds = (2u * n_buckets + (packed ? 2u : 3u) * tile + 2u) * 4u, sort_lds = ((1u << low_bits) + BKT_STAGE) * 4u;
+#define BKT_LAUNCH(PK, NT)                                                                                                            \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL(bucket_hist_kernel<NT>, dim3(n_blocks), dim3(NT), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table); \
+        hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(blocks_for(n_buckets, 16)), dim3(64 * RSCAN_WAVES), 0, s, table, n_blocks, n_buckets, bucket_tot); \
+        hipLaunchKernelGGL((bucket_scatter_kernel<PK, NT>), dim3(n_blocks), dim3(NT), scatter_lds, s, bins, n_slots, low_bits, n_buckets, n_blocks, \
+                           table, bucket_tot, bucket_base, pairs);                                                                   \
+        hipLaunchKernelGGL(bucket_sort_kernel<PK>, dim3(n_buckets), dim3(256), sort_lds, s, pairs, bucket_base, low_bits, sorted);     \
+    } while (0)
+    if (big) {      // more than 64 KB of dynamic LDS: the kernel has to be told (once per size)
+        static uint32_t raised[2] = {0, 0};
+        if (scatter_lds > raised[packed]) {
+            const void* f = packed ? reinterpret_cast<const void*>(&bucket_scatter_kernel<true, 1024>) : reinterpret_cast<const void*>(&bucket_scatter_kernel<false, 512>);
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds);
+            if (e != hipSuccess) return e;
+            raised[packed] = scatter_lds;
+        }
     }
+    if (packed) { if (big) BKT_LAUNCH(true, 1024); else BKT_LAUNCH(true, 256); }
+    else { if (big) BKT_LAUNCH(false, 512); else BKT_LAUNCH(false, 256); }
+#undef BKT_LAUNCH
     return hipGetLastError();
 }
 

@@ -398,12 +398,19 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
 
 
 def test_ray_sort_entry_layouts_agree():
-    """The bucket sort keeps an entry in one dword (low bin bits | slot) while the slot ids leave room, else in two: 20 480
-    envs x 64 slots with 4 096 bins per bucket (bin_low_bits 12) take the two-dword layout, the default the packed one; the
-    sorted kernels' results must equal the env-order kernel's either way."""
+    """The bucket sort keeps an entry in one dword (low bin bits | slot) while the slot ids leave room, else in two: 36 864
+    envs x 64 slots with 4 096 bins per bucket (bin_low_bits 12) take the two-dword layout, the default the packed one — both
+    with the large tiles of the first two passes (>= 2 M slots); 8 192 envs the small tiles.  The sorted kernels' results must
+    equal the env-order kernel's either way."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
-    n = 20480
+    _ray_sort_layouts(36864)
+    _ray_sort_layouts(8192)
+
+
+def _ray_sort_layouts(n):
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=96, k=24, n_stones=12)
     distn = synth.ray_distribution("37")
     st = synth.make_states(n, 9.6, seed=77)
