@@ -1178,86 +1178,86 @@ __global__ void __launch_bounds__(NT) bucket_scatter_kernel(const uint32_t* __re
     for (uint32_t k = threadIdx.x; k < n_here; k += NT) pairs[s_dst[k]] = s_val[k];
 }
 
-template <bool PACKED>
-__global__ void __launch_bounds__(256) bucket_sort_kernel(const uint2* __restrict__ pairs2, const uint32_t* __restrict__ bucket_base,
+template <bool PACKED, int NT, int IPT>      // IPT: items a thread may hold (buckets of up to NT x IPT entries take the one-pass path)
+__global__ void __launch_bounds__(NT) bucket_sort_kernel(const uint2* __restrict__ pairs2, const uint32_t* __restrict__ bucket_base,
                                                           uint32_t low_bits, uint32_t* __restrict__ sorted) {
     typedef BktEntry<PACKED> En;
     const typename En::T* __restrict__ pairs = reinterpret_cast<const typename En::T*>(pairs2);
     extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2^low_bits + BKT_STAGE dwords
-    __shared__ uint32_t wl[4];
+    __shared__ uint32_t wl[NT / 64];
     const uint32_t b = blockIdx.x, tid = threadIdx.x, nl = 1u << low_bits;
     uint32_t* const h = bkt_lds;
     uint32_t* const stage = bkt_lds + nl;
     const uint32_t s0 = bucket_base[b], s1 = bucket_base[b + 1u];
     if (s1 <= s0) return;
-    for (uint32_t i = tid; i < nl; i += 256) h[i] = 0;
+    for (uint32_t i = tid; i < nl; i += NT) h[i] = 0;
     __syncthreads();
-    if (s1 - s0 <= 64u * 256u) {
+    if (s1 - s0 <= (uint32_t)(NT * IPT)) {
         // The usual bucket (6-12 k rays): ONE pass of LDS atomics.  A thread keeps its <= 64 items in registers with the rank the
         // histogram atomic returned (rank inside the bin), so after the scan the position is start[bin] + rank — no second read of
         // the pairs and no second round of atomics.
-        uint32_t slot[64], br[64];                                   // br = low bin bits | rank << 12
+        uint32_t slot[IPT], br[IPT];                                 // br = low bin bits | rank << 12
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < IPT / 8; ++g) {
             typename En::T pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u; pv[j] = k < s1 ? pairs[k] : En::none(); }
+            for (int j = 0; j < 8; ++j) { const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * NT; pv[j] = k < s1 ? pairs[k] : En::none(); }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * 256u, lo = En::lo(pv[j], low_bits);
+                const uint32_t k = s0 + tid + (uint32_t)(8 * g + j) * NT, lo = En::lo(pv[j], low_bits);
                 slot[8 * g + j] = En::slot(pv[j], low_bits);
                 br[8 * g + j] = k < s1 ? (lo | (atomicAdd(&h[lo], 1u) << 12)) : 0u;
             }
         }
         __syncthreads();
-        const uint32_t per = nl >> 8, first = tid * per;
+        const uint32_t per = (nl + NT - 1u) / NT, first = tid * per;
         uint32_t sum = 0;
-        for (uint32_t j = 0; j < per; ++j) sum += h[first + j];
-        uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
-        for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
+        for (uint32_t j = 0; j < per; ++j) sum += first + j < nl ? h[first + j] : 0u;
+        uint32_t total, run = block_exclusive_scan<NT / 64>(sum, wl, total);
+        for (uint32_t j = 0; j < per; ++j) if (first + j < nl) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
         __syncthreads();
         // through LDS: a wave's 64 positions are anywhere in the bucket's 24-48 KB of output, 64 partial-line writes per store
         // instruction (4.1 M L2 write transactions a launch); staged, the bucket leaves in whole lines
         if (s1 - s0 <= BKT_STAGE) {
 #pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                const uint32_t k = s0 + tid + (uint32_t)i * 256u;
+            for (int i = 0; i < IPT; ++i) {
+                const uint32_t k = s0 + tid + (uint32_t)i * NT;
                 if (k < s1) stage[h[br[i] & 0xfffu] + (br[i] >> 12)] = slot[i];
             }
             __syncthreads();
-            for (uint32_t k = tid; k < s1 - s0; k += 256u) sorted[s0 + k] = stage[k];
+            for (uint32_t k = tid; k < s1 - s0; k += NT) sorted[s0 + k] = stage[k];
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const uint32_t k = s0 + tid + (uint32_t)i * 256u;
+        for (int i = 0; i < IPT; ++i) {
+            const uint32_t k = s0 + tid + (uint32_t)i * NT;
             if (k < s1) sorted[s0 + h[br[i] & 0xfffu] + (br[i] >> 12)] = slot[i];
         }
         return;
     }
     // eight loads in flight per thread before their atomics: the kernel waits on memory 93 % of the time otherwise
-    for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
+    for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * NT) {
         typename En::T bx[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; bx[j] = k < s1 ? pairs[k] : En::none(); }
+        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * NT; bx[j] = k < s1 ? pairs[k] : En::none(); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * 256u < s1) atomicAdd(&h[En::lo(bx[j], low_bits)], 1u);
+        for (int j = 0; j < 8; ++j) if (k0 + (uint32_t)j * NT < s1) atomicAdd(&h[En::lo(bx[j], low_bits)], 1u);
     }
     __syncthreads();
-    // exclusive scan of h[0..nl): each thread owns nl/256 consecutive entries (nl >= 256)
-    const uint32_t per = nl >> 8, first = tid * per;
+    // exclusive scan of h[0..nl): each thread owns ceil(nl / NT) consecutive entries
+    const uint32_t per = (nl + NT - 1u) / NT, first = tid * per;
     uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; ++j) sum += h[first + j];
-    uint32_t total, run = block_exclusive_scan<4>(sum, wl, total);
-    for (uint32_t j = 0; j < per; ++j) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
+    for (uint32_t j = 0; j < per; ++j) sum += first + j < nl ? h[first + j] : 0u;
+    uint32_t total, run = block_exclusive_scan<NT / 64>(sum, wl, total);
+    for (uint32_t j = 0; j < per; ++j) if (first + j < nl) { const uint32_t c = h[first + j]; h[first + j] = run; run += c; }
     __syncthreads();
-    for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * 256u) {
+    for (uint32_t k0 = s0 + tid; k0 < s1; k0 += 8u * NT) {
         typename En::T pv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * 256u; pv[j] = k < s1 ? pairs[k] : En::none(); }
+        for (int j = 0; j < 8; ++j) { const uint32_t k = k0 + (uint32_t)j * NT; pv[j] = k < s1 ? pairs[k] : En::none(); }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (k0 + (uint32_t)j * 256u < s1) sorted[s0 + atomicAdd(&h[En::lo(pv[j], low_bits)], 1u)] = En::slot(pv[j], low_bits);
+            if (k0 + (uint32_t)j * NT < s1) sorted[s0 + atomicAdd(&h[En::lo(pv[j], low_bits)], 1u)] = En::slot(pv[j], low_bits);
     }
 }
 
@@ -1564,7 +1564,11 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
         hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(blocks_for(n_buckets, 16)), dim3(64 * RSCAN_WAVES), 0, s, table, n_blocks, n_buckets, bucket_tot); \
         hipLaunchKernelGGL((bucket_scatter_kernel<PK, NT>), dim3(n_blocks), dim3(NT), scatter_lds, s, bins, n_slots, low_bits, n_buckets, n_blocks, \
                            table, bucket_tot, bucket_base, pairs);                                                                   \
-        hipLaunchKernelGGL(bucket_sort_kernel<PK>, dim3(n_buckets), dim3(256), sort_lds, s, pairs, bucket_base, low_bits, sorted);     \
+        /* buckets of <= 16 384 entries: 512 threads x 32; mean bucket above 8 192 (dense ray sets: the terrain buckets of 65 536 envs x 120 rays hold 22 k): 1 024 x 32 */ \
+        if ((uint64_t)n_valid > 8192ull * n_buckets)                                                                                  \
+            hipLaunchKernelGGL((bucket_sort_kernel<PK, 1024, 32>), dim3(n_buckets), dim3(1024), sort_lds, s, pairs, bucket_base, low_bits, sorted); \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((bucket_sort_kernel<PK, 512, 32>), dim3(n_buckets), dim3(512), sort_lds, s, pairs, bucket_base, low_bits, sorted);     \
     } while (0)
     if (big) {      // more than 64 KB of dynamic LDS: the kernel has to be told (once per size)
         static uint32_t raised[2] = {0, 0};
