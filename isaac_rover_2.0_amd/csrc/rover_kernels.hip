@@ -203,17 +203,23 @@ __global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
     }
 }
 
-// per (env, slot): ray origin, unit direction, cell id; rank of the ray inside its (map, cell) bin
-__global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
-    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t e = gid / a.R8, slot = gid % a.R8;
-    const bool live = e < a.E;              // lanes past the end stay for the transposed stores below
+// per (env, slot): ray origin, unit direction, cell id, bin key.
+// A workgroup takes 64 envs x 8 ray slots: wave w works on ONE slot (slot0 + w) of 64 consecutive envs, so the three kinds of slot —
+// wheel rays (f32 joint chain), body rays, heightmap rays (f64 transform) — never share a wave.  (One wave per env, lane = slot, ran all
+// three branches in every wave: 373 VALU instructions for work of ~120, 46 us, and neither its stores (-5 us without any) nor the f64
+// arithmetic (f32 instead: no change) were what it waited for.)  The env-record chunks load coalesced (chunk-major: 64 consecutive envs),
+// the slot's constants are wave-uniform.  The 64 x 8 records leave through LDS: per env the 8 slots are 256 contiguous bytes.
+#define PREP_SLOTS 8
+__global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a) {
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t e0 = blockIdx.x * 64u, slot0 = blockIdx.y * PREP_SLOTS;
+    const uint32_t e = e0 + lane, slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 + w));
+    const bool live = e < a.E;
     RayRec rec;
     rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
     uint32_t bin = 0xffffffffu;
     const uint32_t n_real = 26u + a.P;
-    // Every load of the three branches below is issued here, from clamped (always valid) addresses: the wave waits for memory
-    // once instead of once per branch it walks through (a wave of 64 slots meets all three).
+    // every load of the slot's branch is issued here, from clamped (always valid) addresses
     const uint32_t ec = min(e, a.E - 1u);
     const float4* er = reinterpret_cast<const float4*>(a.env_rec) + ec;                  // chunk k of the env: er[k * E]
     const size_t EE = a.E;
@@ -301,21 +307,24 @@ __global__ void __launch_bounds__(256) prep_rays_kernel(PrepArgs a) {
         bin = ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell;
 
     }
-    if (a.bin_out && live) a.bin_out[gid] = bin;              // key of the bucket sort; 0xffffffff for padding slots
-    // The wave's 64 records are 2 KB in a row: transposed through LDS, each of the two stores writes 1 KB contiguously
-    // (lane i: 16 bytes at 16 i) instead of every other 16 bytes of the 2 KB.
-    __shared__ float4 s_t[4][128];
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    s_t[w][2u * lane] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
-    s_t[w][2u * lane + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t base = gid - lane, total = a.E * a.R8;
-    const uint32_t n_here = base < total ? min(64u, total - base) : 0u;    // records of this wave (64 but for the last ones)
-    float4* dst = reinterpret_cast<float4*>(a.rays + base);
-    if (lane < 2u * n_here) dst[lane] = s_t[w][lane];
-    if (lane + 64u < 2u * n_here) dst[lane + 64u] = s_t[w][lane + 64u];
+    // The block's 64 x 8 records and bin keys, env-major through LDS (rows of 17 float4 / 9 dwords: a wave's 64 rows spread over the banks):
+    // a store instruction then writes four envs' 256-byte groups — whole lines — instead of 64 records 2 KB apart.
+    __shared__ float4 s_t[64 * (2 * PREP_SLOTS + 1)];
+    __shared__ uint32_t s_b[64 * (PREP_SLOTS + 1)];
+    s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
+    s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
+    s_b[lane * (PREP_SLOTS + 1) + w] = bin;                  // key of the bucket sort; 0xffffffff for padding slots
+    __syncthreads();
+    float4* const rays4 = reinterpret_cast<float4*>(a.rays);
+#pragma unroll
+    for (uint32_t r = 0; r < 2u; ++r) {
+        const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
+        if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
+    }
+    {
+        const uint32_t el = threadIdx.x / PREP_SLOTS, q = threadIdx.x % PREP_SLOTS;
+        if (a.bin_out && e0 + el < a.E) a.bin_out[(size_t)(e0 + el) * a.R8 + slot0 + q] = s_b[el * (PREP_SLOTS + 1) + q];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1528,9 +1537,8 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 }
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
-    uint64_t n = (uint64_t)a.E * a.R8;
     hipLaunchKernelGGL(prep_env_kernel, dim3(blocks_for(a.E, 256), 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(a.E, 64), a.R8 / PREP_SLOTS), dim3(64 * PREP_SLOTS), 0, s, a);       // (R8 is a multiple of 8)
     return hipGetLastError();
 }
 
