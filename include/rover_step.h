@@ -249,6 +249,21 @@ ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_
                                       const float *const *weights, const float *const *biases, const int32_t *widths,
                                       const int32_t *activations, float *y, int64_t y_stride, void *stream);
 
+/* Two 2-layer chains over the SAME M rows — the two encoders of the actor / critic (learning/model.py:188-190: sparse and dense
+ * heightmap slices of one obs row; neither depends on the other) — and, optionally, the copy of the proprioception columns into the
+ * concat buffer (:191: dst[r][0:copy_cols] = src[r][0:copy_cols]; copy_cols = 0: none).  Small batches (M < 16 384, both chains of
+ * the same built tile shape) run the two side by side: ONE launch for both first layers (split along k), one for both second layers
+ * and the copy — a third of the actor forward's launches at the reference's default numEnvs 512 (cfg/task/Rover.yaml:11).  Otherwise
+ * the chains run one after the other.  Results are those of two rover_mlp_chain_forward calls either way. */
+typedef struct {
+    const float *x; int64_t x_stride; int32_t K0, n_layers;
+    const float *const *weights; const float *const *biases; const int32_t *widths; const int32_t *activations;
+    float *y; int64_t y_stride;
+} rover_chain_desc;
+ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rover_chain_desc *a, const rover_chain_desc *b,
+                                           const float *copy_src, int64_t copy_src_stride, float *copy_dst, int64_t copy_dst_stride,
+                                           int32_t copy_cols, void *stream);
+
 /* ---- tuning knobs ------------------------------------------------------------------------------------- */
 /* name = "raycast_variant": 0 = auto; 1 = one half-wave per ray in env order, every cell block streamed from HBM;
  *        2 = rays counting-sorted by (map, cell), one wave per run of sorted rays, the cell's triangles held in registers

@@ -65,6 +65,11 @@ class CullInfo(C.Structure):
                 ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64)]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("K0", C.c_int32), ("n_layers", C.c_int32), ("weights", C.c_void_p),
+                ("biases", C.c_void_p), ("widths", C.c_void_p), ("activations", C.c_void_p), ("y", C.c_void_p), ("y_stride", C.c_int64)]
+
+
 class ResetIO(C.Structure):
     _fields_ = [("reset_ids", C.c_void_p), ("n_reset_dev", C.c_void_p), ("n_reset_host", C.c_int32),
                 ("initial_pos3", C.c_void_p), ("pos3", C.c_void_p), ("quat4", C.c_void_p), ("joint_pos13", C.c_void_p),
@@ -110,6 +115,7 @@ SYMBOLS = {
     "rover_build_knn_map_ref": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "rover_linear_forward": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "rover_mlp_chain_forward": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "rover_mlp_chain_pair_forward": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
     "rover_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rover_set_profiling": (C.c_int, [_P, C.c_int32]),
     "rover_get_profile": (C.c_int, [_P, C.POINTER(Profile)]),
@@ -445,6 +451,43 @@ class Engine:
         self._check(self.lib.rover_mlp_chain_forward(self._h, _ptr(x), x.stride(0), m, k0, n, w, b, widths, acts, _ptr(out), out.stride(0),
                                                      _stream()), "rover_mlp_chain_forward")
         return out
+
+    def _chain_desc(self, x, layers, out, keep):
+        m, k0 = x.shape
+        for t, name in ((x, "x"), (out, "out")):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+                raise RoverError(f"chain_pair_forward: {name} must be a float32 GPU matrix with unit column stride")
+        n, k = len(layers), k0
+        for l in layers:
+            self._chk(l.weight, (l.weight.shape[0], k), torch.float32, "weight")
+            self._chk(l.bias, (l.weight.shape[0],), torch.float32, "bias")
+            k = l.weight.shape[0]
+        if out.shape[0] != m or out.shape[1] != k:
+            raise RoverError(f"chain_pair_forward: out must be [{m},{k}]")
+        w = (C.c_void_p * n)(*[_ptr(l.weight) for l in layers])
+        b = (C.c_void_p * n)(*[_ptr(l.bias) for l in layers])
+        widths = (C.c_int32 * n)(*[l.weight.shape[0] for l in layers])
+        acts = (C.c_int32 * n)(*[self.ACTIVATIONS[l.activation] for l in layers])
+        keep.extend((w, b, widths, acts))                      # the arrays the descriptor points at live until the call returns
+        return ChainDesc(x.data_ptr(), x.stride(0), k0, n, C.addressof(w), C.addressof(b), C.addressof(widths), C.addressof(acts),
+                         out.data_ptr(), out.stride(0))
+
+    def chain_pair_forward(self, xa, layers_a, out_a, xb, layers_b, out_b, copy_src=None, copy_dst=None, copy_cols=0):
+        """Two 2-layer chains over the same rows (the two encoders: rover_mlp_chain_pair_forward) and, optionally,
+        copy_dst[:, :copy_cols] = copy_src[:, :copy_cols] — side by side in one launch per stage at small batches."""
+        if xa.shape[0] != xb.shape[0]:
+            raise RoverError("chain_pair_forward: the two chains must have the same number of rows")
+        keep = []
+        da, db = self._chain_desc(xa, layers_a, out_a, keep), self._chain_desc(xb, layers_b, out_b, keep)
+        if copy_cols:
+            for t, name in ((copy_src, "copy_src"), (copy_dst, "copy_dst")):
+                if (t is None or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != xa.shape[0]
+                        or t.shape[1] < copy_cols):
+                    raise RoverError(f"chain_pair_forward: {name} must be a float32 GPU matrix of the same rows with >= copy_cols columns")
+        self._check(self.lib.rover_mlp_chain_pair_forward(
+            self._h, xa.shape[0], C.byref(da), C.byref(db), _ptr(copy_src) if copy_cols else None, copy_src.stride(0) if copy_cols else 0,
+            _ptr(copy_dst) if copy_cols else None, copy_dst.stride(0) if copy_cols else 0, int(copy_cols), _stream()),
+            "rover_mlp_chain_pair_forward")
 
     def set_option(self, name, value):
         self._check(self.lib.rover_set_option(self._h, name.encode(), int(value)), "rover_set_option")

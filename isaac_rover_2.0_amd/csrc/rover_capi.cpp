@@ -1124,10 +1124,9 @@ int rover_linear_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t
     return ROVER_OK;
 }
 
-int rover_mlp_chain_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers,
-                            const float* const* weights, const float* const* biases, const int32_t* widths, const int32_t* activations,
-                            float* y, int64_t y_stride, void* stream) {
-    if (!c) return ROVER_E_INVALID;
+// validated ChainArgs of one chain (0 = ok, else the error is recorded)
+static int chain_args_of(rover_ctx* c, const float* x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers, const float* const* weights,
+                         const float* const* biases, const int32_t* widths, const int32_t* activations, float* y, int64_t y_stride, ChainArgs* out) {
     if (!x || !y || !weights || !biases || !widths || !activations || M < 0 || K0 <= 0 || x_stride < K0 || (n_layers != 2 && n_layers != 4))
         return fail(c, ROVER_E_INVALID, "mlp_chain_forward: bad arguments (M=%d K0=%d layers=%d)", M, K0, n_layers);
     ChainArgs a{};
@@ -1138,26 +1137,66 @@ int rover_mlp_chain_forward(rover_ctx* c, const float* x, int64_t x_stride, int3
         a.w[i] = weights[i]; a.b[i] = biases[i]; a.n[i] = widths[i]; a.act[i] = activations[i];
     }
     if (y_stride < a.n[n_layers - 1]) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: y_stride %lld < width %d", (long long)y_stride, a.n[n_layers - 1]);
-    if (M == 0) return ROVER_OK;
-    USE_DEVICE(c);
-    if (chain_wants_splitk(a)) {
-        // small batches: first layer split along k through a scratch buffer (grown here when a larger batch comes: not inside a
-        // stream capture — size the first call before capturing)
-        const size_t need = chain_splitk_scratch_floats(a.M, a.K0, a.n[0]);
-        if (need > c->mlp_scratch_floats) {
-            HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));          // kernels still reading the old buffer
-            dfree(c->d_mlp_scratch);
-            c->mlp_scratch_floats = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->d_mlp_scratch, need * sizeof(float)));
-            c->mlp_scratch_floats = need;
-        }
-        HIP_TRY(c, launch_chain_splitk(a, c->d_mlp_scratch, (hipStream_t)stream));
+    *out = a;
+    return ROVER_OK;
+}
+
+// the split-k scratch buffer, grown when a larger batch comes (not inside a stream capture — size the first call before capturing)
+static int mlp_scratch_reserve(rover_ctx* c, size_t need, hipStream_t s) {
+    if (need <= c->mlp_scratch_floats) return ROVER_OK;
+    HIP_TRY(c, hipStreamSynchronize(s));          // kernels still reading the old buffer
+    dfree(c->d_mlp_scratch);
+    c->mlp_scratch_floats = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_mlp_scratch, need * sizeof(float)));
+    c->mlp_scratch_floats = need;
+    return ROVER_OK;
+}
+
+static int chain_run(rover_ctx* c, const ChainArgs& a, hipStream_t s) {
+    if (a.M == 0) return ROVER_OK;
+    if (chain_wants_splitk(a)) {          // small batches: first layer split along k through a scratch buffer
+        if (int r = mlp_scratch_reserve(c, chain_splitk_scratch_floats(a.M, a.K0, a.n[0]), s)) return r;
+        HIP_TRY(c, launch_chain_splitk(a, c->d_mlp_scratch, s));
         return ROVER_OK;
     }
-    hipError_t e = launch_chain(a, (hipStream_t)stream);
+    hipError_t e = launch_chain(a, s);
     if (e == hipErrorInvalidValue) return fail(c, ROVER_E_INVALID, "mlp_chain_forward: net outside the built tile shapes (<= 96 -> <= 64, or <= 256 -> <= 160 -> <= 128 -> <= 16 with hidden activations none / LeakyReLU / ReLU)");
     HIP_TRY(c, e);
     return ROVER_OK;
+}
+
+int rover_mlp_chain_forward(rover_ctx* c, const float* x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers,
+                            const float* const* weights, const float* const* biases, const int32_t* widths, const int32_t* activations,
+                            float* y, int64_t y_stride, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    ChainArgs a{};
+    if (int r = chain_args_of(c, x, x_stride, M, K0, n_layers, weights, biases, widths, activations, y, y_stride, &a)) return r;
+    USE_DEVICE(c);
+    return chain_run(c, a, (hipStream_t)stream);
+}
+
+int rover_mlp_chain_pair_forward(rover_ctx* c, int32_t M, const rover_chain_desc* da, const rover_chain_desc* db, const float* copy_src,
+                                 int64_t copy_src_stride, float* copy_dst, int64_t copy_dst_stride, int32_t copy_cols, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!da || !db || copy_cols < 0 || (copy_cols > 0 && (!copy_src || !copy_dst || copy_src_stride < copy_cols || copy_dst_stride < copy_cols)))
+        return fail(c, ROVER_E_INVALID, "mlp_chain_pair_forward: bad arguments (copy_cols=%d)", copy_cols);
+    ChainArgs a{}, b{};
+    if (int r = chain_args_of(c, da->x, da->x_stride, M, da->K0, da->n_layers, da->weights, da->biases, da->widths, da->activations, da->y, da->y_stride, &a)) return r;
+    if (int r = chain_args_of(c, db->x, db->x_stride, M, db->K0, db->n_layers, db->weights, db->biases, db->widths, db->activations, db->y, db->y_stride, &b)) return r;
+    if (M == 0) return ROVER_OK;
+    USE_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if (chain_pair_fits(a, b)) {
+        const size_t fa = chain_splitk_scratch_floats(a.M, a.K0, a.n[0]), fb = chain_splitk_scratch_floats(b.M, b.K0, b.n[0]);
+        if (int r = mlp_scratch_reserve(c, fa + fb, s)) return r;
+        HIP_TRY(c, launch_chain_splitk_pair(a, b, c->d_mlp_scratch, c->d_mlp_scratch + fa, copy_src, copy_src_stride, copy_dst, copy_dst_stride, copy_cols, s));
+        return ROVER_OK;
+    }
+    if (copy_cols > 0)
+        HIP_TRY(c, hipMemcpy2DAsync(copy_dst, (size_t)copy_dst_stride * sizeof(float), copy_src, (size_t)copy_src_stride * sizeof(float),
+                                    (size_t)copy_cols * sizeof(float), (size_t)M, hipMemcpyDeviceToDevice, s));
+    if (int r = chain_run(c, a, s)) return r;
+    return chain_run(c, b, s);
 }
 
 int rover_set_option(rover_ctx* c, const char* name, int64_t value) {

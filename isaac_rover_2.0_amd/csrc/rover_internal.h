@@ -181,6 +181,10 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 bool chain_wants_splitk(const ChainArgs& a);
 size_t chain_splitk_scratch_floats(int M, int K0, int n0);
 hipError_t launch_chain_splitk(const ChainArgs& a, float* scratch, hipStream_t s);
+// two such chains over the same rows in one launch per stage (+ an optional column copy), when chain_pair_fits()
+bool chain_pair_fits(const ChainArgs& a, const ChainArgs& b);
+hipError_t launch_chain_splitk_pair(const ChainArgs& a, const ChainArgs& b, float* scratch_a, float* scratch_b, const float* copy_src,
+                                    int64_t copy_src_stride, float* copy_dst, int64_t copy_dst_stride, int copy_cols, hipStream_t s);
 
 hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
                          uint32_t K8, uint32_t T, uint32_t V, uint16_t* table, hipStream_t s);

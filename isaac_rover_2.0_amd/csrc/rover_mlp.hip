@@ -404,11 +404,19 @@ __global__ void __launch_bounds__(512, 4) chain16_kernel(ChainArgs a) {       //
 // scratch [S][M][TN * 16], and a second small kernel adds them in a fixed order (deterministic), applies bias + activation and runs
 // the narrow second layer with plain FMAs.
 // ---------------------------------------------------------------------------------------------------
+// Up to TWO chains over the same M rows side by side in one launch (blockIdx.z picks the chain: the actor's two encoders do not depend
+// on each other, learning/model.py:188-190): their first layers together put two waves on every SIMD instead of one after the other.
+struct SplitkL1 { const float* x; int64_t x_stride; int K; const float* w; int N; int chunk /* multiple of 16 */; int S; float* part; };
+struct SplitkL1Pair { SplitkL1 c[2]; int M; };
 template <int TN, int RT>                  // RT row tiles of 16 rows per wave: a weight operand, once loaded, multiplies RT x operands
-__global__ void __launch_bounds__(64) splitk_layer1_kernel(const float* __restrict__ x, int64_t x_stride, int M, int K, const float* __restrict__ w,
-                                                           int N, int chunk /* multiple of 16 */, float* __restrict__ part) {
+__global__ void __launch_bounds__(64) splitk_layer1_kernel(SplitkL1Pair args) {
+    const SplitkL1& a = args.c[blockIdx.z];
+    const float* __restrict__ x = a.x; const float* __restrict__ w = a.w; float* __restrict__ part = a.part;
+    const int64_t x_stride = a.x_stride;
+    const int M = args.M, K = a.K, N = a.N, chunk = a.chunk;
     const uint32_t lane = threadIdx.x, m = lane & 15u, g = lane >> 4;
     const uint32_t sidx = blockIdx.y;
+    if (sidx >= (uint32_t)a.S) return;                              // (the grid covers the chain with more chunks)
     const uint32_t k_lo = sidx * (uint32_t)chunk, k_hi = min((uint32_t)K, k_lo + (uint32_t)chunk);
     f32x4 acc[RT][TN];
 #pragma unroll
@@ -462,10 +470,23 @@ __global__ void __launch_bounds__(64) splitk_layer1_kernel(const float* __restri
 
 // 16 rows per workgroup: h = act1(sum_s part[s] + b1) and W2 (transposed) in LDS, then y = act2(W2 h + b2): thread (o = tid % 64,
 // q = tid / 64) computes output o of rows q, q + 4, q + 8, q + 12 — W2 reads of a wave are consecutive words, h reads broadcasts
+struct SplitkFin { const float* part; int S; const float* b1; int n1, act1; const float* w2; const float* b2; int n2, act2; float* y; int64_t y_stride; };
+// copy: columns [0, copy_cols) of copy_src's rows to copy_dst (the actor's proprioception columns on their way into the concat buffer,
+// model.py:191 — one launch less), done by the workgroups of chain 0
+struct SplitkFinPair { SplitkFin c[2]; int M; const float* copy_src; int64_t copy_src_stride; float* copy_dst; int64_t copy_dst_stride; int copy_cols; };
 template <int TN>
-__global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restrict__ part, int S, int M, const float* __restrict__ b1, int n1,
-                                                            int act1, const float* __restrict__ w2, const float* __restrict__ b2, int n2,
-                                                            int act2, float* __restrict__ y, int64_t y_stride) {
+__global__ void __launch_bounds__(256) splitk_finish_kernel(SplitkFinPair args) {
+    const SplitkFin& a = args.c[blockIdx.z];
+    const float* __restrict__ part = a.part; const float* __restrict__ b1 = a.b1; const float* __restrict__ w2 = a.w2;
+    const float* __restrict__ b2 = a.b2; float* __restrict__ y = a.y;
+    const int S = a.S, M = args.M, n1 = a.n1, act1 = a.act1, n2 = a.n2, act2 = a.act2;
+    const int64_t y_stride = a.y_stride;
+    if (blockIdx.z == 0 && args.copy_cols > 0) {
+        for (uint32_t i = threadIdx.x; i < 16u * (uint32_t)args.copy_cols; i += 256u) {
+            const uint32_t r = i / (uint32_t)args.copy_cols, col = i % (uint32_t)args.copy_cols, row = blockIdx.x * 16u + r;
+            if (row < (uint32_t)M) args.copy_dst[(size_t)row * args.copy_dst_stride + col] = args.copy_src[(size_t)row * args.copy_src_stride + col];
+        }
+    }
     constexpr uint32_t NP = TN * 16u;
     __shared__ float h[16][NP + 1];
     __shared__ float w2s[NP][65];                                    // [k][o], n2 <= 64
@@ -522,18 +543,48 @@ size_t chain_splitk_scratch_floats(int M, int K0, int n0) {
 // (the same nets at every batch size: what the large-batch 2-layer kernel is built for, <= 96 -> <= 64)
 bool chain_wants_splitk(const ChainArgs& a) { return a.n_layers == 2 && a.M < 16384 && a.K0 >= 128 && a.n[0] <= 96 && a.n[1] <= 64; }
 
+static int splitk_tn(const ChainArgs& a) { return a.n[0] <= 80 ? 5 : 6; }
+static SplitkL1 splitk_l1_of(const ChainArgs& a, float* scratch, int* rt) {
+    int chunk;
+    const int S = splitk_chunks(a.M, a.K0, &chunk, rt);
+    return SplitkL1{a.x, a.x_stride, a.K0, a.w[0], a.n[0], chunk, S, scratch};
+}
+static SplitkFin splitk_fin_of(const ChainArgs& a, const SplitkL1& l) {
+    return SplitkFin{l.part, l.S, a.b[0], a.n[0], a.act[0], a.w[1], a.b[1], a.n[1], a.act[1], a.y, a.y_stride};
+}
 template <int TN>
-static void launch_splitk_tn(const ChainArgs& a, float* scratch, hipStream_t s) {
-    int chunk, rt;
-    const int S = splitk_chunks(a.M, a.K0, &chunk, &rt);
-    const dim3 g1((uint32_t)((a.M + 16 * rt - 1) / (16 * rt)), (uint32_t)S), g2((uint32_t)((a.M + 15) / 16));
-    if (rt == 2) hipLaunchKernelGGL((splitk_layer1_kernel<TN, 2>), g1, dim3(64), 0, s, a.x, a.x_stride, a.M, a.K0, a.w[0], a.n[0], chunk, scratch);
-    else hipLaunchKernelGGL((splitk_layer1_kernel<TN, 1>), g1, dim3(64), 0, s, a.x, a.x_stride, a.M, a.K0, a.w[0], a.n[0], chunk, scratch);
-    hipLaunchKernelGGL((splitk_finish_kernel<TN>), g2, dim3(256), 0, s, scratch, S, a.M, a.b[0], a.n[0], a.act[0], a.w[1], a.b[1], a.n[1],
-                       a.act[1], a.y, a.y_stride);
+static void launch_splitk_tn(const SplitkL1Pair& l, const SplitkFinPair& f, int n_chains, int rt, hipStream_t s) {
+    const int S = n_chains == 2 && l.c[1].S > l.c[0].S ? l.c[1].S : l.c[0].S;
+    const dim3 g1((uint32_t)((l.M + 16 * rt - 1) / (16 * rt)), (uint32_t)S, (uint32_t)n_chains), g2((uint32_t)((l.M + 15) / 16), 1u, (uint32_t)n_chains);
+    if (rt == 2) hipLaunchKernelGGL((splitk_layer1_kernel<TN, 2>), g1, dim3(64), 0, s, l);
+    else hipLaunchKernelGGL((splitk_layer1_kernel<TN, 1>), g1, dim3(64), 0, s, l);
+    hipLaunchKernelGGL((splitk_finish_kernel<TN>), g2, dim3(256), 0, s, f);
 }
 hipError_t launch_chain_splitk(const ChainArgs& a, float* scratch, hipStream_t s) {
-    if (a.n[0] <= 80) launch_splitk_tn<5>(a, scratch, s); else launch_splitk_tn<6>(a, scratch, s);
+    int rt;
+    SplitkL1Pair l{}; SplitkFinPair f{};
+    l.M = f.M = a.M;
+    l.c[0] = splitk_l1_of(a, scratch, &rt);
+    f.c[0] = splitk_fin_of(a, l.c[0]);
+    if (splitk_tn(a) == 5) launch_splitk_tn<5>(l, f, 1, rt, s); else launch_splitk_tn<6>(l, f, 1, rt, s);
+    return hipGetLastError();
+}
+// two chains over the same rows side by side (both chain_wants_splitk, the same tile shape: the caller checks); scratch_b follows
+// chain a's part of the scratch buffer
+bool chain_pair_fits(const ChainArgs& a, const ChainArgs& b) {
+    return a.M == b.M && chain_wants_splitk(a) && chain_wants_splitk(b) && splitk_tn(a) == splitk_tn(b);
+}
+hipError_t launch_chain_splitk_pair(const ChainArgs& a, const ChainArgs& b, float* scratch_a, float* scratch_b, const float* copy_src,
+                                    int64_t copy_src_stride, float* copy_dst, int64_t copy_dst_stride, int copy_cols, hipStream_t s) {
+    int rt, rt_b;
+    SplitkL1Pair l{}; SplitkFinPair f{};
+    l.M = f.M = a.M;
+    l.c[0] = splitk_l1_of(a, scratch_a, &rt);
+    l.c[1] = splitk_l1_of(b, scratch_b, &rt_b);                       // (rt depends on M only)
+    f.c[0] = splitk_fin_of(a, l.c[0]);
+    f.c[1] = splitk_fin_of(b, l.c[1]);
+    f.copy_src = copy_src; f.copy_src_stride = copy_src_stride; f.copy_dst = copy_dst; f.copy_dst_stride = copy_dst_stride; f.copy_cols = copy_cols;
+    if (splitk_tn(a) == 5) launch_splitk_tn<5>(l, f, 2, rt, s); else launch_splitk_tn<6>(l, f, 2, rt, s);
     return hipGetLastError();
 }
 

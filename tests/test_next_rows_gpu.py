@@ -186,6 +186,7 @@ def test_policy_forward_matches_reference_modules(name):
     np.testing.assert_allclose(fused.cpu().numpy(), fx["out_actor"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
     p0 = nobs - ns - nd
     cat_f = actor._bufs["cat"].cpu().numpy()
+    np.testing.assert_array_equal(cat_f[:, :p0], fx["states"].astype(np.float32)[:, :p0])      # (copied by the encoder pair's second launch)
     np.testing.assert_allclose(cat_f[:, p0:p0 + 60], fx["out_actor_encoder0"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
     np.testing.assert_allclose(cat_f[:, p0 + 60:p0 + 120], fx["out_actor_encoder1"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
     out = actor.compute(x, fused=False)
@@ -204,4 +205,36 @@ def test_policy_forward_matches_reference_modules(name):
             v = critic.compute(x, fused=fused_mode)
             torch.cuda.synchronize()
             np.testing.assert_allclose(v.cpu().numpy(), fx["out_critic"], atol=TOL_NET_ABS, rtol=TOL_NET_REL)
+    eng.close()
+
+
+@pytest.mark.parametrize("rows", [1, 17, 512, 4096, 20000])
+def test_encoder_pair_equals_two_chain_calls(rows):
+    """rover_mlp_chain_pair_forward (both encoders + the proprioception copy in one launch per stage below 16 384 rows, one chain
+    after the other above) against two rover_mlp_chain_forward calls and a tensor copy: bit-identical."""
+    from isaac_rover_amd import _lib
+    from isaac_rover_amd.learning.model import HeightmapNet
+    eng = _lib.Engine(8, device=0)
+    torch.manual_seed(rows)
+    net = HeightmapNet(eng, 1750, 634, 1112, 2, "tanh")
+    x = torch.rand(rows, 1750, device="cuda") * 2 - 1
+    p, ef = 4, 60
+    want = torch.full((rows, p + 2 * ef), float("nan"), device="cuda")
+    want[:, :p] = x[:, :p]
+    eng.chain_forward(x[:, p:p + 634], net.encoder0, want[:, p:p + ef])
+    eng.chain_forward(x[:, p + 634:], net.encoder1, want[:, p + ef:])
+    got = torch.full((rows, p + 2 * ef), float("nan"), device="cuda")
+    eng.chain_pair_forward(x[:, p:p + 634], net.encoder0, got[:, p:p + ef], x[:, p + 634:], net.encoder1, got[:, p + ef:],
+                           copy_src=x, copy_dst=got, copy_cols=p)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # without the copy the first columns stay untouched
+    got2 = torch.full((rows, p + 2 * ef), 7.0, device="cuda")
+    eng.chain_pair_forward(x[:, p:p + 634], net.encoder0, got2[:, p:p + ef], x[:, p + 634:], net.encoder1, got2[:, p + ef:])
+    torch.cuda.synchronize()
+    assert torch.equal(got2[:, p:], want[:, p:]) and bool((got2[:, :p] == 7.0).all())
+    # the whole forward through the pair equals the layer-by-layer path within the net tolerance
+    a, b = net.compute(x, fused=True).clone(), net.compute(x, fused=False).clone()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=TOL_NET_ABS, rtol=TOL_NET_REL)
     eng.close()
