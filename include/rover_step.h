@@ -279,7 +279,9 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        2 = AS SHIPPED: (1) plus every operation of ray_casting.py:31-59 rounded to fp16 the way ATen's Half kernels do,
  *        and fp16 collision thresholds (rover.py:667-668).  Bit-identical to the as-shipped reference on ray origins,
  *        distances, collision mask and done flags (ray-cast variants 2 and 3).
- * name = "bin_low_bits": width of the low digit of the ray bucket sort, 8..12 (default 10).
+ * name = "bin_low_bits": width of the low digit of the ray bucket sort (2^bits map cells per bucket), 8..12, or 0 (default) = chosen by
+ *        the library: 10, raised while that gives more than 4 096 buckets, lowered (to 8 at most) when that lets a sort entry fit one
+ *        dword (num_envs x padded rays per env <= 2^(32 - bits)).  Results do not depend on it.
  * name = "raycast_early_out": 1 (default) = the binned kernel drops a whole packed pair of triangles per lane (the far half
  *        of a cell's K-nearest list; on the rocks map also the near half) when a conservative test on the numerators shows that
  *        every triangle of it fails the barycentric test; results are bit-identical with 0 (A/B and tests).

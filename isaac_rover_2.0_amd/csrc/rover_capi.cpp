@@ -71,7 +71,8 @@ struct rover_ctx {
     uint32_t* d_bins = nullptr;         // [E*R8] bin key per slot
     uint32_t* d_bkt_table = nullptr;    // [n_buckets * n_blocks] counts -> offsets
     uint2* d_pairs = nullptr;           // [E*R8] (bin, slot) after the coarse partition
-    uint32_t low_bits = 10;             // option "bin_low_bits"
+    uint32_t low_bits = 10;             // bins per sort bucket = 2^low_bits, in force (alloc_bins)
+    uint32_t low_bits_opt = 0;          // option "bin_low_bits": 0 = chosen by the library, else 8..12
     int precision = 0;                  // option "ray_precision": 0 fp32 mode, 1 fp16 sources, 2 as shipped (fp16 maths)
     uint32_t* d_block_sums = nullptr;   // [4096] bucket totals + [4097] bucket starts
     uint32_t* d_sorted = nullptr;       // [E*R8] ray slots sorted by (map, cell)
@@ -196,7 +197,17 @@ static int alloc_bins(rover_ctx* c) {
     const uint64_t nb = (uint64_t)c->map[0].X * c->map[0].Y + (uint64_t)c->map[1].X * c->map[1].Y;
     if (nb > 0xfffffffeull) return fail(c, ROVER_E_INVALID, "too many map cells for ray binning");
     c->n_bins = (uint32_t)nb;
+    c->low_bits = c->low_bits_opt ? c->low_bits_opt : 10u;
     while (c->low_bits < 12u && bucket_count(c) > 4096u) ++c->low_bits;
+    if (!c->low_bits_opt && c->have_dist) {
+        // One-dword sort entries (low bin bits | slot id) need n_slots <= 2^(32 - low_bits).  A dense ray set that misses that at 1 024 bins
+        // per bucket (65 536 envs x 152 slots: 24 bits of slot id) sorts faster with fewer bins per bucket and packed entries than with
+        // two-dword entries (configs[4]: the four sort passes 158 -> 110 us) — as long as the buckets stay <= 4 096.
+        const uint64_t n_slots = (uint64_t)c->cfg.num_envs * c->R8;
+        uint32_t lb = c->low_bits;
+        while (lb > 8u && n_slots > (1ull << (32u - lb)) && ((c->n_bins + (1u << (lb - 1u)) - 1u) >> (lb - 1u)) <= 4096u) --lb;
+        if (n_slots <= (1ull << (32u - lb))) c->low_bits = lb;
+    }
     if (!c->d_block_sums) HIP_TRY(c, hipMalloc((void**)&c->d_block_sums, (2 * 4096 + 8) * sizeof(uint32_t)));   // bucket totals + bucket starts
     if (c->have_dist) {                                   // table size depends on E*R8 too
         dfree(c->d_bkt_table);
@@ -374,7 +385,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
-    if (const char* v = getenv("ROVER_BIN_LOW_BITS")) { int b = atoi(v); if (b >= 8 && b <= 12) c->low_bits = (uint32_t)b; }
+    if (const char* v = getenv("ROVER_BIN_LOW_BITS")) { int b = atoi(v); if (b >= 8 && b <= 12) c->low_bits_opt = (uint32_t)b; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
     DeviceGuard guard(cfg->device);
     e = guard.err;
@@ -1214,8 +1225,8 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         return alloc_cull_queue(c);
     }
     if (!strcmp(name, "bin_low_bits")) {
-        if (value < 8 || value > 12) return fail(c, ROVER_E_INVALID, "bin_low_bits must be in [8, 12]");
-        c->low_bits = (uint32_t)value;
+        if (value != 0 && (value < 8 || value > 12)) return fail(c, ROVER_E_INVALID, "bin_low_bits must be 0 (chosen by the library) or in [8, 12]");
+        c->low_bits_opt = (uint32_t)value;
         return alloc_bins(c);
     }
     if (!strcmp(name, "raycast_early_out")) {
