@@ -591,6 +591,7 @@ def run_rank(args):
             line["cull"] = {"candidate_pairs_per_ray": ci["pairs_per_ray"], "rays_with_both_tests": ci["rays_both_tests"] / max(ci["rays"], 1),
                             "rays_per_bin": ci["rays"] / max(ci["bins"], 1), "max_pairs_per_run": ci["max_pairs_per_run"],
                             "rays_far_skipped": ci["rays_far_skipped"] / max(ci["rays"], 1),
+                            "rays_not_scanned": ci["rays_not_scanned"] / max(ci["rays"], 1),
                             "always_candidate_triangles": ci["always_candidate_triangles"], "cells_without_cone": ci["cells_without_cone"],
                             "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"],
                             "cells_with_far_bound": ci["cells_with_far_bound"], "far_records_on_demand": bool(ci["far_records_on_demand"])}

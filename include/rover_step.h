@@ -324,6 +324,7 @@ typedef struct {
     uint64_t rays_far_skipped;     /* rays whose scan skipped the farther half of their cell's triangles (proved clear as a group) */
     int64_t cells_with_far_bound[2];  /* per map: cells whose far bound is wide enough to hold for a usual ray (f32 proof tables) */
     uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them */
+    uint64_t rays_not_scanned;        /* rays that cleared BOTH halves of their cell's triangles as groups (no candidate: the distance is the miss value) */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -479,11 +479,11 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 32u;
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u;
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
-            (e = hipMalloc((void**)&d_far, n_cells * 32u)) != hipSuccess || (e = hipMalloc((void**)&d_far_h, n_cells * 32u)) != hipSuccess ||
+            (e = hipMalloc((void**)&d_far, n_cells * 48u)) != hipSuccess || (e = hipMalloc((void**)&d_far_h, n_cells * 48u)) != hipSuccess ||
             (e = hipMalloc((void**)&d_nz, (uint64_t)T_int * sizeof(float))) != hipSuccess ||
             (e = hipMalloc((void**)&d_cnt, 8 * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_order, (uint64_t)T_int * sizeof(uint32_t))) != hipSuccess ||
@@ -663,6 +663,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     const CullProofH ph = cull_proof_h(c->cull_eta_h);
     a.c_a_h = ph.c_a; a.tau2_h = ph.tau2;
     a.far0 = h ? c->cull_far_h[0] : c->cull_far[0]; a.far1 = h ? c->cull_far_h[1] : c->cull_far[1];
+    a.near0 = a.far0 + 2ull * (uint64_t)c->cull_cells[0]; a.near1 = a.far1 + 2ull * (uint64_t)c->cull_cells[1];
     a.k2_far = cull_far_k2(a.half, ph);
     // few rays per (map, cell) bin: most bins have no ray that tests the far pairs, and setting them up lazily halves a bin's set-up
     // (32 768 envs x 63 rays 69.7 -> 76 M env-steps/s, 4 096 envs 26.9 -> 30 M; with 146 rays per env a bin holds 14 rays, nearly every
@@ -983,7 +984,7 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
     std::vector<uint4> h(c->cull_stat_slots);
     HIP_TRY(c, hipMemcpy(h.data(), c->d_cull_stats, h.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (const uint4& v : h) {
-        out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z; out->bins += v.w;
+        out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z & 0xffu; out->rays_not_scanned += v.z >> 8; out->bins += v.w;
         out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
     }
     return ROVER_OK;

@@ -386,25 +386,31 @@ __global__ void __launch_bounds__(256) idx4_build_kernel(const int32_t* __restri
 // direction at angle beta from the vertical and a triangle with decoded centre m, r2:  c_a |h|^2 - (h.d)^2 = c_a W^2 - (dd - c_a) a^2
 // (W: distance from m to the ray's line, a: the axial part of h, dd >= |d|^2), W >= cos(beta) (dist_xy(m, C) - e), e = dist_xy(s, C) +
 // |s_z - m_z| tan(beta) (the line's offset from the cell's centre C at the height of m), |h| <= hmax.  So test (A) holds for EVERY
-// far triangle if  min_t (dist_xy(m_t, C) - k1 sqrt(r2_t))  >  e_max + k2 hmax  with k1 = 1 / (0.9 sqrt(c_a)), k2 = sqrt(dd - c_a) k1 and
+// far triangle if  min_t (dist_xy(m_t, C) - k1 sqrt(r2_t))  >  e_max + k2 a_max  with k1 = 1 / (0.9 sqrt(c_a)), k2 = sqrt(dd - c_a) k1, a_max >= |a| and
 // cos(beta) >= 0.9.  The record holds the left side G (-inf if a far triangle is always a candidate, +inf if slot 1 is empty), the z
 // range of the far centres, the largest dist_xy(m_t, C) and C.
+// The same bound for the NEAR pairs (slot 0): a ray that clears both sets on the cone path has no candidate at all in this cell — most
+// rock rays (the nearest rock triangle of most cells is decimetres to metres away) — and is not scanned; a bin whose rays all do is never set up.
 struct FarRec { float G, z0, z1, rho_out, cx, cy; uint32_t q16, pad1; };    // q16: the cell's normal cone (qrow), here so that the scan's prologue needs one gather
+// (the near bounds {G, z0, z1, rho} are a table of their own behind the n_cells far records: only one of the scan kernels reads them, and
+//  48-byte records cost the others 0.5-1.5 %)
 __global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__ idx4, const uint4* __restrict__ ctab, uint64_t n_cells, uint32_t K8,
                                                         uint32_t Y, float cell_size, float shift_x, float shift_y, float k1, float tau2,
-                                                        const uint32_t* __restrict__ qrow, FarRec* __restrict__ out,
+                                                        const uint32_t* __restrict__ qrow, FarRec* __restrict__ out, float4* __restrict__ out_near,
                                                         uint32_t* __restrict__ n_useful /* cells whose bound can hold for a usual ray, or null */) {
     const uint64_t cell = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u, L = K8 >> 2;
     if (cell >= n_cells) return;
     const float ccx = (float)(cell / Y) * cell_size + shift_x, ccy = (float)(cell % Y) * cell_size + shift_y;
-    float G = __builtin_inff(), z0 = __builtin_inff(), z1 = -__builtin_inff(), ro = 0.0f;
+    // set 0: the far pairs (slot 1 of every lane), set 1: the near pairs (slot 0)
+    float G[2] = {__builtin_inff(), __builtin_inff()}, z0[2] = {__builtin_inff(), __builtin_inff()}, z1[2] = {-__builtin_inff(), -__builtin_inff()}, ro[2] = {0.0f, 0.0f};
     if (lane < L) {
         const int4 id4 = idx4[cell * L + lane];
-        const int32_t ids[2] = {id4.z, id4.w};
+        const int32_t ids[4] = {id4.z, id4.w, id4.x, id4.y};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
             if (ids[j] < 0) continue;
+            const int q = j >> 1;
             const uint4 r = ctab[ids[j]];
             const f2 zn = cvt2(r.z), w = cvt2(r.w);
             const float mx = __uint_as_float(r.x), my = __uint_as_float(r.y), mz = zn.x;
@@ -412,19 +418,23 @@ __global__ void __launch_bounds__(256) far_build_kernel(const int4* __restrict__
             const float dxy = sqrtf((mx - ccx) * (mx - ccx) + (my - ccy) * (my - ccy));
             float g = (dxy - k1 * sqrtf(r2) * 1.00001f) * 0.99999f - 1.0e-6f;
             if (!(g == g) || !(r2 < 3.0e38f)) g = -__builtin_inff();        // always a candidate / broken: never skipped
-            G = fminf(G, g); z0 = fminf(z0, mz); z1 = fmaxf(z1, mz); ro = fmaxf(ro, dxy);
+            G[q] = fminf(G[q], g); z0[q] = fminf(z0[q], mz); z1[q] = fmaxf(z1[q], mz); ro[q] = fmaxf(ro[q], dxy);
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        G = fminf(G, __shfl_xor(G, off)); z0 = fminf(z0, __shfl_xor(z0, off)); z1 = fmaxf(z1, __shfl_xor(z1, off)); ro = fmaxf(ro, __shfl_xor(ro, off));
-    }
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            G[q] = fminf(G[q], __shfl_xor(G[q], off)); z0[q] = fminf(z0[q], __shfl_xor(z0[q], off)); z1[q] = fmaxf(z1[q], __shfl_xor(z1[q], off));
+            ro[q] = fmaxf(ro[q], __shfl_xor(ro[q], off));
+        }
     if (lane == 0u) {
-        out[cell] = FarRec{G, z0, z1, ro, ccx, ccy, qrow[cell], 0u};
+        out[cell] = FarRec{G[0], z0[0], z1[0], ro[0], ccx, ccy, qrow[cell], 0u};
+        out_near[cell] = make_float4(G[1], z0[1], z1[1], ro[1]);
         // A ray's side of the inequality is its line's offset from the cell's centre at the far centres' height — 0.1-0.15 m for a
         // heightmap ray of a rover on gentle ground — plus k2 hmax: cells with G under 0.2 m hardly ever skip (rover_capi.cpp: cull_args
         // picks the kernel that fetches the far records with the near ones when most cells are like that)
-        if (n_useful && G >= 0.2f) atomicAdd(n_useful, 1u);
+        if (n_useful && G[0] >= 0.2f) atomicAdd(n_useful, 1u);
     }
 }
 
@@ -562,7 +572,7 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
         uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
-        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h, const float4 *__restrict__ far0, const float4 *__restrict__ far1, float k2_far
+        const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h, const float4 *__restrict__ far0, const float4 *__restrict__ far1, float k2_far, const float4 *__restrict__ near0, const float4 *__restrict__ near1
 
 // LAZY: the far pairs of a bin (slot 1) are gathered and unpacked only if one of its rays tests them — a second, dependent round of
 // gathers in the bins that do, half the set-up in the bins that do not (most of them when a bin holds few rays).
@@ -613,7 +623,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
     wave_lds_sync();
     bk[lane] = fkey(RAY_MISS);                 // 11.0 where a ray has no candidate at all (a culled triangle contributes exactly that)
-    uint32_t ctot = 0, n_both = 0, n_bins = 0, n_fskip = 0; // queue entries / rays that ran both tests / bins walked / rays that skipped the far pairs (rover_get_cull_info)
+    uint32_t ctot = 0, n_both = 0, n_bins = 0, n_fskip = 0, n_askip = 0; // queue entries / rays that ran both tests / bins walked / rays that skipped the far pairs / rays not scanned at all (rover_get_cull_info)
     uint32_t r_next = 0;                       // first ray of the run that is not scanned yet
     // One SEGMENT = scan rays [r_next, ...) until the run ends or the queue region could overflow with one more ray, then the exact
     // arithmetic on the entries.  Nearly every run is one segment (a run of 64 terrain rays queues ~500 entries).  Everything a
@@ -648,20 +658,46 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float4 fb = fr[1];                                                  // {Cx, Cy, q16, -}
     const uint64_t conemask = __builtin_amdgcn_ballot_w64(__float_as_uint(fb.z) >= (rflags >> 16));
     if (r_next == 0u) n_both += (uint32_t)__builtin_popcountll(~conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
-    uint64_t farskip = 0;
+    // skipall bit i: ray i clears the NEAR pairs as well, on the cone path: no candidate in this cell, not scanned.  In the kernel of small
+    // ray sets on regular meshes only (SKIP = LAZY: a quarter of the rays there, mostly rock rays; where few rays qualify — 1 % on the
+    // irregular mesh, 12 % with 120 rays — walking the live rays through bit masks cost more than it saved: -6 % / -1.5 %).
+    constexpr bool SKIP = LAZY != 0;
+    uint64_t farskip = 0, skipall = 0;
     if (!H) {
-        const float4 fa = fr[0];                                              // {G, z0, z1, rho_out}
+        const float4 fa = fr[0];                                              // {G, z0, z1, rho_out} of the far pairs
         // (hardware square roots, 1 ulp, and no division — the inequality is multiplied through by |d_z| — the margins are 1e-4)
         const float ox = rsa.x - fb.x, oy = rsa.y - fb.y, o = __builtin_amdgcn_sqrtf(ox * ox + oy * oy);
         const float dzm = fmaxf(fabsf(rsa.z - fa.y), fabsf(rsa.z - fa.z));
         const float dxy2 = rsb.x * rsb.x + rsb.y * rsb.y, adz = fabsf(rsb.z);
         const bool steep = adz * adz >= 0.81f * (dxy2 + adz * adz) * 1.0001f;  // cos(beta) >= 0.9
         const float e_adz = o * adz + dzm * __builtin_amdgcn_sqrtf(dxy2) * 1.0001f;                      // e_max |d_z|
-        const float hmax = __builtin_amdgcn_sqrtf((o + fa.w) * (o + fa.w) + dzm * dzm) * 1.00001f;
-        farskip = __builtin_amdgcn_ballot_w64(steep && (fa.x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * hmax * adz) * 1.0001f);
+        // |a| = |h . d| / |d| <= |h_z| |d_z| + |h_xy| |d_xy| (tighter than |h| for the triangles far out: the ray is steep)
+        const float dxy1 = __builtin_amdgcn_sqrtf(dxy2) * 1.0001f;
+        const float amax = (dzm * adz + (o + fa.w) * dxy1) * 1.0001f;
+        farskip = __builtin_amdgcn_ballot_w64(steep && (fa.x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * amax * adz) * 1.0001f);
+        if (SKIP) {     // the same inequality for the near pairs, with their own G, z range and largest distance
+            const float4 fn = (kmap ? near1 : near0)[kcell];
+            const float dzm_n = fmaxf(fabsf(rsa.z - fn.y), fabsf(rsa.z - fn.z));
+            const float e_adz_n = o * adz + dzm_n * __builtin_amdgcn_sqrtf(dxy2) * 1.0001f;
+            const float amax_n = (dzm_n * adz + (o + fn.w) * dxy1) * 1.0001f;
+            skipall = farskip & conemask &
+                      __builtin_amdgcn_ballot_w64(steep && (fn.x * 0.9999f - 1.0e-5f) * adz > (e_adz_n + k2_far * amax_n * adz) * 1.0001f);
+        }
     }
-    if (r_next == 0u) n_fskip += (uint32_t)__builtin_popcountll(farskip & conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
-    uint64_t hm = (heads | (1ull << r_next)) & (~0ull << r_next);        // bins of the segment (its first ray opens one)
+    const uint64_t runmask = n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull);
+    if (r_next == 0u) { n_fskip += (uint32_t)__builtin_popcountll(farskip & conemask & runmask); n_askip += (uint32_t)__builtin_popcountll(skipall & runmask); }
+    // the rays of the segment that are scanned at all, and its bins: the segment's first ray opens one; bins without a live ray are
+    // dropped here — no id row is requested for them, no record gathered
+    const uint64_t live = ~skipall & runmask & (~0ull << r_next);
+    const uint64_t hm_all = (heads | (1ull << r_next)) & (~0ull << r_next);
+    uint64_t hm = SKIP ? 0ull : hm_all;
+    for (uint64_t tt = SKIP ? hm_all : 0ull; tt;) {
+        const uint32_t b0 = (uint32_t)__builtin_ctzll(tt);
+        tt &= tt - 1ull;
+        const uint32_t b1 = tt ? (uint32_t)__builtin_ctzll(tt) : n_run;
+        const uint64_t bm = (b1 >= 64u ? ~0ull : ((1ull << b1) - 1ull)) & (~0ull << b0);
+        if (live & bm) hm |= 1ull << b0;
+    }
     n_bins += (uint32_t)__builtin_popcountll(hm);
     uint64_t pf_heads = hm;                    // bins whose row is not requested yet
     uint32_t pf_n = 0, use_n = 0;              // rows requested / consumed so far (slot = count % CULL_RING)
@@ -685,12 +721,18 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         a4 = rp[0]; b4 = rp[1];
     };
     float4 nxa, nxb;
-    load_ray(r_next, nxa, nxb);
+    load_ray(live ? (uint32_t)__builtin_ctzll(live) : r_next, nxa, nxb);       // the segment's first live ray
     bool full = false;
     while (hm && !full) {                      // one (map, cell) bin of the run: rays [i, i_end)
         const uint32_t i = (uint32_t)__builtin_ctzll(hm);
         hm &= hm - 1ull;
-        const uint32_t i_end = hm ? (uint32_t)__builtin_ctzll(hm) : n_run;
+        uint32_t i_end;
+        if (SKIP) {                                                         // (the bin ends at the next head of the run, live or not)
+            const uint64_t heads_above = hm_all & (~1ull << i);
+            i_end = heads_above ? (uint32_t)__builtin_ctzll(heads_above) : n_run;
+        } else {
+            i_end = hm ? (uint32_t)__builtin_ctzll(hm) : n_run;
+        }
         const uint32_t map = (uint32_t)__builtin_amdgcn_readlane((int)rowm, (int)i) & 1u;
         // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -701,7 +743,8 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         const uint4* ct = map ? ctab1 : ctab0;
         // does any ray of this bin test the FAR pairs (slot 1)?  (off the cone path always, on it unless its far-skip bit is set)
         const uint64_t binmask = (i_end >= 64u ? ~0ull : ((1ull << i_end) - 1ull)) & (~0ull << i);
-        const bool need1 = !LAZY || (~(farskip & conemask) & binmask) != 0ull;
+        uint64_t todo = SKIP ? live & binmask : binmask;                    // the bin's rays that are scanned (at least one)
+        const bool need1 = !LAZY || (~(farskip & conemask) & todo) != 0ull;
         uint4 rec[4];
 #pragma unroll
         for (int jj = 0; jj < (LAZY ? 2 : 4); ++jj) rec[jj] = ct[id[jj] < 0 ? 0 : id[jj]];
@@ -740,10 +783,21 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         asm volatile("" :: "v"(t.mx[0]), "v"(t.mx[1]), "v"(t.nz[0]), "v"(t.nz[1]), "v"(t.r2[0]), "v"(t.r2[1]) : "memory");
         if (pf_heads) { wave_lds_sync(); prefetch_row(); }              // into the slot just read (the ids are in registers)
         uint32_t r = i;
-        for (; r < i_end; ++r) {
+        for (;;) {
+            // the next ray of the bin: the next live one through the mask (SKIP), or simply the next
+            if (SKIP) {
+                if (!todo) break;
+                r = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+            } else if (r >= i_end) break;
             // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
             const float4 ra = nxa, rb = nxb;
-            load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
+            if (SKIP) {
+                const uint64_t later = live & (~1ull << r);                 // the next live ray, of this bin or a later one
+                load_ray(later ? (uint32_t)__builtin_ctzll(later) : r, nxa, nxb);
+            } else {
+                load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
+            }
             const sgpr2 sxy = sgpr_pair(ra.x, ra.y), szc = sgpr_pair(ra.z, ra.w), dxy = sgpr_pair(rb.x, rb.y), dzf = sgpr_pair(rb.z, rb.w);
             uint64_t any[2];
             const bool cone = (conemask >> r) & 1ull;                                   // (B) holds for every triangle of the cell
@@ -784,11 +838,13 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
                     }
                 }
                 // the next ray could add 128 more: finish what is queued first (rare: > 14 candidate pairs per ray over a whole run)
-                if (cused > CULL_QCAP - 128u) { full = true; ++r; break; }
+                if (cused > CULL_QCAP - 128u) { full = true; if (!SKIP) ++r; break; }
             }
+            if (!SKIP) ++r;
         }
-        r_next = r;
+        r_next = SKIP ? r + 1u : r;            // (a full queue: the next segment starts behind the last ray scanned)
     }
+    if (!full) r_next = n_run;                 // every live ray of the run is scanned (what is left, if anything, clears its whole cell)
     // PHASE 2 on the wave's own entries.  They were stored to global memory by this wave and are read back by this wave, and no
     // other wave ever touches the region: a wave sees its own stores in program order, so waiting for their acknowledgement is all
     // the ordering that takes.  An agent-scope fence here writes back the whole L2 of the XCD: 3.7 ms instead of 0.6.
@@ -801,7 +857,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     wave_lds_sync();
     if (lane < n_run) out[gid] = funkey(bk[lane]);
     // per-wave counters of THIS launch (plain stores, 16 B per wave; summed on the host by rover_get_cull_info)
-    if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both, n_bins);
+    if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins);
     }
 }
 
@@ -845,10 +901,10 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
     float k1, k2;
     cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab, n_cells, K8, Y,
-                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, qrow, reinterpret_cast<FarRec*>(far), counts + 4);
+                       cell_size, shift_x, shift_y, k1, CullK<0>::tau2, qrow, reinterpret_cast<FarRec*>(far), far + 2ull * n_cells, counts + 4);
     cull_far_consts(ph.c_a, 1.004, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab_h, n_cells, K8, Y,
-                       cell_size, shift_x, shift_y, k1, ph.tau2, qrow_h, reinterpret_cast<FarRec*>(far_h), (uint32_t*)nullptr);
+                       cell_size, shift_x, shift_y, k1, ph.tau2, qrow_h, reinterpret_cast<FarRec*>(far_h), far_h + 2ull * n_cells, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -899,7 +955,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
-                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h, a.far0, a.far1, a.k2_far);
+                           reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h, a.far0, a.far1, a.k2_far, a.near0, a.near1);
     }
     return hipGetLastError();
 }

@@ -73,6 +73,7 @@ struct CullArgs {
     int half;                    // the exact phase runs the reference's as-shipped fp16 arithmetic (ctab / qrow are then that proof's tables)
     float c_a_h, tau2_h;         // test constants of that proof (CullProofH)
     const float4 *far0, *far1;   // [cell][2]: the bound of the cell's far pairs (FarRec, rover_cull.hip) for the proof in force
+    const float4 *near0, *near1; // [cell]: the same bound for the cell's near pairs (behind the far records in the same allocation)
     float k2_far;                // and the ray-side constant of the far skip
     int lazy_far;                // set up a bin's far pairs only when one of its rays tests them (few rays per bin)
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}

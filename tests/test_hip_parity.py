@@ -428,6 +428,37 @@ def _ray_sort_layouts(n):
                 np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} bin_low_bits={low_bits}")
 
 
+def test_rays_that_clear_their_cell_are_not_scanned():
+    """The on-demand scan kernel (small ray sets, regular meshes) does not scan rays that provably clear BOTH halves of their cell's
+    triangles — most rock rays — and drops bins without a live ray; the other kernel scans everything.  Same bits either way."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 8192
+    scene = synth.make_scene(n_cells=160, k=40, n_stones=24)
+    distn = synth.ray_distribution("37")
+    st = synth.make_states(n, 16.0, seed=5)
+    outs, infos = {}, {}
+    for lazy in ("1", "0"):
+        os.environ["ROVER_CULL_LAZY"] = lazy
+        try:
+            eng = make_engine(scene, distn, n, variant=3)
+        finally:
+            os.environ.pop("ROVER_CULL_LAZY", None)
+        outs[lazy] = hip_step(eng, st)
+        infos[lazy] = eng.cull_info()
+        eng.close()
+    eng = make_engine(scene, distn, n, variant=1)
+    ref = hip_step(eng, st)
+    eng.close()
+    for lazy in outs:
+        for key in ref:
+            np.testing.assert_array_equal(outs[lazy][key], ref[key], err_msg=f"{key} lazy={lazy}")
+    assert infos["1"]["far_records_on_demand"] == 1 and infos["0"]["far_records_on_demand"] == 0
+    assert infos["1"]["rays_not_scanned"] > 0.1 * infos["1"]["rays"], infos["1"]
+    assert infos["0"]["rays_not_scanned"] == 0
+    assert infos["1"]["bins"] < infos["0"]["bins"]
+
+
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the culled kernel above (the binned one
     whenever the as-shipped fp16 maths are asked for); K8 > 256 always falls back to the env-order kernel."""

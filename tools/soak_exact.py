@@ -44,6 +44,30 @@ def run_engines(engs, st, P):
     return outs
 
 
+def make_engine(name):
+    """"culled" is the scan kernel the library picks for the scene and ray set; "culled_other" the other one (far records on demand +
+    rays that clear their whole cell not scanned, or neither), forced through the experiment variable read at rover_create."""
+    if name != "culled_other":
+        return _lib.Engine(E, device=0)
+    probe = _lib.Engine(E, device=0)
+    return probe            # (the choice needs the scene: set below, see other_kernel())
+
+
+def other_kernel(engs, scene, distn):
+    """Re-create engs["culled_other"] with the scan kernel "culled" did NOT get."""
+    lazy = engs["culled"].cull_info()["far_records_on_demand"]
+    engs["culled_other"].close()
+    os.environ["ROVER_CULL_LAZY"] = "0" if lazy else "1"
+    try:
+        e = _lib.Engine(E, device=0)
+    finally:
+        os.environ.pop("ROVER_CULL_LAZY", None)
+    e.set_scene(scene, distn)
+    e.set_option("raycast_variant", 3); e.set_option("raycast_early_out", 1); e.set_option("ray_precision", 0)
+    assert e.cull_info()["far_records_on_demand"] != lazy
+    engs["culled_other"] = e
+
+
 irr_total = 0
 from isaac_rover_amd import assets
 for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1.2, 0.0375, "120"), (12, 64, 30.0, 60, 3.0, 0.05, "37"),
@@ -58,12 +82,13 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
     distn = synth.ray_distribution(dist_name)
     P = distn[0].shape[0]
     engs = {}
-    for name, (variant, early, prec) in {"culled": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
+    for name, (variant, early, prec) in {"culled": (3, 1, 0), "culled_other": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
                                          "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2)}.items():
-        e = _lib.Engine(E, device=0)
+        e = make_engine(name)
         e.set_scene(scene, distn)
         e.set_option("raycast_variant", variant); e.set_option("raycast_early_out", early); e.set_option("ray_precision", prec)
         engs[name] = e
+    other_kernel(engs, scene, distn)
     print(f"irregular seed {seed}: {scene.terrain.triangles.shape[0]} triangles ({scene.rocks.triangles.shape[0]} on rocks), K={k}, {extent} m", flush=True)
     for r in range(irr_rounds):
         st = synth.make_states(E, extent, seed=7000 + 100 * seed + r, heightfn=zf, margin_m=0.5)
@@ -80,29 +105,30 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
             st["pos"][:, 0] = torch.from_numpy(x).float(); st["pos"][:, 1] = torch.from_numpy(y).float()
             st["pos"][:, 2] = torch.from_numpy(zf(x, y)).float() + 0.3
         outs = run_engines(engs, st, P)
-        compare(outs, (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"), ("h_culled", "h_noearly")),
+        compare(outs, (("culled", "envorder"), ("culled_other", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"), ("h_culled", "h_noearly")),
                 f"irregular seed={seed} K={k} round={r}")
         ci = engs["culled"].cull_info()
         irr_total += E * (P + 26)
         hit = float((outs["binned"][0] < 11.0).float().mean())
         print(f"irregular seed {seed} round {r}: ok, terrain hit rate {hit:.3f}, candidate pairs / ray {ci['pairs_per_ray']:.2f} (max per run {ci['max_pairs_per_run']}), "
-              f"rays with both tests {ci['rays_both_tests'] / ci['rays']:.3f}, always-candidate triangles {ci['always_candidate_triangles']}, "
+              f"rays with both tests {ci['rays_both_tests'] / ci['rays']:.3f}, not scanned {engs['culled_other'].cull_info()['rays_not_scanned'] / ci['rays']:.3f} (forced kernel), always-candidate triangles {ci['always_candidate_triangles']}, "
               f"cells without cone {ci['cells_without_cone']}", flush=True)
     for e in engs.values():
         e.close()
 if irr_rounds > 0:
-    print(f"irregular soak ok: {irr_total / 1e6:.1f} M rays x 6 comparisons on irregular meshes, all bit-identical", flush=True)
+    print(f"irregular soak ok: {irr_total / 1e6:.1f} M rays x 7 comparisons on irregular meshes, all bit-identical", flush=True)
 
 for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"), (16, 128, "9")):
     scene = synth.make_scene(n_cells=cells, k=k, n_stones=max(8, cells * cells // 400), device="cuda")
     distn = synth.ray_distribution(dist_name)
     engs = {}
-    for name, (variant, early, prec) in {"culled": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
+    for name, (variant, early, prec) in {"culled": (3, 1, 0), "culled_other": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
                                          "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2)}.items():
-        e = _lib.Engine(E, device=0)
+        e = make_engine(name)
         e.set_scene(scene, distn)
         e.set_option("raycast_variant", variant); e.set_option("raycast_early_out", early); e.set_option("ray_precision", prec)
         engs[name] = e
+    other_kernel(engs, scene, distn)
     P = distn[0].shape[0]
     for r in range(rounds):
         st = synth.make_states(E, cells * 0.1, seed=1000 * k + r)
@@ -123,8 +149,8 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
             e.step(sin, e.make_out(obs, **bufs), increment_progress=False)
             torch.cuda.synchronize()
             outs[name] = (bufs["ray_dist"], bufs["wheel_dist"], bufs["body_dist"], bufs["rock_collision"], bufs["reset"])
-        for a, b in (("culled", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"),
-                     ("h_culled", "h_noearly")):
+        for a, b in (("culled", "envorder"), ("culled_other", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"),
+                     ("h", "h_noearly"), ("h_culled", "h_noearly")):
             for x, y, what in zip(outs[a], outs[b], ("ray", "wheel", "body", "coll", "reset")):
                 same = torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all())
                 if not same:
@@ -132,7 +158,8 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
                     raise SystemExit(f"MISMATCH {a} vs {b} {what} K={k} round={r}: {bad.tolist()} {x[tuple(bad[0])]} {y[tuple(bad[0])]}")
         total += E * (P + 26)
         hit = float((outs["binned"][0] < 11.0).float().mean())
-        print(f"K={k} round {r}: ok, terrain hit rate {hit:.3f}", flush=True)
+        ns = max(engs[n].cull_info()["rays_not_scanned"] for n in ("culled", "culled_other")) / (E * (P + 26))
+        print(f"K={k} round {r}: ok, terrain hit rate {hit:.3f}, rays not scanned (on-demand kernel) {ns:.3f}", flush=True)
     for e in engs.values():
         e.close()
-print(f"soak ok: {total / 1e6:.1f} M rays x 6 comparisons, all bit-identical")
+print(f"soak ok: {total / 1e6:.1f} M rays x 7 comparisons, all bit-identical")
