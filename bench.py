@@ -290,6 +290,14 @@ def _lib_version():
         return ""
 
 
+def _lib_matches_tree():
+    try:
+        from isaac_rover_amd import _lib
+        return _lib.version().endswith("src-" + _lib.source_hash())
+    except Exception:
+        return None
+
+
 def _gpu_event():
     """A timing event on the current stream, or None without a GPU (the CPU stand-in of tests/test_host_logic.py)."""
     import torch
@@ -585,6 +593,7 @@ def run_rank(args):
             "backend": dist.get_backend() if world > 1 else None,
             "roofline": roofline(args, E, n_rays, prof, info, _lib_version()),
             "lib": _lib_version(),
+            "lib_built_from_tree": _lib_matches_tree(),      # false: the .so was built from other sources than the ones next to it
         }
         if info.raycast_variant == 3:
             ci = eng.cull_info()

@@ -15,6 +15,9 @@ rm -rf "$P"; mkdir -p "$P"
 cp profiles/valu.json profiles/traffic.json "$OUT"/ 2>/dev/null
 LIB=$(python3 -c "import sys; sys.path.insert(0, '.'); from isaac_rover_amd import _lib; print(_lib.version())")
 echo "profiling $LIB"
+# the library must be the one the sources in the tree build (an A/B session leaves an experiment's .so in csrc/): refuse otherwise
+python3 -c "import sys; sys.path.insert(0, '.'); from isaac_rover_amd import _lib; sys.exit(0 if _lib.version().endswith('src-' + _lib.source_hash()) else 1)" \
+  || { echo "librover_step.so was not built from the sources in the tree: run csrc/build.sh first"; exit 1; }
 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1       # builds the scene cache
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprof.json" 2> $P/stats.err
 
