@@ -251,7 +251,7 @@ ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_
 
 /* Two 2-layer chains over the SAME M rows — the two encoders of the actor / critic (learning/model.py:188-190: sparse and dense
  * heightmap slices of one obs row; neither depends on the other) — and, optionally, the copy of the proprioception columns into the
- * concat buffer (:191: dst[r][0:copy_cols] = src[r][0:copy_cols]; copy_cols = 0: none).  Small batches (M < 16 384, both chains of
+ * concat buffer (:191: dst[r][0:copy_cols] = src[r][0:copy_cols]; copy_cols = 0: none).  Small batches (M < 20 480, both chains of
  * the same built tile shape) run the two side by side: ONE launch for both first layers (split along k), one for both second layers
  * and the copy — a third of the actor forward's launches at the reference's default numEnvs 512 (cfg/task/Rover.yaml:11).  Otherwise
  * the chains run one after the other.  Results are those of two rover_mlp_chain_forward calls either way. */
@@ -323,7 +323,7 @@ typedef struct {
     uint64_t launches_per_step;    /* 1, unless the queue budget ("cull_queue_mb") forces a step's ray cast into slices */
     uint64_t rays_far_skipped;     /* rays whose scan skipped the farther half of their cell's triangles (proved clear as a group) */
     int64_t cells_with_far_bound[2];  /* per map: cells whose far bound is wide enough to hold for a usual ray (f32 proof tables) */
-    uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them */
+    uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them, and does not scan rays that clear their whole cell (rays_not_scanned) */
     uint64_t rays_not_scanned;        /* rays that cleared BOTH halves of their cell's triangles as groups (no candidate: the distance is the miss value) */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);

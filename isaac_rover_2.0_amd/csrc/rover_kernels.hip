@@ -1579,7 +1579,10 @@ hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_va
             hipLaunchKernelGGL((bucket_sort_kernel<PK, 512, 32>), dim3(n_buckets), dim3(512), sort_lds, s, pairs, bucket_base, low_bits, sorted);     \
     } while (0)
     if (big) {      // more than 64 KB of dynamic LDS: the kernel has to be told (once per size)
-        static uint32_t raised[2] = {0, 0};
+        static uint32_t raised_of[64][2] = {};       // per device: the attribute belongs to the function on the current device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        uint32_t* raised = raised_of[dev];
         if (scatter_lds > raised[packed]) {
             const void* f = packed ? reinterpret_cast<const void*>(&bucket_scatter_kernel<true, 1024>) : reinterpret_cast<const void*>(&bucket_scatter_kernel<false, 512>);
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds);

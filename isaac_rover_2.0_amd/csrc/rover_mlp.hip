@@ -541,7 +541,7 @@ size_t chain_splitk_scratch_floats(int M, int K0, int n0) {
     return (size_t)S * (size_t)M * (size_t)(n0 <= 80 ? 80 : 96);
 }
 // (the same nets at every batch size: what the large-batch 2-layer kernel is built for, <= 96 -> <= 64)
-bool chain_wants_splitk(const ChainArgs& a) { return a.n_layers == 2 && a.M < 16384 && a.K0 >= 128 && a.n[0] <= 96 && a.n[1] <= 64; }
+bool chain_wants_splitk(const ChainArgs& a) { return a.n_layers == 2 && a.M < 20480 && a.K0 >= 128 && a.n[0] <= 96 && a.n[1] <= 64; }
 
 static int splitk_tn(const ChainArgs& a) { return a.n[0] <= 80 ? 5 : 6; }
 static SplitkL1 splitk_l1_of(const ChainArgs& a, float* scratch, int* rt) {
@@ -653,7 +653,7 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
     // (the same nets at every batch size: what the large-batch kernel is built for)
     const bool mlp4 = a.n_layers == 4 && a.n[0] <= 256 && a.n[1] <= 160 && a.n[2] <= 128 && a.n[3] <= 16 && cheap(a.act[0]) && cheap(a.act[1]) &&
                       cheap(a.act[2]);
-    if (mlp4 && a.M < 16384 && a.K0 <= 256) {
+    if (mlp4 && a.M < 20480 && a.K0 <= 256) {
         hipLaunchKernelGGL(mlp_small_kernel, dim3((uint32_t)((a.M + 15) / 16)), dim3(512), 0, s, a);      // small batches: latency, not throughput
         return hipGetLastError();
     }

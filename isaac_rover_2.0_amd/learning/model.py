@@ -62,15 +62,15 @@ class HeightmapNet:
     def compute(self, states, fused=None):
         """model.py:185-195 / :231-241.  ``states`` [E, num_observations] float32 (may be the task's obs_buf itself).
         ``fused``: run each encoder and the MLP + head as ONE kernel each (``rover_mlp_chain_forward``: activations stay in
-        registers) — default for batches of >= 16 384 rows when the layer widths fit the built tile shapes; otherwise one
+        registers) — default for batches of >= 20 480 rows when the layer widths fit the built tile shapes; otherwise one
         ``rover_linear_forward`` launch per layer."""
         e = states.shape[0]
         p, ns, nd = self.num_proprioception, self.num_sparse, self.num_dense
         ef = self.encoder0[-1].weight.shape[0]
         cat = self._buf("cat", e, p + 2 * ef)
         if fused is None:
-            fused = True          # encoders: one fused kernel from 16 384 rows, a split-k pair below (the library decides); MLP + head: one kernel
-        if (fused and ns > 0 and nd > 0 and e < 16384 and len(self.encoder0) == 2 and len(self.encoder1) == 2
+            fused = True          # encoders: one fused kernel from 20 480 rows, a split-k pair below (the library decides); MLP + head: one kernel
+        if (fused and ns > 0 and nd > 0 and e < 20480 and len(self.encoder0) == 2 and len(self.encoder1) == 2
                 and self.engine.chain_fits(self.encoder0) and self.engine.chain_fits(self.encoder1)):
             # small batches: both encoders and the proprioception copy side by side, then the MLP + head: 3 launches instead of 6
             self.engine.chain_pair_forward(states[:, p:p + ns], self.encoder0, cat[:, p:p + ef],

@@ -208,9 +208,9 @@ def test_policy_forward_matches_reference_modules(name):
     eng.close()
 
 
-@pytest.mark.parametrize("rows", [1, 17, 512, 4096, 20000])
+@pytest.mark.parametrize("rows", [1, 17, 512, 4096, 20000, 24000])
 def test_encoder_pair_equals_two_chain_calls(rows):
-    """rover_mlp_chain_pair_forward (both encoders + the proprioception copy in one launch per stage below 16 384 rows, one chain
+    """rover_mlp_chain_pair_forward (both encoders + the proprioception copy in one launch per stage below 20 480 rows, one chain
     after the other above) against two rover_mlp_chain_forward calls and a tensor copy: bit-identical."""
     from isaac_rover_amd import _lib
     from isaac_rover_amd.learning.model import HeightmapNet
