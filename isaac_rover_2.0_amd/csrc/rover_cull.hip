@@ -566,6 +566,12 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 // Nothing here is heavy in registers or LDS, so 7-8 waves per SIMD hide the latencies of the id rows (HBM, streamed
 // through LDS CULL_RING bins ahead) and of the record gathers (L2).
 // ---------------------------------------------------------------------------------------------------
+// Waves per hardware workgroup.  The kernel has no workgroup-level synchronisation, and a wave's lifetime depends on where its rays are:
+// with four waves in a workgroup the slots of the three that finish first idle until the fourth is done (a new workgroup needs a free
+// slot on every SIMD) — the resident waves averaged 5.0 per SIMD of the 6 the registers allow.  One wave per workgroup: ray cast
+// 0.504 -> 0.487 ms at 65 536 envs, 0.315 -> 0.302 at 32 768 (4 / CULL_WPB consecutive workgroups of an XCD form one block slot of the
+// XCD-aware order below; round 2 measured 2 against 4 and found no difference — at 8 waves per SIMD and twice the work per ray).
+#define CULL_WPB 1
 #define CULL_QCAP 1024u              // entries of one queue region (a wave's own).  A ray adds at most 128, so a wave that finds more than
                                      // CULL_QCAP - 128 entries after a ray finishes (exact phase) what it has and scans on from the next ray
 #define CULL_SCAN_ARGS                                                                                                          \
@@ -577,17 +583,19 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 // LAZY: the far pairs of a bin (slot 1) are gathered and unpacked only if one of its rays tests them — a second, dependent round of
 // gathers in the bins that do, half the set-up in the bins that do not (most of them when a bin holds few rays).
 template <int H, int LAZY>
-__global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
+__global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float k_ca = H ? c_a_h : CullK<0>::c_a, k_tau2 = H ? tau2_h : CullK<0>::tau2;      // (f32 proof: compile-time constants)
     // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
     // exposed memory latency per run instead of one per bin); s_bk: the run's 64 running minima as ordered-u32 keys.
-    __shared__ int4 s_ids[4][CULL_RING][64];
-    __shared__ uint32_t s_bk[4][64];
-    const uint32_t x = blockIdx.x & 7u, w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t* const bk = s_bk[w];
+    __shared__ int4 s_ids[CULL_WPB][CULL_RING][64];
+    __shared__ uint32_t s_bk[CULL_WPB][64];
+    const uint32_t x = blockIdx.x & 7u, tw = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // this wave: wave w (0..3) of block slot jslot of XCD x
+    const uint32_t qx = blockIdx.x >> 3, w = (qx % (4u / CULL_WPB)) * CULL_WPB + tw, jslot = qx / (4u / CULL_WPB);
+    uint32_t* const bk = s_bk[tw];
     // the wave's region of the candidate queue (CULL_QCAP entries): by its position in THIS launch — a step whose regions would
-    // exceed the queue budget is cast in several launches over slices [j0, j0 + gridDim.x / 8) of the block slots, which re-use them
-    uint2* const qw = queue + (size_t)(blockIdx.x * 4u + w) * CULL_QCAP;
+    // exceed the queue budget is cast in several launches over slices [j0, j0 + n) of the block slots (n x 8 XCDs x 4 / CULL_WPB workgroups), which re-use them
+    uint2* const qw = queue + (size_t)((jslot * 8u + x) * 4u + w) * CULL_QCAP;
 
     // XCD-aware order (blocks b, b + 8, ... run on one XCD): the TERRAIN blocks [0, split) are dealt to the XCDs in chunks of
     // 2^chs consecutive blocks, round robin, then the ROCKS blocks [split, n_blocks) the same way (chunks of 2^chr).  Chunks, so that neighbouring bins
@@ -599,7 +607,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
     //  resident workgroups, each walking the slots j, j + stride, ... of its XCD with a queue region of its own — 56 MB of queue for
     //  any batch — took 0.69 - 0.82 ms instead of 0.58: the cost of a block depends on where its rays are, and the slowest of 1 792
     //  static sums of ~12 blocks ends a third after the mean; the hardware's dynamic order ends one block after it.)
-    const uint32_t j = (blockIdx.x >> 3) + j0;
+    const uint32_t j = jslot + j0;
     {
     uint32_t lb;
     // (chs / chr = 31: one contiguous eighth per XCD — small batches, where a chunk would be too few bins to share anything)
@@ -709,7 +717,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         const uint32_t rm = (uint32_t)__builtin_amdgcn_readlane((int)rowm, (int)jj), m2 = rm & 1u;
         const char* src = reinterpret_cast<const char*>(m2 ? idx1 : idx0) + (rm & ~15u) + lane_off(m2);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)&s_ids[w][pf_n % CULL_RING][0], 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)&s_ids[tw][pf_n % CULL_RING][0], 16, 0, 0);
         ++pf_n;
     };
 #pragma unroll 1
@@ -737,7 +745,7 @@ __global__ void __launch_bounds__(256) cull_scan_kernel(CULL_SCAN_ARGS) {
         // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
-        const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[w][use_n % CULL_RING][0]) + lane_off(map));
+        const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[tw][use_n % CULL_RING][0]) + lane_off(map));
         ++use_n;
         const int32_t id[4] = {id4.x, id4.y, id4.z, id4.w};
         const uint4* ct = map ? ctab1 : ctab0;
@@ -952,7 +960,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     for (uint32_t j0 = 0; j0 < slots; j0 += per) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
         auto kern = a.half ? cull_scan_kernel<1, 0> : (a.lazy_far ? cull_scan_kernel<0, 1> : cull_scan_kernel<0, 0>);
-        hipLaunchKernelGGL(kern, dim3(n * 8u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted,
+        hipLaunchKernelGGL(kern, dim3(n * 8u * (4u / CULL_WPB)), dim3(64 * CULL_WPB), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
                            reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h, a.far0, a.far1, a.k2_far, a.near0, a.near1);
