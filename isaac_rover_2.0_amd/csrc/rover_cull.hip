@@ -94,7 +94,7 @@ CullProofH cull_proof_h(double eta) {
 }
 static_assert(0.999 * (CullK<0>::tau - 1.0e-3) * CullK<0>::sigma > 2.0 * 1.0e-6 / 0.02, "f32 cull proof: (B) must contradict (A)");
 #define CULL_RUNMAX 64               // sorted rays per wave (one result slot per lane)
-#define CULL_RING   4                // id rows (one bin each) in flight per wave: global -> LDS loads issued this many bins ahead
+#define CULL_RING   2                // id rows (one bin each) in flight per wave: global -> LDS loads issued this many bins ahead
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
@@ -471,12 +471,14 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 // ---------------------------------------------------------------------------------------------------
 template <int H>
 __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
-                                           const uint2* qw, uint32_t n, uint32_t gid /* per lane: ray id of run position `lane` */,
-                                           uint32_t lane, uint32_t* bk) {
+                                           const uint2* lq, uint32_t lcap, const uint2* qw, uint32_t n,
+                                           uint32_t gid /* per lane: ray id of run position `lane` */, uint32_t lane, uint32_t* bk) {
+    // entry i of the wave's queue: the first lcap in LDS, the rest in its global region
+    auto entry = [&](uint32_t i) { return i < lcap ? lq[i] : qw[i - lcap]; };
     // The queue entries are read one round ahead: a round then waits for ONE memory round trip (the gathers its entries
     // address: two triangle records and the ray, 72 bytes per lane), not two.
     if (n == 0u) return;
-    uint2 en_next = qw[min(lane, n - 1u)];
+    uint2 en_next = entry(min(lane, n - 1u));
     for (uint32_t base = 0; base < n; base += 64u) {                // wave-uniform
         const bool live = base + lane < n;
         const uint2 en = en_next;
@@ -487,7 +489,7 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
         const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
         const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
-        if (base + 64u < n) en_next = qw[min(base + 64u + lane, n - 1u)];
+        if (base + 64u < n) en_next = entry(min(base + 64u + lane, n - 1u));
         float best;
         if (H) {
             // the reference's as-shipped fp16 arithmetic (cast_pairs_h: what raycast_binned_h_kernel runs on every triangle); the
@@ -589,10 +591,17 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // exposed memory latency per run instead of one per bin); s_bk: the run's 64 running minima as ordered-u32 keys.
     __shared__ int4 s_ids[CULL_WPB][CULL_RING][64];
     __shared__ uint32_t s_bk[CULL_WPB][64];
+    // The first LCAP entries of the wave's candidate queue live in LDS (a run of 64 terrain rays queues ~230, at most ~600): phase 2 reads
+    // them back without a round trip through memory, and phase 1 does not wait for the acknowledgement of 8-byte stores scattered over
+    // 120 MB.  What does not fit goes to the wave's global region as before.  (Sized so that the LDS never caps the waves the registers
+    // allow: 6 per SIMD x 4.25 + 4 KB, 7 x 4.25 + 3 KB.)
+    constexpr uint32_t LCAP = LAZY ? 512u : 384u;
+    __shared__ uint2 s_lq[CULL_WPB][LCAP];
     const uint32_t x = blockIdx.x & 7u, tw = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // this wave: wave w (0..3) of block slot jslot of XCD x
     const uint32_t qx = blockIdx.x >> 3, w = (qx % (4u / CULL_WPB)) * CULL_WPB + tw, jslot = qx / (4u / CULL_WPB);
     uint32_t* const bk = s_bk[tw];
+    uint2* const lq = s_lq[tw];
     // the wave's region of the candidate queue (CULL_QCAP entries): by its position in THIS launch — a step whose regions would
     // exceed the queue budget is cast in several launches over slices [j0, j0 + n) of the block slots (n x 8 XCDs x 4 / CULL_WPB workgroups), which re-use them
     uint2* const qw = queue + (size_t)((jslot * 8u + x) * 4u + w) * CULL_QCAP;
@@ -840,8 +849,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
                 for (int p = 0; p < 2; ++p) {
                     if (any[p]) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any[p], 0u));
-                        if (__builtin_amdgcn_inverse_ballot_w64(any[p]))
-                            qw[cused + rank] = make_uint2(qid[p][0], qid[p][1] | (r << 26));
+                        if (__builtin_amdgcn_inverse_ballot_w64(any[p])) {
+                            const uint32_t at = cused + rank;
+                            const uint2 e = make_uint2(qid[p][0], qid[p][1] | (r << 26));
+                            if (at < LCAP) lq[at] = e; else qw[at - LCAP] = e;
+                        }
                         cused += (uint32_t)__builtin_popcountll(any[p]);
                     }
                 }
@@ -859,7 +871,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // The wait also retires id-row loads of bins this segment did not reach (the ring restarts with the next segment).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
-    cull_exact<H>(rays, rtab0, rtab1, qw, cused, gid, lane, bk);
+    cull_exact<H>(rays, rtab0, rtab1, lq, LCAP, qw, cused, gid, lane, bk);
     ctot += cused;
     }
     wave_lds_sync();
