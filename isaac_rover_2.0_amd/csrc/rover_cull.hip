@@ -574,7 +574,8 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 // 0.504 -> 0.487 ms at 65 536 envs, 0.315 -> 0.302 at 32 768 (4 / CULL_WPB consecutive workgroups of an XCD form one block slot of the
 // XCD-aware order below; round 2 measured 2 against 4 and found no difference — at 8 waves per SIMD and twice the work per ray).
 #define CULL_WPB 1
-#define CULL_QCAP 1024u              // entries of one queue region (a wave's own).  A ray adds at most 128, so a wave that finds more than
+#define CULL_QGLOBAL 640u            // entries of a wave's GLOBAL queue region: what of its CULL_QCAP entries cannot be in LDS (the eager kernels keep 384 there)
+#define CULL_QCAP 1024u              // entries of a wave's queue (LDS part + global region).  A ray adds at most 128, so a wave that finds more than
                                      // CULL_QCAP - 128 entries after a ray finishes (exact phase) what it has and scans on from the next ray
 #define CULL_SCAN_ARGS                                                                                                          \
     const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
@@ -596,6 +597,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // 120 MB.  What does not fit goes to the wave's global region as before.  (Sized so that the LDS never caps the waves the registers
     // allow: 6 per SIMD x 4.25 + 4 KB, 7 x 4.25 + 3 KB.)
     constexpr uint32_t LCAP = LAZY ? 512u : 384u;
+    static_assert(CULL_QCAP - LCAP <= CULL_QGLOBAL, "the global region holds what the LDS part does not");
     __shared__ uint2 s_lq[CULL_WPB][LCAP];
     const uint32_t x = blockIdx.x & 7u, tw = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // this wave: wave w (0..3) of block slot jslot of XCD x
@@ -604,7 +606,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     uint2* const lq = s_lq[tw];
     // the wave's region of the candidate queue (CULL_QCAP entries): by its position in THIS launch — a step whose regions would
     // exceed the queue budget is cast in several launches over slices [j0, j0 + n) of the block slots (n x 8 XCDs x 4 / CULL_WPB workgroups), which re-use them
-    uint2* const qw = queue + (size_t)((jslot * 8u + x) * 4u + w) * CULL_QCAP;
+    uint2* const qw = queue + (size_t)((jslot * 8u + x) * 4u + w) * CULL_QGLOBAL;
 
     // XCD-aware order (blocks b, b + 8, ... run on one XCD): the TERRAIN blocks [0, split) are dealt to the XCDs in chunks of
     // 2^chs consecutive blocks, round robin, then the ROCKS blocks [split, n_blocks) the same way (chunks of 2^chr).  Chunks, so that neighbouring bins
@@ -957,9 +959,9 @@ static CullGrid cull_grid(uint32_t n_sorted, uint32_t n_terrain, uint32_t run) {
     return g;
 }
 
-// block slots per XCD one launch may cover so that its queue regions (8 XCDs x 4 waves x CULL_QCAP entries per slot) fit `entries`
+// block slots per XCD one launch may cover so that its queue regions (8 XCDs x 4 waves x CULL_QGLOBAL entries per slot) fit `entries`
 static uint32_t cull_slots_per_launch(uint64_t entries) {
-    const uint64_t s = entries / (8ull * 4ull * CULL_QCAP);
+    const uint64_t s = entries / (8ull * 4ull * CULL_QGLOBAL);
     return (uint32_t)(s < 1 ? 1 : (s > 0x7fffffffull ? 0x7fffffffull : s));
 }
 
@@ -988,7 +990,7 @@ uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run) {
     return (uint32_t)(4u * ((n_rays / rr + 4u) / 4u + 3u));
 }
 
-// Entries of the candidate queue: one region of CULL_QCAP entries per wave of a launch, capped by `budget_bytes` (a launch then
+// Entries of the candidate queue: one region of CULL_QGLOBAL entries per wave of a launch, capped by `budget_bytes` (a launch then
 // covers a slice of the block slots; *n_launches says how many a step takes).
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches) {
     const CullGrid g = cull_grid((uint32_t)n_rays, n_terrain, run);
@@ -996,7 +998,7 @@ uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, u
     uint32_t per = cull_slots_per_launch(budget_bytes / sizeof(uint2));
     if (per > slots) per = slots ? slots : 1u;
     if (n_launches) *n_launches = slots ? (slots + per - 1u) / per : 1u;
-    return (uint64_t)per * 8u * 4u * CULL_QCAP;
+    return (uint64_t)per * 8u * 4u * CULL_QGLOBAL;
 }
 
 }  // namespace rover
