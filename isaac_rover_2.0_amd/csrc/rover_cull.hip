@@ -708,6 +708,19 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // the rays of the segment that are scanned at all, and its bins: the segment's first ray opens one; bins without a live ray are
     // dropped here — no id row is requested for them, no record gathered
     const uint64_t live = ~skipall & runmask & (~0ull << r_next);
+    // Per run position, in ONE register, what the ray loop needs when it reaches ray r — the id of the NEXT live ray (whose record it
+    // requests) in bits 0..29, "ray r is on the cone path" in bit 31, "ray r skips the far pairs" in bit 30: one v_readlane per ray instead
+    // of a dozen scalar instructions on the 64-bit masks (SKIP: the next LIVE ray)
+    uint32_t nxw;
+    {
+        uint32_t nxt = lane + 1u < n_run ? lane + 1u : lane;               // (every ray is live without SKIP)
+        if (SKIP) {
+            const uint64_t above = live & (~1ull << lane);                 // (per lane)
+            nxt = above ? (uint32_t)__builtin_ctzll(above) : lane;
+        }
+        const uint32_t gnx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)gid);
+        nxw = (gnx & 0x3fffffffu) | ((uint32_t)((conemask >> lane) & 1ull) << 31) | ((uint32_t)((farskip >> lane) & 1ull) << 30);
+    }
     const uint64_t hm_all = (heads | (1ull << r_next)) & (~0ull << r_next);
     uint64_t hm = SKIP ? 0ull : hm_all;
     for (uint64_t tt = SKIP ? hm_all : 0ull; tt;) {
@@ -811,15 +824,14 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
             } else if (r >= i_end) break;
             // tests (A), (B): lanes whose pair p holds a triangle that they do not both reject
             const float4 ra = nxa, rb = nxb;
-            if (SKIP) {
-                const uint64_t later = live & (~1ull << r);                 // the next live ray, of this bin or a later one
-                load_ray(later ? (uint32_t)__builtin_ctzll(later) : r, nxa, nxb);
-            } else {
-                load_ray(r + 1u < n_run ? r + 1u : r, nxa, nxb);
+            const uint32_t xr = (uint32_t)__builtin_amdgcn_readlane((int)nxw, (int)r);
+            {
+                const float4* rp = reinterpret_cast<const float4*>(rays + (xr & 0x3fffffffu));      // the next (live) ray, of this bin or a later one
+                nxa = rp[0]; nxb = rp[1];
             }
             const sgpr2 sxy = sgpr_pair(ra.x, ra.y), szc = sgpr_pair(ra.z, ra.w), dxy = sgpr_pair(rb.x, rb.y), dzf = sgpr_pair(rb.z, rb.w);
             uint64_t any[2];
-            const bool cone = (conemask >> r) & 1ull;                                   // (B) holds for every triangle of the cell
+            const bool cone = (xr >> 31) != 0u;                                          // (B) holds for every triangle of the cell
             if (cone) {
                 auto test_a = [&](int p) {                                                  // (A): c_a |h|^2 - (h.d)^2 > r2
                     const f2 hx = pk_rsub<0>(sxy, t.mx[p]), hy = pk_rsub<1>(sxy, t.my[p]), hz = pk_rsub<0>(szc, t.mz[p]);
@@ -829,7 +841,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
                     return ~(__builtin_amdgcn_ballot_w64(A.x > t.r2[p].x) & __builtin_amdgcn_ballot_w64(A.y > t.r2[p].y));
                 };
                 any[0] = test_a(0);
-                any[1] = ((farskip >> r) & 1ull) ? 0ull : test_a(1);                         // every far triangle cleared: slot 1 skipped
+                any[1] = (xr & 0x40000000u) ? 0ull : test_a(1);                               // every far triangle cleared: slot 1 skipped
             } else {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
