@@ -673,6 +673,9 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     // triangles that span many cells: few — there the second, dependent round of gathers cost 3 %).
     const bool lazy_auto = 26 + c->P < 100 && 2 * c->cull_farok[0] >= c->cull_cells[0];
     a.lazy_far = (c->cull_lazy < 0 ? lazy_auto : c->cull_lazy != 0) ? 1 : 0;
+    // rays that clear their whole cell are left out of the scan where some do: a mesh whose cells mostly have a usable bound, and rock
+    // rays (the ones that qualify) at least a tenth of the ray set (120 + 26 rays: 12 % of the rays, +3.8 %; the native 1 634 + 26: none)
+    a.skip_clear = (2 * c->cull_farok[0] >= c->cull_cells[0] && 26 + c->P <= 260) ? 1 : 0;
     a.kp0 = (uint32_t)c->map[0].K8; a.kp1 = (uint32_t)c->map[1].K8;
     a.run = effective_run(c);
     a.out = c->d_dist_out;

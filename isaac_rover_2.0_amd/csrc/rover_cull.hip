@@ -585,7 +585,7 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 
 // LAZY: the far pairs of a bin (slot 1) are gathered and unpacked only if one of its rays tests them — a second, dependent round of
 // gathers in the bins that do, half the set-up in the bins that do not (most of them when a bin holds few rays).
-template <int H, int LAZY>
+template <int H, int LAZY, int SKIPT>
 __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float k_ca = H ? c_a_h : CullK<0>::c_a, k_tau2 = H ? tau2_h : CullK<0>::tau2;      // (f32 proof: compile-time constants)
     // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
@@ -677,10 +677,10 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     const float4 fb = fr[1];                                                  // {Cx, Cy, q16, -}
     const uint64_t conemask = __builtin_amdgcn_ballot_w64(__float_as_uint(fb.z) >= (rflags >> 16));
     if (r_next == 0u) n_both += (uint32_t)__builtin_popcountll(~conemask & (n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull)));
-    // skipall bit i: ray i clears the NEAR pairs as well, on the cone path: no candidate in this cell, not scanned.  In the kernel of small
-    // ray sets on regular meshes only (SKIP = LAZY: a quarter of the rays there, mostly rock rays; where few rays qualify — 1 % on the
-    // irregular mesh, 12 % with 120 rays — walking the live rays through bit masks cost more than it saved: -6 % / -1.5 %).
-    constexpr bool SKIP = LAZY != 0;
+    // skipall bit i: ray i clears the NEAR pairs as well, on the cone path: no candidate in this cell, not scanned.  SKIP kernels only: the
+    // host picks them where rays qualify (regular meshes, rock rays a tenth of the set or more: a quarter of the rays with 37 + 26, 12 %
+    // with 120 + 26); on the irregular mesh 1 % qualify and dropping dead bins / walking live rays costs 2 % (6 % before the per-lane word).
+    constexpr bool SKIP = SKIPT != 0;
     uint64_t farskip = 0, skipall = 0;
     if (!H) {
         const float4 fa = fr[0];                                              // {G, z0, z1, rho_out} of the far pairs
@@ -985,7 +985,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     // of the slot list, one launch each on the same stream, re-using the regions
     for (uint32_t j0 = 0; j0 < slots; j0 += per) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
-        auto kern = a.half ? cull_scan_kernel<1, 0> : (a.lazy_far ? cull_scan_kernel<0, 1> : cull_scan_kernel<0, 0>);
+        auto kern = a.half ? cull_scan_kernel<1, 0, 0> : (a.lazy_far ? cull_scan_kernel<0, 1, 1> : (a.skip_clear ? cull_scan_kernel<0, 0, 1> : cull_scan_kernel<0, 0, 0>));
         hipLaunchKernelGGL(kern, dim3(n * 8u * (4u / CULL_WPB)), dim3(64 * CULL_WPB), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,

@@ -76,6 +76,7 @@ struct CullArgs {
     const float4 *near0, *near1; // [cell]: the same bound for the cell's near pairs (behind the far records in the same allocation)
     float k2_far;                // and the ray-side constant of the far skip
     int lazy_far;                // set up a bin's far pairs only when one of its rays tests them (few rays per bin)
+    int skip_clear;              // (eager kernel) do not scan rays that clear their whole cell — the on-demand kernel always does
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);

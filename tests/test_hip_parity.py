@@ -429,8 +429,9 @@ def _ray_sort_layouts(n):
 
 
 def test_rays_that_clear_their_cell_are_not_scanned():
-    """The on-demand scan kernel (small ray sets, regular meshes) does not scan rays that provably clear BOTH halves of their cell's
-    triangles — most rock rays — and drops bins without a live ray; the other kernel scans everything.  Same bits either way."""
+    """On a regular mesh the scan kernels do not scan rays that provably clear BOTH halves of their cell's triangles — most rock
+    rays — and drop bins without a live ray (on an irregular mesh the eager kernel scans everything: test_culled_raycast_changes_no_bit_on_
+    irregular_meshes forces both kernels there).  Same bits as the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     n = 8192
@@ -455,8 +456,10 @@ def test_rays_that_clear_their_cell_are_not_scanned():
             np.testing.assert_array_equal(outs[lazy][key], ref[key], err_msg=f"{key} lazy={lazy}")
     assert infos["1"]["far_records_on_demand"] == 1 and infos["0"]["far_records_on_demand"] == 0
     assert infos["1"]["rays_not_scanned"] > 0.1 * infos["1"]["rays"], infos["1"]
-    assert infos["0"]["rays_not_scanned"] == 0
-    assert infos["1"]["bins"] < infos["0"]["bins"]
+    # (the eager kernel leaves them out too where the library expects enough of them — most terrain cells with a far bound, rock rays a
+    #  tenth of the ray set — and then counts the same rays; otherwise it scans everything)
+    assert infos["0"]["rays_not_scanned"] in (0, infos["1"]["rays_not_scanned"])
+    assert infos["1"]["bins"] <= infos["0"]["bins"]
 
 
 def test_auto_variant_and_run_selection():
