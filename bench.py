@@ -73,9 +73,9 @@ def parse(argv=None):
     ap.add_argument("--ray-precision", default="fp32", choices=["fp32", "fp16_sources", "fp16_as_shipped"],
                     help="fp32 = the reference's fp32 mode (default, the north star's parity mode); fp16_as_shipped = bit-identical to the "
                          "reference as shipped (Camera.dtype = float16)")
-    ap.add_argument("--cell-index-mode", default="cpu_div", choices=["cpu_div", "cuda_rcp"],
-                    help="camera.py:241 `x / 0.1`: a true division as ATen evaluates it on CPU (what the golden vectors pin) or the "
-                         "multiply by the reciprocal ATen's CUDA kernels turn it into")
+    ap.add_argument("--cell-index-mode", default="cuda_rcp", choices=["cpu_div", "cuda_rcp"],
+                    help="camera.py:241 `x / 0.1`: the multiply by the reciprocal ATen's CUDA kernels turn it into (default: the "
+                         "reference as deployed, rover.py:90) or a true division as ATen evaluates it on CPU (what the golden vectors pin)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: headline pass waits for the RCCL gather of a step before the next step starts (default: the gather "
                          "of step i runs on RCCL's stream under the kernels of step i + 1; the other mode is timed as the alt pass)")
@@ -355,7 +355,15 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
         stale = True                               # an entry from before the library carried a source hash
     # The bound is whichever resource the kernel uses the larger fraction of (both from profiles/ counters at the live time)
     hbm_bound = hbm is not None and (frac is None or hbm["frac_of_8TBps"] >= frac)
-    if hbm_bound:
+    if stale or (hbm is None and frac is None):
+        # no counters for this workload key, or counters of another build of the library: no bound and no fraction is claimed
+        # (the live launch time and the no-reuse byte model below are still this run's)
+        head = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
+                "profile_missing": not (valu or traf)}
+        if stale:
+            hbm = None
+            valu_obj.update({"achieved": None, "frac": None})
+    elif hbm_bound:
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     else:
         head = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": valu_obj["unit"], "frac": frac}
@@ -569,19 +577,26 @@ def run_rank(args):
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = E_global * args.steps / elapsed
-        cfg_idx = 4 if args.validate_goals else (3 if world > 1 else (1 if E == 4096 else 2))
+        # which BASELINE.json config this run IS: configs[3] only at its own size (262 144 envs in total over the ranks);
+        # any other N > 1 run is weak scaling of configs[2] (the per-GPU workload of the N = 1 line, what SCALE compares)
+        if args.validate_goals:
+            cfg_name = "BASELINE configs[4]"
+        elif world > 1:
+            cfg_name = "BASELINE configs[3]" if E_global == 262144 else f"weak scaling of BASELINE configs[2] ({E_global} envs in total)"
+        else:
+            cfg_name = "BASELINE configs[1]" if E == 4096 else "BASELINE configs[2]"
         line = {
             "metric": "env-steps/sec (obs+reward+done)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.ray_precision == "fp16_as_shipped" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{cfg_idx}]: {E} envs/GPU x {world} GPU, "
+            "config": {"workload": f"{cfg_name}: {E} envs/GPU x {world} GPU, "
                                    f"{args.rays}-point heightmap + 26 rock rays, K={args.k}, {args.cells}x{args.cells} "
                                    f"cells @0.1 m, stone_info mask over {args.stones} stones"
                                    + (f", mesh={args.mesh}" if args.mesh != "grid" else "")
                                    + (", + goal validation" if args.validate_goals else "")
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
-                                   + (f", cell_index_mode={args.cell_index_mode}" if args.cell_index_mode != "cpu_div" else "")
+                                   + f", cell_index_mode={args.cell_index_mode}"
                                    + (", step replayed from a hipGraph" if args.graph else "")
                                    + ((", RCCL gather(obs f32, rew f32, done u8)->rank0"
                                        + (" overlapped with the next step" if overlap else " serialised with the steps"))
@@ -615,6 +630,11 @@ def run_rank(args):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, scene, distn, batches[0])
         print(json.dumps(line), flush=True)
+        if line["lib_built_from_tree"] is False:
+            # a number measured on a library built from OTHER sources than the ones next to it is not a number of this tree
+            print("bench.py: librover_step.so was not built from the sources in the tree (run isaac_rover_2.0_amd/csrc/build.sh)",
+                  file=sys.stderr)
+            rc = rc or 4
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

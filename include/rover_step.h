@@ -105,6 +105,12 @@ typedef struct {
     /* ADDITIONAL output: reset != 0 as one byte per env — the form the multi-GPU gather ships (SURVEY.md 8e:
      * "done [E/8] u8 or i64"); written by the is_done stage next to the int64 reset_buf. */
     uint8_t *done_u8;              /* optional [E]                                                         */
+    /* The other two return values of Camera.get_depths (camera.py:118-120,145: `return output_distances, output_pt, sources`;
+     * rover.py:286 binds and drops them): per terrain ray its origin (camera.py:212) and the point the reference calls the
+     * intersection, sources - d * k with d = -normalize(direction) and k the ray's distance (ray_casting.py:63; for a miss
+     * k = 11.0).  In the as-shipped fp16 mode both are fp16 values (widened to f32), each operation rounded to fp16. */
+    float *ray_src;                /* optional [E,P,3]                                                     */
+    float *hit_pt;                 /* optional [E,P,3]                                                     */
 } rover_step_out;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -142,6 +148,12 @@ ROVER_API int rover_get_observations(rover_ctx *ctx, const rover_step_in *in, co
 ROVER_API int rover_calculate_metrics(rover_ctx *ctx, const rover_step_in *in, const rover_step_out *out, void *stream);
 /* RoverTask.is_done rover.py:610-647 (writes reset) */
 ROVER_API int rover_is_done(rover_ctx *ctx, const rover_step_in *in, const rover_step_out *out, void *stream);
+/* Camera.get_depths(positions, rotations) camera.py:60-145 as its own call: positions [E,3], rotations [E,3] EULER angles (what the
+ * reference passes: self.rover_rotation, rover.py:286) -> distances [E,P], points [E,P,3], sources [E,P,3] (each optional).  Runs the
+ * step's ray pipeline on the given poses (ray precision / cell index mode / ray-cast variant as set); the observation state of the
+ * ctx (heading, euler of the last rover_get_observations) is left untouched. */
+ROVER_API int rover_get_depths(rover_ctx *ctx, const float *positions, const float *rotations_euler, float *distances,
+                               float *points, float *sources, void *stream);
 /* reset_buf.nonzero() rover.py:356 without the host sync: ids ascending (+env_offset), count to n_reset[0] */
 ROVER_API int rover_compact_resets(rover_ctx *ctx, const int64_t *reset, int64_t *reset_ids, int32_t *n_reset, void *stream);
 /* tensor_quat_to_eul tasks/utils/math/tensor_quat_to_euler.py:6-31 */
@@ -244,7 +256,11 @@ ROVER_API int rover_linear_forward(rover_ctx *ctx, const float *x, int64_t x_str
  * they are (csrc/rover_mlp.hip).  weights[i] is nn.Linear's [widths[i]][widths[i-1]] (K0 for i = 0), biases[i] may be NULL.
  * Built tile shapes: 2 layers with widths <= 96, <= 64; 4 layers with widths <= 256, <= 160, <= 128, <= 16 and activation 0, 1 or 3
  * (none / LeakyReLU / ReLU) on the three hidden layers (else ROVER_E_INVALID: use rover_linear_forward per layer).  Same numerics as
- * rover_linear_forward up to the summation order inside a layer. */
+ * rover_linear_forward up to the summation order inside a layer.
+ * Small batches (M < 20 480 with a 2-layer chain) go through a split-k scratch buffer that the ctx owns and grows on demand: the
+ * chain entry points of one ctx must therefore run on ONE stream at a time (two forwards overlapped on different streams need two
+ * ctxs), and the first small-batch call of a given size must not happen inside a stream capture (it may hipMalloc and synchronise);
+ * warm it up once before capturing. */
 ROVER_API int rover_mlp_chain_forward(rover_ctx *ctx, const float *x, int64_t x_stride, int32_t M, int32_t K0, int32_t n_layers,
                                       const float *const *weights, const float *const *biases, const int32_t *widths,
                                       const int32_t *activations, float *y, int64_t y_stride, void *stream);

@@ -49,7 +49,7 @@ class StepOut(C.Structure):
                 ("reset_ids", C.c_void_p), ("n_reset", C.c_void_p), ("euler", C.c_void_p),
                 ("heading_diff", C.c_void_p), ("ray_dist", C.c_void_p), ("wheel_dist", C.c_void_p),
                 ("body_dist", C.c_void_p), ("stone_collision", C.c_void_p), ("stone_margin", C.c_float),
-                ("done_u8", C.c_void_p)]
+                ("done_u8", C.c_void_p), ("ray_src", C.c_void_p), ("hit_pt", C.c_void_p)]
 
 
 class Info(C.Structure):
@@ -100,6 +100,7 @@ SYMBOLS = {
     "rover_calculate_metrics": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), _P]),
     "rover_is_done": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), _P]),
     "rover_compact_resets": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rover_get_depths": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "rover_quat_to_euler": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "rover_clearance": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rover_shift_spawns": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
@@ -309,7 +310,7 @@ class Engine:
 
     def make_out(self, obs, rew=None, reset=None, rock_collision=None, extras=None, reset_ids=None, n_reset=None,
                  euler=None, heading_diff=None, ray_dist=None, wheel_dist=None, body_dist=None, stone_collision=None,
-                 stone_margin=0.0, done_u8=None):
+                 stone_margin=0.0, done_u8=None, ray_src=None, hit_pt=None):
         e, f, i64 = self.num_envs, torch.float32, torch.int64
         stride = 0
         if obs is not None:
@@ -330,15 +331,17 @@ class Engine:
         self._chk(body_dist, (e, 2), f, "body_dist")
         self._chk(stone_collision, (e,), i64, "stone_collision")
         self._chk(done_u8, (e,), torch.uint8, "done_u8")
+        self._chk(ray_src, (e, self.P, 3), f, "ray_src")
+        self._chk(hit_pt, (e, self.P, 3), f, "hit_pt")
         ex = extras or {}
         for k in EXTRAS:
             self._chk(ex.get(k), (e,), i64 if k == "collision_penalty" else f, "extras." + k)
         sout = StepOut(_ptr(obs), stride, _ptr(rew), _ptr(reset), _ptr(rock_collision),
                        *[_ptr(ex.get(k)) for k in EXTRAS], _ptr(reset_ids), _ptr(n_reset), _ptr(euler),
                        _ptr(heading_diff), _ptr(ray_dist), _ptr(wheel_dist), _ptr(body_dist), _ptr(stone_collision),
-                       float(stone_margin), _ptr(done_u8))
+                       float(stone_margin), _ptr(done_u8), _ptr(ray_src), _ptr(hit_pt))
         sout._keep = (obs, rew, reset, rock_collision, dict(ex), reset_ids, n_reset, euler, heading_diff, ray_dist, wheel_dist,
-                      body_dist, stone_collision, done_u8)
+                      body_dist, stone_collision, done_u8, ray_src, hit_pt)
         return sout
 
     def step(self, sin: StepIn, sout: StepOut, increment_progress=True, compact=False):
@@ -355,6 +358,19 @@ class Engine:
 
     def is_done(self, sin, sout):
         self._check(self.lib.rover_is_done(self._h, C.byref(sin), C.byref(sout), _stream()), "rover_is_done")
+
+    def get_depths(self, positions, rotations):
+        """Camera.get_depths (camera.py:60-145): positions [E,3], rotations [E,3] euler angles -> (distances [E,P], points [E,P,3],
+        sources [E,P,3])."""
+        e, f = self.num_envs, torch.float32
+        self._chk(positions, (e, 3), f, "positions")
+        self._chk(rotations, (e, 3), f, "rotations")
+        dist = torch.empty(e, self.P, device=positions.device)
+        pts = torch.empty(e, self.P, 3, device=positions.device)
+        src = torch.empty(e, self.P, 3, device=positions.device)
+        self._check(self.lib.rover_get_depths(self._h, _ptr(positions), _ptr(rotations), _ptr(dist), _ptr(pts), _ptr(src), _stream()),
+                    "rover_get_depths")
+        return dist, pts, src
 
     def compact_resets(self, reset, reset_ids, n_reset):
         self._chk(reset, (self.num_envs,), torch.int64, "reset")

@@ -223,8 +223,12 @@ static int alloc_cull_queue(rover_ctx* c) {
     if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) != 3) return ROVER_OK;
     const uint32_t run = effective_run(c);
     const uint64_t entries = cull_queue_entries(valid_rays(c), (uint32_t)c->cfg.num_envs * (uint32_t)c->P, run, c->cull_budget, &c->cull_launches);
-    if (c->d_cull_queue && c->d_cull_stats && entries == c->cull_entries && run == c->cull_run) return ROVER_OK;
+    // (the per-wave counters are sized by the RAY count, the queue — once capped by the budget — is not: a second
+    //  rover_set_distribution with more rays must grow the counters even when the queue keeps its size)
+    const uint32_t slots = rover::cull_stat_slots(valid_rays(c), run);
+    if (c->d_cull_queue && c->d_cull_stats && entries == c->cull_entries && run == c->cull_run && slots == c->cull_stat_slots) return ROVER_OK;
     dfree(c->d_cull_queue); dfree(c->d_cull_stats);
+    c->cull_stat_slots = 0;
     c->cull_entries = 0;
     // no fallback to another kernel: a queue that cannot be allocated is an error the caller sees
     hipError_t e = hipMalloc((void**)&c->d_cull_queue, entries * sizeof(uint2));
@@ -234,8 +238,8 @@ static int alloc_cull_queue(rover_ctx* c) {
         return fail(c, ROVER_E_NOMEM, "culled ray cast: candidate queue of %llu bytes: %s", (unsigned long long)(entries * sizeof(uint2)), hipGetErrorString(e));
     }
     c->cull_entries = entries; c->cull_run = run;
-    c->cull_stat_slots = rover::cull_stat_slots(valid_rays(c), run);
-    HIP_TRY(c, hipMalloc((void**)&c->d_cull_stats, (size_t)c->cull_stat_slots * sizeof(uint4)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_cull_stats, (size_t)slots * sizeof(uint4)));
+    c->cull_stat_slots = slots;
     HIP_TRY(c, hipMemset(c->d_cull_stats, 0, (size_t)c->cull_stat_slots * sizeof(uint4)));
     return ROVER_OK;
 }
@@ -685,18 +689,17 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     return a;
 }
 
-static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, hipStream_t s) {
-    if (!in->pos || !in->quat || !in->joints || !in->target || !in->lin_hist || !in->ang_hist)
-        return fail(c, ROVER_E_INVALID, "get_observations: null input pointer");
-    if (!out->obs) return fail(c, ROVER_E_INVALID, "get_observations: obs is required");
-    const uint32_t E = (uint32_t)c->cfg.num_envs, W = (uint32_t)(4 + c->Ns + c->Nd);
-    const int64_t stride = out->obs_stride ? out->obs_stride : (int64_t)W;
-    if (stride < (int64_t)W) return fail(c, ROVER_E_INVALID, "obs_stride %lld < row width %u", (long long)stride, W);
+// The ray pipeline of a step: env records + ray records, the bucket sort by (map, cell), the ray cast -> d_dist_out [E][R8].
+// euler_in != NULL (rover_get_depths): the poses come as euler angles, quat / joints / target may be NULL, and the ctx's euler / heading
+// state of the last observation is left alone.
+static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const float* joints, const float* target, const float* euler_in,
+                     hipStream_t s) {
+    const uint32_t E = (uint32_t)c->cfg.num_envs;
     PrepArgs p{};
     p.E = E; p.P = (uint32_t)c->P; p.R8 = c->R8;
-    p.pos = in->pos; p.quat = in->quat; p.joints = in->joints; p.target = in->target;
+    p.pos = pos; p.quat = quat; p.joints = joints; p.target = target; p.euler_in = euler_in;
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
-    p.rays = c->d_rays; p.euler = c->d_euler; p.heading = c->d_heading; p.env_rec = c->d_env_rec;
+    p.rays = c->d_rays; p.euler = euler_in ? nullptr : c->d_euler; p.heading = euler_in ? nullptr : c->d_heading; p.env_rec = c->d_env_rec;
     const int variant = effective_variant(c);
     // (the queue is sized by every call that changes its size — never here: no hipMalloc inside a step / a stream capture)
     if (variant == 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
@@ -731,14 +734,26 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     c->last_variant = variant;
     c->sorted_valid = variant >= 2;
     c->rays_valid = true;
+    return ROVER_OK;
+}
+
+static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_step_out* out, hipStream_t s) {
+    if (!in->pos || !in->quat || !in->joints || !in->target || !in->lin_hist || !in->ang_hist)
+        return fail(c, ROVER_E_INVALID, "get_observations: null input pointer");
+    if (!out->obs) return fail(c, ROVER_E_INVALID, "get_observations: obs is required");
+    const uint32_t E = (uint32_t)c->cfg.num_envs, W = (uint32_t)(4 + c->Ns + c->Nd);
+    const int64_t stride = out->obs_stride ? out->obs_stride : (int64_t)W;
+    if (stride < (int64_t)W) return fail(c, ROVER_E_INVALID, "obs_stride %lld < row width %u", (long long)stride, W);
+    if (int r = cast_rays(c, in->pos, in->quat, in->joints, in->target, nullptr, s)) return r;
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
     o.dist = c->d_dist_out; o.obs_idx = c->d_obs_idx; o.obs = out->obs; o.fp16_div = c->precision == 2;
     if (c->defer_obs) { c->pending_obs = o; c->obs_pending = true; }
     else HIP_TRY(c, launch_assemble_obs(o, s));
-    if (out->ray_dist || out->wheel_dist || out->body_dist)
-        HIP_TRY(c, launch_export_dist(c->d_dist_out, E, c->R8, (uint32_t)c->P, out->ray_dist, out->wheel_dist, out->body_dist, s));
+    if (out->ray_dist || out->wheel_dist || out->body_dist || out->ray_src || out->hit_pt)
+        HIP_TRY(c, launch_export_dist(c->d_dist_out, c->d_rays, E, c->R8, (uint32_t)c->P, c->precision, out->ray_dist, out->wheel_dist,
+                                      out->body_dist, out->ray_src, out->hit_pt, s));
     if (out->euler) HIP_TRY(c, hipMemcpyAsync(out->euler, c->d_euler, (uint64_t)E * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->heading_diff) HIP_TRY(c, hipMemcpyAsync(out->heading_diff, c->d_heading, (uint64_t)E * sizeof(float), hipMemcpyDeviceToDevice, s));
     return ROVER_OK;
@@ -812,6 +827,20 @@ int rover_is_done(rover_ctx* c, const rover_step_in* in, const rover_step_out* o
     if (int r = check_ready(c)) return r;
     USE_DEVICE(c);
     return do_metrics(c, in, out, 0, 0, 0, 1, (hipStream_t)stream);
+}
+
+int rover_get_depths(rover_ctx* c, const float* positions, const float* rotations_euler, float* distances, float* points,
+                     float* sources, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!positions || !rotations_euler) return fail(c, ROVER_E_INVALID, "get_depths: positions and rotations are required");
+    if (int r = check_ready(c)) return r;
+    USE_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if (int r = cast_rays(c, positions, nullptr, nullptr, nullptr, rotations_euler, s)) return r;
+    if (distances || points || sources)
+        HIP_TRY(c, launch_export_dist(c->d_dist_out, c->d_rays, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, c->precision, distances,
+                                      nullptr, nullptr, sources, points, s));
+    return ROVER_OK;
 }
 
 int rover_compact_resets(rover_ctx* c, const int64_t* reset, int64_t* ids, int32_t* n_reset, void* stream) {

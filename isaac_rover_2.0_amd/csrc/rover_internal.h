@@ -50,6 +50,7 @@ struct PrepArgs {
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
     int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
+    const float* euler_in;       // optional [E,3]: the pose's euler angles as given (rover_get_depths) instead of quat -> euler
 
 };
 
@@ -215,8 +216,8 @@ hipError_t launch_knn_select(const float* cx, const float* cy, const uint32_t* b
                              float g, uint32_t nbx, uint32_t nby, uint32_t X, uint32_t Y, float res, uint32_t K, const float* cell_x,
                              const float* cell_y, int32_t* out, int32_t* overflow, hipStream_t s);
 hipError_t launch_assemble_obs(const ObsArgs& a, hipStream_t s);
-hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
-                              hipStream_t s);
+hipError_t launch_export_dist(const float* dist, const RayRec* rays, uint32_t E, uint32_t R8, uint32_t P, int precision, float* ray_dist,
+                              float* wheel, float* body, float* ray_src, float* hit_pt, hipStream_t s);
 hipError_t launch_obs_metrics(const ObsArgs& o, const MetricsArgs& m, hipStream_t s);     // both in one launch (rover_step)
 hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s);
 hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint32_t* block_cnt, bool counted, int64_t* ids,

@@ -174,22 +174,27 @@ __global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
     float4* r = reinterpret_cast<float4*>(a.env_rec) + e;      // chunk k of this env: r[k * E]
     const size_t E = a.E;
     if (blockIdx.y == 0u) {
-        const float q[4] = {a.quat[4ull * e], a.quat[4ull * e + 1], a.quat[4ull * e + 2], a.quat[4ull * e + 3]};
-        const float tx = a.target[3ull * e] - a.pos[3ull * e], ty = a.target[3ull * e + 1] - a.pos[3ull * e + 1];
+        // (rover_get_depths: the pose comes as euler angles — camera.py:60 takes `rotations` — and there is no quaternion / target)
+        const float* qp = a.euler_in ? a.euler_in : a.quat + 4ull * e;
+        const float q[4] = {qp[0], qp[1], qp[2], a.euler_in ? 0.0f : qp[3]};
+        const float* tp = a.target ? a.target : a.pos;
+        const float tx = tp[3ull * e] - a.pos[3ull * e], ty = tp[3ull * e + 1] - a.pos[3ull * e + 1];
         float roll, pitch, yaw;
         quat_to_euler(q, roll, pitch, yaw);
+        if (a.euler_in) { roll = a.euler_in[3ull * e]; pitch = a.euler_in[3ull * e + 1]; yaw = a.euler_in[3ull * e + 2]; }
         float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
         float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
         Trig6 t = euler_trig(roll, pitch, yaw);
-        a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw;
-        a.heading[e] = hd;
+        if (a.euler) { a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw; }
+        if (a.heading) a.heading[e] = hd;
         r[0] = make_float4(roll, pitch, yaw, hd);
         r[1 * E] = make_float4(t.sx, t.cx, t.sy, t.cy);
         r[2 * E] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
         return;
     }
-    const float* j = a.joints + 13ull * e;
-    const float j0 = j[0], j1 = j[1], j2 = j[2], j4 = j[4], j6 = j[6], j7 = j[7], j8 = j[8];
+    const float* j = a.joints ? a.joints + 13ull * e : nullptr;        // (null: rover_get_depths casts the heightmap rays only; joints at rest)
+    const float j0 = j ? j[0] : 0.0f, j1 = j ? j[1] : 0.0f, j2 = j ? j[2] : 0.0f, j4 = j ? j[4] : 0.0f, j6 = j ? j[6] : 0.0f,
+                j7 = j ? j[7] : 0.0f, j8 = j ? j[8] : 0.0f;
 #pragma unroll
     for (int w = 0; w < 6; ++w) {
         if ((uint32_t)(w >> 1) + 1u != blockIdx.y) continue;
@@ -441,10 +446,15 @@ __device__ __forceinline__ void assemble_obs_block(const ObsArgs& a, uint32_t bi
 }
 __global__ void __launch_bounds__(256) assemble_obs_kernel(ObsArgs a) { assemble_obs_block(a, blockIdx.x, gridDim.x); }
 
-// optional intermediates for parity tests
-__global__ void __launch_bounds__(256) export_dist_kernel(const float* __restrict__ dist, uint32_t E, uint32_t R8, uint32_t P,
-                                                          float* __restrict__ ray_dist, float* __restrict__ wheel,
-                                                          float* __restrict__ body) {
+// optional intermediates: the per-ray distances by kind, and the other two return values of Camera.get_depths (camera.py:145) —
+// the ray origins (camera.py:212) and the "intersection points" sources - d * k (ray_casting.py:63: d = -normalize(direction), the
+// ray record's direction; k = the ray's distance, 11.0 for a miss).  As shipped (precision 2) the product and the difference are
+// fp16 operations on fp16 values: rounded once each (the f32 product of two fp16 values is exact, and rounding an f32 difference of
+// fp16 values to fp16 equals the fp16 difference: 24 >= 2 * 11 + 2 bits).
+__global__ void __launch_bounds__(256) export_dist_kernel(const float* __restrict__ dist, const RayRec* __restrict__ rays, uint32_t E,
+                                                          uint32_t R8, uint32_t P, int precision, float* __restrict__ ray_dist,
+                                                          float* __restrict__ wheel, float* __restrict__ body,
+                                                          float* __restrict__ ray_src, float* __restrict__ hit_pt) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 26u + P;
     if (i >= (uint64_t)E * n) return;
@@ -452,7 +462,21 @@ __global__ void __launch_bounds__(256) export_dist_kernel(const float* __restric
     float v = dist[(uint64_t)e * R8 + s];
     if (s < 24u) { if (wheel) wheel[24ull * e + s] = v; }
     else if (s < 26u) { if (body) body[2ull * e + (s - 24u)] = v; }
-    else if (ray_dist) ray_dist[(uint64_t)e * P + (s - 26u)] = v;
+    else {
+        const uint64_t o = (uint64_t)e * P + (s - 26u);
+        if (ray_dist) ray_dist[o] = v;
+        if (ray_src || hit_pt) {
+            const RayRec r = rays[(uint64_t)e * R8 + s];
+            if (ray_src) { ray_src[3 * o] = r.sx; ray_src[3 * o + 1] = r.sy; ray_src[3 * o + 2] = r.sz; }
+            if (hit_pt) {
+                float tx = r.dx * v, ty = r.dy * v, tz = r.dz * v;
+                if (precision == 2) { tx = (float)(_Float16)tx; ty = (float)(_Float16)ty; tz = (float)(_Float16)tz; }
+                float hx = r.sx - tx, hy = r.sy - ty, hz = r.sz - tz;
+                if (precision == 2) { hx = (float)(_Float16)hx; hy = (float)(_Float16)hy; hz = (float)(_Float16)hz; }
+                hit_pt[3 * o] = hx; hit_pt[3 * o + 1] = hy; hit_pt[3 * o + 2] = hz;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1131,11 +1155,11 @@ __global__ void __launch_bounds__(NT) bucket_scatter_kernel(const uint32_t* __re
                                                              uint2* __restrict__ pairs2) {
     typedef BktEntry<PACKED> En;
     typename En::T* __restrict__ pairs = reinterpret_cast<typename En::T*>(pairs2);
-    extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2 n_buckets + (NT * BKT_ITEMS) (1 + dwords per entry) dwords
+    extern __shared__ __attribute__((aligned(8))) uint32_t bkt_lds[];        // sized by the launch: 2 n_buckets + (NT * BKT_ITEMS) (1 + dwords per entry) dwords
     uint32_t* const cur = bkt_lds;               // global position of this block's first entry in each bucket
     uint32_t* const cnt = cur + n_buckets;       // this block's entries per bucket -> their local start
     uint32_t* const s_dst = cnt + n_buckets;
-    typename En::T* const s_val = reinterpret_cast<typename En::T*>(s_dst + (NT * BKT_ITEMS) + (n_buckets & 1u));      // (8-byte aligned)
+    typename En::T* const s_val = reinterpret_cast<typename En::T*>(s_dst + (NT * BKT_ITEMS));      // (an even dword offset from an 8-byte aligned base: two-dword entries stay 8-byte aligned)
     __shared__ uint32_t wl[NT / 64];
     const uint32_t per = (n_buckets + NT - 1u) / NT, first = threadIdx.x * per;
     const uint32_t base = blockIdx.x * (NT * BKT_ITEMS);
@@ -1654,10 +1678,10 @@ hipError_t launch_assemble_obs(const ObsArgs& a_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_export_dist(const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* ray_dist, float* wheel, float* body,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, E, R8, P,
-                       ray_dist, wheel, body);
+hipError_t launch_export_dist(const float* dist, const RayRec* rays, uint32_t E, uint32_t R8, uint32_t P, int precision, float* ray_dist,
+                              float* wheel, float* body, float* ray_src, float* hit_pt, hipStream_t s) {
+    hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, rays, E, R8, P, precision,
+                       ray_dist, wheel, body, ray_src, hit_pt);
     return hipGetLastError();
 }
 

@@ -56,20 +56,33 @@ class _Camera:
         self.heightmap = heightmap
         self.heightmap_distribution = heightmap.get_distribution()
         self.num_exteroceptive = self.heightmap_distribution.shape[0]
+        self._engine = None                 # bound by RoverTask once the library holds the scene
 
     def get_num_exteroceptive(self):
         return self.num_exteroceptive
 
+    def get_depths(self, positions, rotations):
+        """camera.py:60-145: rover positions [E,3] and euler rotations [E,3] -> (distances [E,P], intersection points [E,P,3],
+        ray sources [E,P,3]), through ``rover_get_depths`` (the step's own ray pipeline; the step path itself does not call this —
+        it casts the heightmap rays inside ``rover_step``)."""
+        if self._engine is None:
+            raise _lib.RoverError("Camera.get_depths: the camera is not bound to a task yet")
+        return self._engine.get_depths(positions.float().contiguous(), rotations.float().contiguous())
+
 
 class RoverTask(RLTask):
     def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
-                 device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0, stone_mask_margin=None) -> None:
+                 device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0, stone_mask_margin=None,
+                 cell_index_mode="cuda_rcp") -> None:
         """``scene``: a ``synth.Scene`` (or ``assets.load_reference_assets(root)``) with the terrain / rocks KNN maps,
         stone list and heightfield the reference loads from disk (:92-94,:144,:210).  ``distribution``: optional
         (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set.
         ``stone_mask_margin``: if not None, every step also fills ``self.stone_collision`` [E] int64 with the stone_info
         occupancy mask ``nearest_rock(pos_xy) <= margin`` (the clearance of :536-539) — an ADDITIONAL output that
-        the reference's step does not have and that never feeds reward or done."""
+        the reference's step does not have and that never feeds reward or done.
+        ``cell_index_mode``: how the cell lookup ``(xy - shift) / 0.1`` (camera.py:241, rock_detect.py:381, rover.py:590) is
+        rounded.  Default "cuda_rcp" = the reference AS DEPLOYED (rover.py:90 pins cuda:0, where ATen multiplies by the
+        reciprocal); "cpu_div" = ATen's CPU division, what the golden vectors (captured on the CPU) pin."""
         if scene is None:
             raise ValueError("RoverTask needs the terrain assets: pass scene=assets.load_reference_assets(root) "
                              "or a synth.Scene")
@@ -123,6 +136,8 @@ class RoverTask(RLTask):
         # "fp32" = the reference with Camera.dtype = float32 (parity target); "fp16_as_shipped" = Camera.dtype = float16
         # exactly as the reference ships (camera.py:55); "fp16_sources" = fp16 ray origins, f32 arithmetic
         self._engine.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[ray_precision])
+        self._engine.set_option("cell_index_mode", {"cpu_div": 0, "cuda_rcp": 1}[cell_index_mode])
+        self.Camera._engine = self._engine
         self._env_offset = int(env_offset)
 
         # persistent side-state the three methods hand to each other (:274-283, :343, :667)

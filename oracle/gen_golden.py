@@ -220,6 +220,12 @@ def main():
         k200_fixtures()
         irregular_fixtures()
         return
+    if "--only-pre-physics" in sys.argv:
+        pre_physics_fixture()
+        return
+    if "--only-get-depths" in sys.argv:
+        get_depths_fixture()
+        return
     torch.manual_seed(0)
     scene = synth.make_scene(**SCENE_KW)
     digest = scene_digest(scene)
@@ -302,6 +308,54 @@ def main():
     save("ackermann", lin=lin.numpy(), ang=ang.numpy(), steer=steer.numpy(), vel=vel.numpy())
 
     next_rows(ref2, g)
+    pre_physics_fixture()
+    get_depths_fixture()
+
+
+def get_depths_fixture():
+    """All three return values of the reference's ``Camera.get_depths(positions, rotations)`` (camera.py:60-145: distances, the
+    "intersection points" sources - d * k of ray_casting.py:63, the ray sources) on the poses of step_e64_p37 — fp32 mode and as
+    shipped (fp16 tensors) — for ``rover_get_depths`` / the optional ``ray_src`` / ``hit_pt`` outputs of the step."""
+    scene = synth.make_scene(**SCENE_KW)
+    digest = scene_digest(scene)
+    dist = synth.ray_distribution("37")
+    st = synth.make_states(64, SCENE_KW["n_cells"] * 0.1, seed=1)
+    st = edge_states(st, scene)
+    out = {}
+    for tag, fp32 in (("fp32", True), ("fp16", False)):
+        ref = rh.Reference(scene, fp32=fp32, distribution=dist)
+        eul = ref.quat_mod.tensor_quat_to_eul(st["quat"].clone())
+        d, pt, src = ref.cam.get_depths(st["pos"].clone(), eul.clone())
+        out[f"out_{tag}_dist"], out[f"out_{tag}_pt"], out[f"out_{tag}_src"] = d.float().numpy(), pt.float().numpy(), src.float().numpy()
+        out["in_euler"] = eul.numpy()
+    save("get_depths_e64_p37", scene_kw=np.array(repr(SCENE_KW)), scene_digest=np.array(digest), distribution=dist[0], sparse_idx=dist[1],
+         dense_idx=dist[2], in_pos=st["pos"].numpy(), in_quat=st["quat"].numpy(), **out)
+
+
+def pre_physics_fixture():
+    """"next" row f-1: the action side of ``pre_physics_step`` (rover.py:338-343,379-414) as the reference runs it — pre-physics euler,
+    both Memory shifts, actions_nn, Ackermann and the scatter into the (positions, joint_indices) / (velocities, joint_indices)
+    handed to the RoverView — on random actions plus the edge rows of ackermann.npz (0 / straight line / 0-0 / huge radius) and
+    non-finite actions."""
+    scene = synth.make_scene(n_cells=128, k=16, n_stones=10)
+    ref = rh.Reference(scene, fp32=True)
+    g = torch.Generator().manual_seed(41)
+    e = 192
+    actions = 2 * torch.rand(e, 2, generator=g) - 1
+    edge = torch.tensor([[0.0, -2.0], [0.5, 0.0], [0.0, 0.0], [1.0, 1e-4], [0.2, 1.0], [-0.7, 0.3],
+                         [float("nan"), 0.3], [0.4, float("nan")], [float("inf"), 0.2], [0.3, float("-inf")], [float("inf"), float("inf")],
+                         [-0.0, 0.0], [1e-30, 1e-30], [3.0, -3.0]])
+    actions[: len(edge)] = edge
+    q = torch.randn(e, 4, generator=g)
+    quat = q / q.norm(dim=1, keepdim=True)
+    quat[20] = torch.tensor([0.70710678, 0.0, 0.70710678, 0.0])        # sinp = 1: the copysign(pi / 2) seam of tensor_quat_to_euler.py:24
+    quat[21] = torch.tensor([0.70710678, 0.0, -0.70710678, 0.0])
+    lin_hist = 2 * torch.rand(e, 3, generator=g) - 1
+    ang_hist = 2 * torch.rand(e, 3, generator=g) - 1
+    actions_nn = 2 * torch.rand(e, 2, 3, generator=g) - 1
+    out = ref.pre_physics_step(actions, quat, lin_hist, ang_hist, actions_nn)
+    save("pre_physics_step", in_actions=actions.numpy(), in_quat=quat.numpy(), in_lin_hist=lin_hist.numpy(), in_ang_hist=ang_hist.numpy(),
+         in_actions_nn=actions_nn.numpy(), **{"out_" + k: v.numpy() for k, v in out.items()})
 
 
 knn_mesh = synth.knn_test_mesh      # the meshes are rebuilt bit-identically by the tests (parameters + a digest are stored)

@@ -46,6 +46,9 @@ class _StubBase:
             raise AttributeError(name)
         return _StubBase()
 
+    def initialize(self, *a, **k):      # ArticulationView.initialize: reached through super() from RoverView.initialize
+        return None
+
 
 class _StubModule(types.ModuleType):
     __all__: list = []
@@ -269,6 +272,42 @@ class Reference:
 
     def ackermann(self, lin, ang):
         return self.kin_mod.Ackermann(lin, ang, "cpu")
+
+    # ------------------------------------------------------------ pre_physics_step (f-1)
+    def pre_physics_step(self, actions, quat, lin_hist, ang_hist, actions_nn, global_step=20):
+        """``RoverTask.pre_physics_step`` (rover.py:338-414) called unbound with no env flagged for reset and ``global_step`` away
+        from the curriculum switch (:344), on the reference's own ``RoverView`` (its ``initialize`` sets the joint index lists,
+        robots/articulations/views/rover_view.py:45-46) with the PhysX setters replaced by recorders.  Returns what the method left
+        in the task and what it handed to ``set_joint_position_targets`` / ``set_joint_velocity_targets``."""
+        Rover = self.rover_mod.RoverTask
+        rv_mod = importlib.import_module("omniisaacgymenvs.robots.articulations.views.rover_view")
+        e = actions.shape[0]
+        view = rv_mod.RoverView("/World/envs/.*/Rover", "rover_view")
+        view.num_dof = 13
+        view.initialize(None)
+        pos, q = torch.zeros(e, 3), quat.clone()
+        calls = {}
+        view.get_world_poses = lambda: (pos, q)
+        view.count = e
+        view.set_joint_position_targets = lambda x, indices=None, joint_indices=None: calls.__setitem__("pos", (x.clone(), list(joint_indices)))
+        view.set_joint_velocity_targets = lambda x, indices=None, joint_indices=None: calls.__setitem__("vel", (x.clone(), list(joint_indices)))
+        lin = self.rover_mod.Memory(e, 1, 3, "cpu")
+        ang = self.rover_mod.Memory(e, 1, 3, "cpu")
+        lin.tracker = lin_hist.reshape(e, 1, 3).clone()
+        ang.tracker = ang_hist.reshape(e, 1, 3).clone()
+        t = SimpleNamespace(global_step=global_step, _rover=view, reset_buf=torch.zeros(e, dtype=torch.long), save_teacher_data=False,
+                            _device="cpu", linear_velocity=lin, angular_velocity=ang, num_envs=e, _num_actions=2,
+                            actions_nn=actions_nn.clone())
+        real = self.rover_mod.Ackermann
+        self.rover_mod.Ackermann = lambda l, a: real(l, a, "cpu")      # (:391 relies on the default device 'cuda:0')
+        try:
+            Rover.pre_physics_step(t, actions.clone())
+        finally:
+            self.rover_mod.Ackermann = real
+        assert t.global_step == global_step + 1
+        return dict(rover_rot=t.rover_rot, lin_tracker=t.linear_velocity.tracker.reshape(e, 3), ang_tracker=t.angular_velocity.tracker.reshape(e, 3),
+                    actions_nn=t.actions_nn, positions=calls["pos"][0], pos_joint_indices=torch.tensor(calls["pos"][1]),
+                    velocities=calls["vel"][0], vel_joint_indices=torch.tensor(calls["vel"][1]))
 
     # ------------------------------------------------------------ reset_idx (f-2)
     def reset_idx(self, env_ids, degrees, initial_pos, base_pos, reset_buf, progress_buf):

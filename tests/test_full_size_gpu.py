@@ -1,5 +1,6 @@
-"""GPU (-m gpu): BASELINE.json's full size (65 536 envs, 37 + 26 rays, 600 x 600 cells, K = 200) through size-independent
-properties — the oracle only sees a sample, everything else is checked by invariants of the path itself."""
+"""GPU (-m gpu): BASELINE.json's full size (65 536 envs, 37 + 26 rays, 600 x 600 cells, K = 200): EVERY env of configs[2] and
+configs[4] against the CPU oracle, in the fp32 parity mode and in the reference's as-shipped fp16 arithmetic, on the regular grid
+scene and on the irregular (decimated-style) mesh — plus size-independent properties of the path itself."""
 import numpy as np
 import pytest
 import torch
@@ -196,3 +197,97 @@ def test_full_size_config4_dense_rays_and_goal_validation():
     assert int(used2.item()) == want_used
     np.testing.assert_allclose(t2[:, 0:2].cpu().numpy(), want_t[:, 0:2], rtol=1e-6, atol=1e-5)
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ALL envs against the oracle (round 4).  The C oracle (OpenMP) does ~0.3 M env-steps/s on the GPU box's host cores in fp32
+# and ~60 k in its fp16 mode, so a whole BASELINE-size batch costs it 0.2-3 s — no reason to sample.
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_maps(scene):
+    from oracle import oracle as orc
+    return (orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices),
+            orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices))
+
+
+def _all_envs_vs_oracle(scene, distn, st, label):
+    """fp32 mode: the kernel the library picks for a full batch against the oracle on every env (tolerances of conftest.py: scalars
+    1e-5, ray distances 2e-3 on >= 99.9 % of the rays, integer outputs exact away from their thresholds).
+    fp16_as_shipped: the culled kernel (fp16 proof tables, fp16 exact phase) == the every-triangle kernel bit for bit on every
+    output, and against the oracle's fp16 mode everything but the rays whose fp16 rounding a sin / cos / atan2 ulp moved."""
+    from oracle import oracle as orc
+    n = st["pos"].shape[0]
+    t, r = _oracle_maps(scene)
+    got = _run(scene, distn, st, variant=None)                       # the library's own choice of ray-cast kernel
+    want = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp32")
+    g = dict(got)
+    np.testing.assert_array_equal(g.pop("reset_ids"), np.nonzero(got["reset_buf"])[0])      # compaction of the flags the step itself set
+    assert_step_close(g, {"out_" + k: v for k, v in want.items()}, f"{label} fp32, all {n} envs")
+    # stricter than the budget of assert_step_close, and reported: how many rays / flags differ at all
+    flips = float(((got["ray_dist"] < 11.0) != (want["ray_dist"] < 11.0)).mean())
+    assert flips < 2e-4, f"{label}: {flips:.5%} of the terrain rays flip hit <-> miss against the oracle"
+    assert float((got["reset_buf"] != want["reset_buf"]).mean()) < 1e-4
+    assert float((got["rock_collision"] != want["rock_collision"]).mean()) < 1e-4
+
+    outs = {}
+    for variant in (3, 2):
+        from hip_helpers import hip_step, make_engine
+        eng = make_engine(scene, distn, n, variant=variant)
+        eng.set_option("ray_precision", 2)
+        assert eng.info().raycast_variant == variant
+        outs[variant] = hip_step(eng, st)
+        eng.close()
+    for k in outs[3]:
+        np.testing.assert_array_equal(outs[3][k], outs[2][k], err_msg=f"{label} as shipped: {k}, culled vs every-triangle kernel")
+    want16 = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp16_as_shipped")
+    for k in ("ray_dist", "wheel_dist", "body_dist"):
+        bad = float((outs[3][k] != want16[k]).mean())
+        assert bad < 2e-3, f"{label} as shipped: {k}: {bad:.4%} of the rays differ from the oracle's fp16 mode"
+    assert float((outs[3]["reset_buf"] != want16["reset_buf"]).mean()) < 2e-3
+    assert float((outs[3]["rock_collision"] != want16["rock_collision"]).mean()) < 2e-3
+    np.testing.assert_array_equal(outs[3]["progress_buf"], want16["progress_buf"])
+    return got
+
+
+def test_full_size_config2_every_env_against_the_oracle(full):
+    """BASELINE configs[2]: all 65 536 envs (4.1 M rays x K = 200) against the oracle, fp32 and as shipped."""
+    scene, distn, st = full
+    _all_envs_vs_oracle(scene, distn, st, "configs[2]")
+
+
+def test_full_size_config4_every_env_against_the_oracle():
+    """BASELINE configs[4]'s step (65 536 envs, 120 + 26 rays): all envs against the oracle, fp32 and as shipped."""
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=CELLS, k=K, n_stones=1024, device="cuda")
+    _all_envs_vs_oracle(scene, synth.ray_distribution("120"), synth.make_states(E, CELLS * 0.1, seed=9), "configs[4]")
+
+
+def test_full_size_irregular_mesh_every_env_against_the_oracle():
+    """configs[2]'s batch on the scene of `bench.py --mesh irregular` (decimated-style mesh: 349 k triangles from millimetres to
+    metres, ~80 degree rock flanks, needle / zero-area triangles, shuffled ids; K = 200 maps by rover_build_knn_map): all 65 536
+    envs against the oracle, fp32 and as shipped — the geometry the reference's real terrain has
+    (utils/terrain_utils/terrain_generation.py:217-243)."""
+    from isaac_rover_amd import _lib, assets, synth
+    spec = synth.IrregularSpec(extent_x=CELLS * 0.1, extent_y=CELLS * 0.1, n_rocks=1024, seed=5, fine=0.05)
+    tool = _lib.Engine(8, device=0)
+    scene, zf = assets.build_irregular_scene(tool, spec, K)
+    tool.close()
+    st = synth.make_states(E, CELLS * 0.1, seed=11, heightfn=zf)
+    got = _all_envs_vs_oracle(scene, synth.ray_distribution("37"), st, "irregular mesh")
+    assert 0.3 < (got["ray_dist"] < 11.0).mean() <= 1.0
+
+
+def test_reference_operating_point_512_envs_native_rays():
+    """The reference's own operating point: numEnvs 512 (cfg/task/Rover.yaml:11) x its native 1 634-point heightmap + 26 rock rays
+    (heightmap_distribution.py:36-115), K = 200 (rover_utils.py:49), on a decimated-style mesh: every env against the oracle in
+    both arithmetics, with the kernel the library itself picks at this size."""
+    from isaac_rover_amd import _lib, assets, synth
+    from isaac_rover_amd.tasks.utils.heightmap_distribution import generate_native
+    spec = synth.IrregularSpec(extent_x=30.0, extent_y=30.0, n_rocks=256, seed=6, fine=0.05)
+    tool = _lib.Engine(8, device=0)
+    scene, zf = assets.build_irregular_scene(tool, spec, K)
+    tool.close()
+    distn = tuple(np.asarray(x) for x in generate_native())
+    assert distn[0].shape[0] == 1634
+    st = synth.make_states(512, 30.0, seed=12, heightfn=zf)
+    got = _all_envs_vs_oracle(scene, distn, st, "512 envs x native rays")
+    assert got["obs_buf"].shape == (512, 1750)

@@ -397,6 +397,34 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
         assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
+def test_budget_capped_queue_and_a_larger_ray_set_later():
+    """A queue capped by its budget keeps its size when the ray set grows (rover_set_distribution with more points), but the
+    per-wave counters are sized by the ray count: they must be re-allocated, or the scan kernel's counter stores run past the
+    buffer (round-3 advisor finding).  37 -> 120 points at a 1 MB budget, then the step and its counters."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 8192
+    scene = synth.make_scene(n_cells=96, k=24, n_stones=12)
+    st = synth.make_states(n, 9.6, seed=3)
+    eng = make_engine(scene, synth.ray_distribution("37"), n, variant=3)
+    eng.set_option("cull_queue_mb", 1)
+    a = hip_step(eng, st)
+    ci = eng.cull_info()
+    assert ci["rays"] == n * 63 and ci["launches_per_step"] > 1 and ci["queue_bytes"] <= 1 << 20
+    dense = synth.ray_distribution("120")
+    eng.set_distribution(*dense)
+    b = hip_step(eng, st)
+    ci = eng.cull_info()
+    assert ci["rays"] == n * 146 and ci["queue_bytes"] <= 1 << 20
+    eng.close()
+    ref = make_engine(scene, dense, n, variant=1)
+    want = hip_step(ref, st)
+    ref.close()
+    for k in want:
+        np.testing.assert_array_equal(b[k], want[k], err_msg=k)
+    assert a["obs_buf"].shape[1] == 41 and b["obs_buf"].shape[1] == 124
+
+
 def test_ray_sort_entry_layouts_agree():
     """The bucket sort keeps an entry in one dword (low bin bits | slot) while the slot ids leave room, else in two: 36 864
     envs x 64 slots with 4 096 bins per bucket (bin_low_bits 12) take the two-dword layout, the default the packed one — both
@@ -784,6 +812,49 @@ def test_philox_goals_have_clearance():
     assert bool((c > 1.0).all())
     r = (target[ids][:, 0:2] - initial[ids][:, 0:2]).norm(dim=1)
     np.testing.assert_allclose(r.cpu().numpy(), 8.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("precision,tag", [(0, "fp32"), (2, "fp16")])
+def test_get_depths_returns_the_reference_triple(precision, tag):
+    """All three return values of Camera.get_depths (camera.py:145: distances, "intersection points" sources - d k of
+    ray_casting.py:63, ray sources) against the reference's own (tests/golden/get_depths_e64_p37.npz): `rover_get_depths` on the
+    reference's (positions, euler rotations), and the optional `ray_src` / `hit_pt` outputs of `rover_step`.  As shipped (fp16
+    tensors): bit for bit, every ray."""
+    from hip_helpers import make_engine
+    fx = load_golden("get_depths_e64_p37")
+    scene = scene_for(fx)
+    distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
+    e, p_n = fx["in_pos"].shape[0], fx["distribution"].shape[0]
+    want_d, want_pt, want_src = fx[f"out_{tag}_dist"], fx[f"out_{tag}_pt"], fx[f"out_{tag}_src"]
+    for variant in (3, 2, 1) if precision == 0 else (3, 2):
+        eng = make_engine(scene, distn, e, variant=variant)
+        eng.set_option("ray_precision", precision)
+        dev = eng.device
+        d, pt, src = eng.get_depths(torch.from_numpy(fx["in_pos"]).to(dev), torch.from_numpy(fx["in_euler"]).to(dev))
+        # the step's optional outputs (euler from the quaternion on the device)
+        st = states_of(load_golden("step_e64_p37_fp32" if precision == 0 else "step_e64_p37_fp16_as_shipped"))
+        np.testing.assert_array_equal(st["pos"].numpy(), fx["in_pos"])
+        dd = {k: v.to(dev).contiguous() for k, v in st.items()}
+        sin = eng.make_in(dd["pos"], dd["quat"], dd["joints"], dd["target"], dd["lin_hist"], dd["ang_hist"], dd["euler_pre"], dd["progress"].clone())
+        obs = torch.zeros(e, eng.num_observations, device=dev)
+        rsrc = torch.zeros(e, p_n, 3, device=dev); hpt = torch.zeros(e, p_n, 3, device=dev); rd = torch.zeros(e, p_n, device=dev)
+        sout = eng.make_out(obs, rew=torch.zeros(e, device=dev), reset=torch.ones(e, dtype=torch.int64, device=dev),
+                            rock_collision=torch.zeros(e, dtype=torch.int64, device=dev), ray_dist=rd, ray_src=rsrc, hit_pt=hpt)
+        eng.step(sin, sout)
+        torch.cuda.synchronize()
+        for label, (gd, gp, gs) in (("get_depths", (d, pt, src)), ("step", (rd, hpt, rsrc))):
+            gd, gp, gs = gd.cpu().numpy(), gp.cpu().numpy(), gs.cpu().numpy()
+            if precision == 2:
+                np.testing.assert_array_equal(gs, want_src, err_msg=f"{label} sources v{variant}")
+                np.testing.assert_array_equal(gd, want_d, err_msg=f"{label} distances v{variant}")
+                np.testing.assert_array_equal(gp, want_pt, err_msg=f"{label} points v{variant}")
+            else:
+                np.testing.assert_allclose(gs, want_src, rtol=1e-6, atol=2e-6, err_msg=f"{label} sources v{variant}")
+                close = np.abs(gd - want_d) <= 2e-3
+                assert close.mean() >= 0.999, f"{label} distances v{variant}"
+                np.testing.assert_allclose(gp[close], want_pt[close], rtol=0, atol=2.5e-3, err_msg=f"{label} points v{variant}")
+        eng.close()
+    assert (want_d < 11.0).mean() > 0.5 and (want_d == 11.0).any()          # hits and misses (k = 11: the point 11 m along the ray)
 
 
 def test_quat_to_euler_and_ackermann():

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the "next" rows f-2 / f-3 / f-4 against golden vectors captured from the reference's OWN code
+"""GPU (-m gpu): the "next" rows f-1 / f-2 / f-3 / f-4 against golden vectors captured from the reference's OWN code
 (oracle/gen_golden.py: RoverTask.reset_idx, rover_utils._get_knn_triangles, learning/model.py's networks) — not against
 restatements written for the test."""
 import hashlib
@@ -13,6 +13,80 @@ pytestmark = pytest.mark.gpu
 
 TOL_QUAT = 1e-6          # reset orientation: f32 sin/cos of d/2 vs scipy's float64 quaternion cast to f32
 TOL_NET_ABS, TOL_NET_REL = 2e-5, 2e-4      # f32 MFMA accumulation order vs the reference's nn.Linear on CPU (MKL sgemm)
+
+
+# --------------------------------------------------------------------------------------------------------------- f-1
+def test_pre_physics_step_matches_reference():
+    """`rover_pre_physics_step` (one kernel) against what the reference's own `RoverTask.pre_physics_step` (rover.py:338-343,379-414,
+    run unbound on its own RoverView by oracle/ref_harness.py) left behind: `rover_rot`, both Memory trackers, and the
+    (positions, joint_indices) / (velocities, joint_indices) it handed to `set_joint_position_targets` / `set_joint_velocity_targets`
+    (robots/articulations/views/rover_view.py:45-46) — including straight-line / turn-on-the-spot / 0-0 / NaN / inf actions.  The task's
+    host-side control flow (device_reset=False: the reference's method split) must produce the same."""
+    from isaac_rover_amd import _lib
+    fx = load_golden("pre_physics_step")
+    e = fx["in_actions"].shape[0]
+    eng = _lib.Engine(e, device=0)
+    dev = eng.device
+    actions = torch.from_numpy(fx["in_actions"]).to(dev)
+    quat = torch.from_numpy(fx["in_quat"]).to(dev)
+    lin = torch.from_numpy(fx["in_lin_hist"]).to(dev).clone()
+    ang = torch.from_numpy(fx["in_ang_hist"]).to(dev).clone()
+    euler = torch.full((e, 3), 7.0, device=dev)
+    jpt = torch.full((e, 13), -5.0, device=dev)
+    jvt = torch.full((e, 13), -6.0, device=dev)
+    eng.pre_physics_step(actions, quat, lin, ang, euler_pre=euler, pos_targets13=jpt, vel_targets13=jvt)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(euler.cpu().numpy(), fx["out_rover_rot"], rtol=1e-5, atol=1e-5)       # :343
+    np.testing.assert_array_equal(lin.cpu().numpy(), fx["out_lin_tracker"])                         # :379-380 (bitwise, NaN included)
+    np.testing.assert_array_equal(ang.cpu().numpy(), fx["out_ang_tracker"])
+    pi, vi = fx["out_pos_joint_indices"], fx["out_vel_joint_indices"]
+    np.testing.assert_array_equal(pi, [6, 8, 4, 7])
+    np.testing.assert_array_equal(vi, [10, 5, 12, 9, 3, 11])
+    jp, jv = jpt.cpu().numpy(), jvt.cpu().numpy()
+    np.testing.assert_allclose(jp[:, pi], fx["out_positions"], rtol=1e-5, atol=1e-5, equal_nan=True)   # :400-412
+    np.testing.assert_allclose(jv[:, vi], fx["out_velocities"], rtol=1e-5, atol=1e-4, equal_nan=True)  # :404-414
+    assert np.isnan(fx["out_velocities"]).any() and np.isinf(fx["out_velocities"]).any()                # the edge rows are in
+    rest_p = np.setdiff1d(np.arange(13), pi)
+    rest_v = np.setdiff1d(np.arange(13), vi)
+    assert (jp[:, rest_p] == -5.0).all() and (jv[:, rest_v] == -6.0).all()                            # other joints' targets untouched
+    eng.close()
+
+
+def test_task_pre_physics_step_matches_reference():
+    """The drop-in `RoverTask.pre_physics_step` in both control flows against the same reference capture (`actions_nn` too)."""
+    from isaac_rover_amd import synth
+    from isaac_rover_amd.config import SimConfig
+    from isaac_rover_amd.tasks.rover import RoverTask
+    from isaac_rover_amd.vec_env import VecEnv
+    fx = load_golden("pre_physics_step")
+    e = fx["in_actions"].shape[0]
+    scene = synth.make_scene(n_cells=128, k=16, n_stones=10)
+    for device_reset in (True, False):
+        env = VecEnv(headless=True)
+        task = RoverTask("Rover", SimConfig(num_envs=e, device="cuda:0"), env, scene=scene, distribution=synth.ray_distribution("9"),
+                         device_reset=device_reset)
+        env.set_task(task, sim_params={"dt": 0.05})
+        dev = "cuda:0"
+        task._rover._quat.copy_(torch.from_numpy(fx["in_quat"]).to(dev))
+        task.linear_velocity.tracker.copy_(torch.from_numpy(fx["in_lin_hist"]).to(dev).reshape(task.linear_velocity.tracker.shape))
+        task.angular_velocity.tracker.copy_(torch.from_numpy(fx["in_ang_hist"]).to(dev).reshape(task.angular_velocity.tracker.shape))
+        task.actions_nn = torch.from_numpy(fx["in_actions_nn"]).to(dev)
+        task.reset_buf.zero_()
+        task._compaction_fresh = False
+        task.global_step = 20
+        task.pre_physics_step(torch.from_numpy(fx["in_actions"]).to(dev))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(task.rover_rot.cpu().numpy(), fx["out_rover_rot"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(task.linear_velocity.tracker.reshape(e, 3).cpu().numpy(), fx["out_lin_tracker"])
+        np.testing.assert_array_equal(task.angular_velocity.tracker.reshape(e, 3).cpu().numpy(), fx["out_ang_tracker"])
+        np.testing.assert_array_equal(task.actions_nn.cpu().numpy(), fx["out_actions_nn"])
+        np.testing.assert_array_equal(task._rover.actuated_pos_indices, fx["out_pos_joint_indices"])
+        np.testing.assert_array_equal(task._rover.actuated_vel_indices, fx["out_vel_joint_indices"])
+        jp = task._rover._joint_pos_targets.cpu().numpy()
+        jv = task._rover._joint_vel_targets.cpu().numpy()
+        np.testing.assert_allclose(jp[:, fx["out_pos_joint_indices"]], fx["out_positions"], rtol=1e-5, atol=1e-5, equal_nan=True)
+        np.testing.assert_allclose(jv[:, fx["out_vel_joint_indices"]], fx["out_velocities"], rtol=1e-5, atol=1e-4, equal_nan=True)
+        env.close()
 
 
 # --------------------------------------------------------------------------------------------------------------- f-2

@@ -201,6 +201,24 @@ def test_ackermann_matches_reference():
     np.testing.assert_allclose(vel, fx["vel"], rtol=1e-6, atol=1e-5, equal_nan=True)
 
 
+def test_pre_physics_fixture_is_consistent_with_the_oracle():
+    """tests/golden/pre_physics_step.npz (captured from the reference's RoverTask.pre_physics_step): the oracle's quat -> euler and
+    Ackermann, scattered with the index lists the reference's RoverView handed over, reproduce it; the trackers are the Memory shift."""
+    fx = load_golden("pre_physics_step")
+    a = fx["in_actions"]
+    np.testing.assert_allclose(orc.quat_to_euler(fx["in_quat"]), fx["out_rover_rot"], rtol=1e-5, atol=1e-5)
+    steer, vel = orc.ackermann(a[:, 0].copy(), a[:, 1].copy())
+    np.testing.assert_allclose(steer[:, [1, 5, 0, 4]], fx["out_positions"], rtol=1e-6, atol=1e-6, equal_nan=True)     # rover.py:400-403
+    np.testing.assert_allclose(vel[:, [1, 3, 5, 0, 2, 4]], fx["out_velocities"], rtol=1e-6, atol=1e-5, equal_nan=True)  # :404-409
+    for key, col in (("lin", 0), ("ang", 1)):
+        np.testing.assert_array_equal(fx[f"out_{key}_tracker"][:, 0], a[:, col])
+        np.testing.assert_array_equal(fx[f"out_{key}_tracker"][:, 1:], fx[f"in_{key}_hist"][:, :2])
+    np.testing.assert_array_equal(fx["out_actions_nn"][:, :, 0], a)
+    np.testing.assert_array_equal(fx["out_actions_nn"][:, :, 1:], fx["in_actions_nn"][:, :, :2])
+    np.testing.assert_array_equal(fx["out_pos_joint_indices"], [6, 8, 4, 7])                  # rover_view.py:45-46
+    np.testing.assert_array_equal(fx["out_vel_joint_indices"], [10, 5, 12, 9, 3, 11])
+
+
 def test_torch_ref_matches_the_c_oracle():
     """oracle/torch_ref.py (the tensor-program CPU baseline: dense [E, p, K, 3, 3] gathers + batched ray_distance + min, as
     the reference runs it) against the per-ray C oracle on the same seeded inputs, fp32 mode; plus a smoke of the fp16 mode."""

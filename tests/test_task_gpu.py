@@ -21,7 +21,8 @@ def _make_task(fx, fused, level=2, device_reset=True):
     cfg = SimConfig(num_envs=e, device="cuda:0")
     env = VecEnv(headless=True)
     task = RoverTask("Rover", cfg, env, scene=scene, distribution=(fx["distribution"], fx["sparse_idx"], fx["dense_idx"]),
-                     fused=fused, device_reset=device_reset)
+                     fused=fused, device_reset=device_reset,
+                     cell_index_mode="cpu_div")      # the golden vectors were captured from the reference on the CPU (ATen division)
     env.set_task(task, sim_params={"dt": 0.05}, spawn_positions=st["pos"].clone())
     # feed the captured sim state (the reference harness does the same on its SimpleNamespace)
     dev = task.device
