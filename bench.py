@@ -367,7 +367,7 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     else:
         head = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": valu_obj["unit"], "frac": frac}
-    head.update({"kernel": {4: "walk_scan_kernel", 3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
+    head.update({"kernel": {3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "launches_timed_every": int(getattr(args, "event_every", 1)), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
                  "reuse_factor": (algo / traffic) if traffic else None,
@@ -619,14 +619,6 @@ def run_rank(args):
                             "always_candidate_triangles": ci["always_candidate_triangles"], "cells_without_cone": ci["cells_without_cone"],
                             "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"],
                             "cells_with_far_bound": ci["cells_with_far_bound"], "far_records_on_demand": bool(ci["far_records_on_demand"])}
-        if info.raycast_variant == 4:
-            ci = eng.cull_info()
-            rays = max(ci["rays"], 1)
-            line["walk"] = {"candidates_per_ray": ci["candidate_pairs"] / rays, "entries_tested_per_ray": ci["walk_entries_tested"] / rays,
-                            "trips_per_wave": ci["walk_trips"] / max(rays / 64.0, 1.0), "rays_walking_a_prefix": ci["rays_far_skipped"] / rays,
-                            "rays_walking_nothing": ci["rays_not_scanned"] / rays, "rays_off_the_all_B_path": ci["rays_both_tests"] / rays,
-                            "max_candidates_per_run": ci["max_pairs_per_run"], "front_entries": ci["walk_front_entries"],
-                            "triangles": ci["triangles"]}
         if world > 1:
             line["gather_check"] = ok
             line["per_rank"] = per_rank          # [rank]: ms per step of that rank; ms per step its compute stream waited for a transfer (rank 0 = the root's receive time that was not hidden)

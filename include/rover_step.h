@@ -287,10 +287,6 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        (16 B per triangle, built at rover_set_knn_map) first proves for most (ray, triangle) pairs that ray_casting.py:59
  *        rejects them, and only the remaining candidates get the exact arithmetic (csrc/rover_cull.hip) — in f32 or, with
  *        ray_precision = 2, in the reference's as-shipped fp16 arithmetic (its own, wider proof margins).
- *        4 = walked (csrc/rover_walk.hip): one LANE per sorted ray; per cell the K sphere records are stored in the order a ray needs
- *        them (by the group bound of rover_cull.hip's far skip), a ray walks only the prefix it cannot prove clear as a group
- *        (12 levels per cell) with tests (A) and (B) per entry, and the same wave runs the exact arithmetic on the candidates, one
- *        lane per (ray, triangle).  No per-bin set-up: the cost follows the triangles a ray can reach, not K.
  *        All give bit-identical results; auto picks 3 when a step casts more than 131 072 rays (below that the binning passes
  *        cost more than they save: 1, or 2 with ray_precision = 2).
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
@@ -345,13 +341,6 @@ typedef struct {
     int64_t cells_with_far_bound[2];  /* per map: cells whose far bound is wide enough to hold for a usual ray (f32 proof tables) */
     uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them, and does not scan rays that clear their whole cell (rays_not_scanned) */
     uint64_t rays_not_scanned;        /* rays that cleared BOTH halves of their cell's triangles as groups (no candidate: the distance is the miss value) */
-    /* variant 4 (the walked ray cast, csrc/rover_walk.hip): a lane walks the prefix of its cell's list it cannot clear as a group.
-     * candidate_pairs then counts single (ray, triangle) candidates, rays_far_skipped the rays that walked less than their whole
-     * list, rays_not_scanned the rays that walked nothing, rays_both_tests the rays whose cone bound does not cover the non-front
-     * entries (they walk everything). */
-    uint64_t walk_entries_tested;     /* list entries tested against their ray (camera.py:84-117 evaluates K per ray) */
-    uint64_t walk_trips;              /* sum over the waves of the longest walk among their 64 rays (what a wave's time follows) */
-    int64_t walk_front_entries[2];    /* per map, over all cells: list entries no group bound stands for (always-candidates, steep triangles) */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -62,8 +62,7 @@ class CullInfo(C.Structure):
     _fields_ = [("triangles", C.c_int64 * 2), ("always_candidate_triangles", C.c_int64 * 2), ("cells_without_cone", C.c_int64 * 2),
                 ("rays", C.c_uint64), ("candidate_pairs", C.c_uint64), ("rays_both_tests", C.c_uint64), ("bins", C.c_uint64),
                 ("max_pairs_per_run", C.c_uint64), ("queue_bytes", C.c_uint64), ("launches_per_step", C.c_uint64), ("rays_far_skipped", C.c_uint64),
-                ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64), ("rays_not_scanned", C.c_uint64),
-                ("walk_entries_tested", C.c_uint64), ("walk_trips", C.c_uint64), ("walk_front_entries", C.c_int64 * 2)]
+                ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64), ("rays_not_scanned", C.c_uint64)]
 
 
 class ChainDesc(C.Structure):
@@ -128,8 +127,8 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_cull.hip", "rover_walk.hip", "rover_mlp.hip",
-                                             "rover_internal.h", "rover_raymath.h", "build.sh")]
+    srcs = [os.path.join(_CSRC, f) for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_cull.hip", "rover_mlp.hip", "rover_internal.h",
+                                             "rover_raymath.h", "build.sh")]
     srcs.append(os.path.join(os.path.dirname(_CSRC), "..", "include", "rover_step.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -162,7 +161,7 @@ def source_hash() -> str:
     """The same hash computed from the source files in the tree (what a fresh build.sh would embed)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_cull.hip", "rover_walk.hip", "rover_mlp.hip", "rover_internal.h", "rover_raymath.h"):
+    for f in ("rover_capi.cpp", "rover_kernels.hip", "rover_cull.hip", "rover_mlp.hip", "rover_internal.h", "rover_raymath.h"):
         h.update(open(os.path.join(_CSRC, f), "rb").read())
     h.update(open(os.path.join(os.path.dirname(_CSRC), "..", "include", "rover_step.h"), "rb").read())
     return h.hexdigest()[:12]
@@ -283,7 +282,7 @@ class Engine:
         """Diagnostics of the culled ray cast (rover_get_cull_info) as a dict; synchronises the device."""
         i = CullInfo()
         self._check(self.lib.rover_get_cull_info(self._h, C.byref(i)), "rover_get_cull_info")
-        d = {k: (list(getattr(i, k)) if k in ("triangles", "always_candidate_triangles", "cells_without_cone", "cells_with_far_bound", "walk_front_entries") else int(getattr(i, k)))
+        d = {k: (list(getattr(i, k)) if k in ("triangles", "always_candidate_triangles", "cells_without_cone", "cells_with_far_bound") else int(getattr(i, k)))
              for k, _ in CullInfo._fields_}
         d["pairs_per_ray"] = d["candidate_pairs"] / d["rays"] if d["rays"] else 0.0
         return d

@@ -32,12 +32,6 @@ struct rover_ctx {
     float4* cull_far_h[2]{nullptr, nullptr};
     uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint32_t* cull_qrow[2]{nullptr, nullptr};
-    // the walked ray cast (variant 4, rover_walk.hip): per cell the K sphere records in walk order + 12 group-bound levels, per proof
-    uint4* walk_rec[2]{nullptr, nullptr};
-    uint4* walk_lvl[2]{nullptr, nullptr};
-    uint4* walk_rec_h[2]{nullptr, nullptr};
-    uint4* walk_lvl_h[2]{nullptr, nullptr};
-    int64_t walk_front[2]{0, 0}, walk_front_h[2]{0, 0};        // front entries over all cells of a map (triangles no group bound stands for)
     uint64_t cull_bytes[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
@@ -178,8 +172,6 @@ static int effective_variant(const rover_ctx* c) {
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
-    const bool v4_ok = c->walk_rec[0] && c->walk_rec[1];      // (built for maps of < 2^25 internal triangle ids: a queue entry's id field)
-    if (c->variant == 4 && v4_ok) return 4;
     return 3;
 }
 
@@ -191,7 +183,6 @@ static uint32_t effective_run(const rover_ctx* c) {
     const uint64_t r = valid_rays(c) / 65536u;
     // the culled ray cast (round 3, one call each: 4 096 envs run 4 / 8 / 16 / 32 -> 0.155 / 0.151 / 0.161 / 0.173 ms per step;
     // 8 192 envs 0.246 / 0.227 / 0.236 / 0.249; 16 384 envs 0.407 / 0.335 / 0.331 / 0.343): small batches want many short-lived waves
-    if (effective_variant(c) == 4) return 64u;                                  // the walked ray cast: a lane per ray, nothing to amortise over a run
     if (effective_variant(c) == 3) return r < 12 ? 8u : (r < 24 ? 16u : (r < 48 ? 32u : 64u));        // powers of two: 63 instead of 64 cost 6 %
     return (uint32_t)(r < 4 ? 4 : (r > 32 ? 32 : r));
 }
@@ -229,18 +220,8 @@ static int alloc_bins(rover_ctx* c) {
 
 // candidate queue of the culled ray cast (one bounded region per resident wave) + its per-wave counters, for the options in force
 static int alloc_cull_queue(rover_ctx* c) {
-    if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) < 3) return ROVER_OK;
+    if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) != 3) return ROVER_OK;
     const uint32_t run = effective_run(c);
-    if (effective_variant(c) == 4) {      // the walked ray cast keeps its queue in LDS: only the per-wave counters live in memory
-        const uint32_t slots4 = rover::cull_stat_slots(valid_rays(c), run);
-        if (c->d_cull_stats && slots4 == c->cull_stat_slots && run == c->cull_run && !c->d_cull_queue) return ROVER_OK;
-        dfree(c->d_cull_queue); dfree(c->d_cull_stats);
-        c->cull_entries = 0; c->cull_stat_slots = 0; c->cull_launches = 1;
-        HIP_TRY(c, hipMalloc((void**)&c->d_cull_stats, (size_t)slots4 * sizeof(uint4)));
-        HIP_TRY(c, hipMemset(c->d_cull_stats, 0, (size_t)slots4 * sizeof(uint4)));
-        c->cull_stat_slots = slots4; c->cull_run = run;
-        return ROVER_OK;
-    }
     const uint64_t entries = cull_queue_entries(valid_rays(c), (uint32_t)c->cfg.num_envs * (uint32_t)c->P, run, c->cull_budget, &c->cull_launches);
     // (the per-wave counters are sized by the RAY count, the queue — once capped by the budget — is not: a second
     //  rover_set_distribution with more rays must grow the counters even when the queue keeps its size)
@@ -404,7 +385,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
-    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 4) ? x : 0; }
+    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 2) ? x : 0; }
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
@@ -423,8 +404,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); dfree(c->cull_far[w]); dfree(c->cull_far_h[w]);
-                                  dfree(c->walk_rec[w]); dfree(c->walk_lvl[w]); dfree(c->walk_rec_h[w]); dfree(c->walk_lvl_h[w]); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); dfree(c->cull_far[w]); dfree(c->cull_far_h[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -476,7 +456,6 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint16_t* d_rtab = nullptr;
     uint32_t *d_qrow = nullptr, *d_qrow_h = nullptr;
     float4 *d_far = nullptr, *d_far_h = nullptr;
-    uint4 *d_wrec = nullptr, *d_wlvl = nullptr, *d_wrec_h = nullptr, *d_wlvl_h = nullptr;
     float* d_nz = nullptr;
     uint32_t* d_cnt = nullptr;
     uint32_t h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -485,7 +464,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     if (K8 <= 256 && (uint32_t)T < 0x1ffffffu) {
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t);
         uint32_t T_int = 0;
-        auto drop = [&]() { cleanup(); dfree(d_wrec); dfree(d_wlvl); dfree(d_wrec_h); dfree(d_wlvl_h); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_far); dfree(d_far_h); dfree(d_nz); dfree(d_cnt);
+        auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_far); dfree(d_far_h); dfree(d_nz); dfree(d_cnt);
                             dfree(d_order); dfree(d_newid); dfree(d_table); };
         // internal triangle numbering (spatial partners get ids 2p, 2p + 1, pairs ordered along a Morton curve): cull_numbering()
         std::vector<uint32_t> order, newid((size_t)T);
@@ -504,13 +483,8 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        // the walked ray cast's per-cell lists (rover_walk.hip): its queue entries keep 25 bits of triangle id
-        const bool walk_ok = T_int < 0x2000000u;
-        const uint64_t b_wr = n_cells * (uint64_t)K * sizeof(uint4), b_wl = n_cells * (uint64_t)WALK_LEVELS_N * sizeof(uint4);
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u + (walk_ok ? 2 * (b_wr + b_wl) : 0);
-        if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess ||
-            (walk_ok && ((e = hipMalloc((void**)&d_wrec, b_wr)) != hipSuccess || (e = hipMalloc((void**)&d_wlvl, b_wl)) != hipSuccess ||
-                         (e = hipMalloc((void**)&d_wrec_h, b_wr)) != hipSuccess || (e = hipMalloc((void**)&d_wlvl_h, b_wl)) != hipSuccess)) || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u;
+        if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_far, n_cells * 48u)) != hipSuccess || (e = hipMalloc((void**)&d_far_h, n_cells * 48u)) != hipSuccess ||
@@ -523,7 +497,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = hipMemset(d_cnt, 0, 8 * sizeof(uint32_t))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
                                    d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
-                                   shift_x, shift_y, d_wrec, d_wlvl, d_wrec_h, d_wlvl_h, nullptr)) != hipSuccess ||
+                                   shift_x, shift_y, nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
             drop();
@@ -535,9 +509,6 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     c->cull_always[which] = h_cnt[0]; c->cull_nocone[which] = h_cnt[1]; c->cull_tris[which] = T;
     c->cull_always_h[which] = h_cnt[2]; c->cull_nocone_h[which] = h_cnt[3];
     c->cull_farok[which] = h_cnt[4]; c->cull_cells[which] = (int64_t)n_cells;
-    c->walk_front[which] = h_cnt[5]; c->walk_front_h[which] = h_cnt[6];
-    dfree(c->walk_rec[which]); dfree(c->walk_lvl[which]); dfree(c->walk_rec_h[which]); dfree(c->walk_lvl_h[which]);
-    c->walk_rec[which] = d_wrec; c->walk_lvl[which] = d_wlvl; c->walk_rec_h[which] = d_wrec_h; c->walk_lvl_h[which] = d_wlvl_h;
     uint16_t* old = const_cast<uint16_t*>(c->map[which].table);
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
@@ -718,25 +689,6 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     return a;
 }
 
-static WalkLaunch walk_args(const rover_ctx* c, uint32_t n_valid) {
-    WalkLaunch w{};
-    const bool h = c->precision == 2;
-    w.rays = c->d_rays; w.sorted = c->d_sorted; w.n_sorted = n_valid;
-    w.rec0 = h ? c->walk_rec_h[0] : c->walk_rec[0]; w.rec1 = h ? c->walk_rec_h[1] : c->walk_rec[1];
-    w.lvl0 = h ? c->walk_lvl_h[0] : c->walk_lvl[0]; w.lvl1 = h ? c->walk_lvl_h[1] : c->walk_lvl[1];
-    w.rtab0 = c->cull_rtab[0]; w.rtab1 = c->cull_rtab[1];
-    w.K0 = (uint32_t)c->map[0].K; w.K1 = (uint32_t)c->map[1].K;
-    const CullGrid g = cull_grid(n_valid, (uint32_t)c->cfg.num_envs * (uint32_t)c->P, effective_run(c));
-    w.n_blocks = g.n_blocks; w.split = g.split; w.t8 = g.t8; w.r8 = g.r8; w.chs = g.chs; w.chr = g.chr; w.run = g.run; w.run_r = g.run_r;
-    w.half = h ? 1 : 0;
-    const CullProofH ph = cull_proof_h(c->cull_eta_h);
-    w.c_a = cull_c_a(w.half, ph); w.k2_far = cull_far_k2(w.half, ph); w.tau2 = cull_tau2(w.half, ph);
-    w.ctab0 = h ? c->cull_ctab_h[0] : c->cull_ctab[0]; w.ctab1 = h ? c->cull_ctab_h[1] : c->cull_ctab[1];
-    w.out = c->d_dist_out; w.stats = c->d_cull_stats;
-    if (const char* v = getenv("ROVER_WALK_DIAG")) w.diag = (uint32_t)atoi(v);
-    return w;
-}
-
 // The ray pipeline of a step: env records + ray records, the bucket sort by (map, cell), the ray cast -> d_dist_out [E][R8].
 // euler_in != NULL (rover_get_depths): the poses come as euler angles, quat / joints / target may be NULL, and the ctx's euler / heading
 // state of the last observation is left alone.
@@ -752,8 +704,6 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     // (the queue is sized by every call that changes its size — never here: no hipMalloc inside a step / a stream capture)
     if (variant == 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
         return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
-    if (variant == 4 && (!c->d_cull_stats || c->cull_run != effective_run(c)))
-        return fail(c, ROVER_E_STATE, "the walked ray cast's counters are not allocated for the options in force");
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
     if (variant >= 2) p.bin_out = c->d_bins;
@@ -768,9 +718,7 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
     }
-    if (variant == 4)
-        HIP_TRY(c, launch_raycast_walk(walk_args(c, n_valid), s));
-    else if (variant == 3)
+    if (variant == 3)
         HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
     else if (variant == 2)
         HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
@@ -1062,22 +1010,11 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
     out->far_records_on_demand = (c->have_dist && c->have_map[0] && c->precision != 2) ? (uint64_t)cull_args(c, 0).lazy_far : 0;
     out->queue_bytes = c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0;
     out->launches_per_step = c->d_cull_queue ? c->cull_launches : 0;
-    if (!c->d_cull_stats || c->last_variant < 3) return ROVER_OK;
+    if (!c->d_cull_stats || c->last_variant != 3) return ROVER_OK;
     USE_DEVICE(c);
     HIP_TRY(c, hipDeviceSynchronize());
     std::vector<uint4> h(c->cull_stat_slots);
     HIP_TRY(c, hipMemcpy(h.data(), c->d_cull_stats, h.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-    if (c->last_variant == 4) {
-        // the walked ray cast (rover_walk.hip): candidates are single (ray, triangle) entries; "far skipped" = rays that walked only a
-        // prefix of their cell's list, "both tests" = rays off the all-(B) path, "not scanned" = rays that walked nothing
-        for (int w = 0; w < 2; ++w) out->walk_front_entries[w] = c->precision == 2 ? c->walk_front_h[w] : c->walk_front[w];
-        for (const uint4& v : h) {
-            out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z & 0xffu;
-            out->rays_not_scanned += v.z >> 8; out->walk_entries_tested += v.w >> 9; out->walk_trips += v.w & 0x1ffu;
-            out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
-        }
-        return ROVER_OK;
-    }
     for (const uint4& v : h) {
         out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z & 0xffu; out->rays_not_scanned += v.z >> 8; out->bins += v.w;
         out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
@@ -1310,7 +1247,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
     USE_DEVICE(c);                                 // some options (re)allocate device workspace
     if (!strcmp(name, "raycast_variant")) {
-        if (value < 0 || value > 4) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned), 3 (culled) or 4 (walked)");
+        if (value < 0 || value > 3) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned) or 3 (culled)");
         c->variant = (int)value;
         return alloc_cull_queue(c);
     }
@@ -1395,11 +1332,7 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (v >= 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
-    if (v == 4) {
-        if (!c->d_cull_stats || c->cull_run != effective_run(c))
-            return fail(c, ROVER_E_STATE, "the walked ray cast's counters are not allocated for the options in force");
-        HIP_TRY(c, launch_raycast_walk(walk_args(c, n_valid), s));
-    } else if (v == 3) {
+    if (v == 3) {
         if (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c))
             return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
         HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));

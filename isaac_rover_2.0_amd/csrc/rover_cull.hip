@@ -911,8 +911,6 @@ static void cull_far_consts(double c_a, double dd, float* k1, float* k2) {
     *k1 = (float)(1.00001 / (0.9 * sqrt(ca)));
     *k2 = (float)(1.00001 * sqrt(dd + 1.0e-5 - ca) / (0.9 * sqrt(ca)));
 }
-float cull_c_a(int half, CullProofH ph) { return half ? ph.c_a : CullK<0>::c_a; }      // test (A)'s constant of a proof
-float cull_tau2(int half, CullProofH ph) { return half ? ph.tau2 : CullK<0>::tau2; }  // test (B)'s tau^2
 float cull_far_k2(int half, CullProofH ph) {
     float k1, k2;
     if (half) cull_far_consts(ph.c_a, 1.004, &k1, &k2); else cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
@@ -926,20 +924,16 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
                              int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
                              float4* far_h, float* nz_scratch,
                              uint32_t* counts /* [5], zeroed: always-candidate triangles, cells without a cone; the same for fp16; cells with a useful far bound */,
-                             CullProofH ph, uint32_t Y, float cell_size, float shift_x, float shift_y,
-                             uint4* wrec, uint4* wlvl, uint4* wrec_h, uint4* wlvl_h /* the walked ray cast's per-cell lists (rover_walk.hip), or null */, hipStream_t s) {
-    float k1, k2;
+                             CullProofH ph, uint32_t Y, float cell_size, float shift_x, float shift_y, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
     hipLaunchKernelGGL(ctab_build_kernel<1>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab_h, nz_scratch, counts + 2, ph);
     hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, rtab, Y, cell_size,
                        shift_x, shift_y, idx4, qrow_h, counts + 2);
-    cull_far_consts(ph.c_a, 1.004, &k1, &k2);
-    if (wrec_h) (void)launch_walk_build(map_idx, n_cells, K, T, newid, ctab_h, nz_scratch, ph.tau2, k1, WALK_C0_F16, Y, cell_size, shift_x, shift_y, wrec_h, wlvl_h, counts + 6, s);
     hipLaunchKernelGGL(ctab_build_kernel<0>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab, nz_scratch, counts, ph);
     hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, rtab, Y, cell_size,
                        shift_x, shift_y, idx4, qrow, counts);
+    float k1, k2;
     cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
-    if (wrec) (void)launch_walk_build(map_idx, n_cells, K, T, newid, ctab, nz_scratch, CullK<0>::tau2, k1, WALK_C0_F32, Y, cell_size, shift_x, shift_y, wrec, wlvl, counts + 5, s);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab, n_cells, K8, Y,
                        cell_size, shift_x, shift_y, k1, CullK<0>::tau2, qrow, reinterpret_cast<FarRec*>(far), far + 2ull * n_cells, counts + 4);
     cull_far_consts(ph.c_a, 1.004, &k1, &k2);
@@ -948,7 +942,8 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
     return hipGetLastError();
 }
 
-CullGrid cull_grid(uint32_t n_sorted, uint32_t n_terrain, uint32_t run) {
+struct CullGrid { uint32_t run, run_r, split, n_blocks, chs, chr, t8, r8; };
+static CullGrid cull_grid(uint32_t n_sorted, uint32_t n_terrain, uint32_t run) {
     CullGrid g{};
     if (run > CULL_RUNMAX) run = CULL_RUNMAX;
     if (run == 0) run = 1;
@@ -984,8 +979,7 @@ static uint32_t cull_slots_per_launch(uint64_t entries) {
 
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const CullGrid g = cull_grid(a.n_sorted, a.n_terrain, a.run);
-    uint32_t slots = g.t8 + g.r8;                              // block slots per XCD
-    if (getenv("ROVER_DIAG_TERRAIN_ONLY")) slots = g.t8;
+    const uint32_t slots = g.t8 + g.r8;                              // block slots per XCD
     const uint32_t per = cull_slots_per_launch(a.queue_entries);
     // one launch, unless the queue regions of all slots exceed the budget the queue was sized for (huge batches): then slices
     // of the slot list, one launch each on the same stream, re-using the regions

@@ -81,29 +81,6 @@ struct CullArgs {
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
-
-// the walked ray cast (rover_walk.hip): one lane per ray; per-cell record lists ordered for the walk + their group-bound levels
-struct CullGrid { uint32_t run, run_r, split, n_blocks, chs, chr, t8, r8; };      // XCD-aware order of the runs of sorted rays (rover_cull.hip)
-CullGrid cull_grid(uint32_t n_sorted, uint32_t n_terrain, uint32_t run);
-struct WalkLaunch {
-    const RayRec* rays; const uint32_t* sorted; uint32_t n_sorted;
-    const uint4 *rec0, *rec1, *lvl0, *lvl1;      // [cell][K] walk records / [cell][12] levels of the two maps, for the proof in force
-    const uint16_t *rtab0, *rtab1;               // [T] 20 B: the nine fp16 vertex components (exact phase)
-    uint32_t K0, K1;
-    uint32_t n_blocks, split, t8, r8, chs, chr, run, run_r;
-    int half;                                    // the exact phase runs the as-shipped fp16 arithmetic
-    const uint4 *ctab0, *ctab1;                  // [T] the proof's sphere / normal records: test (B) itself where the cone code fails
-    float c_a, k2_far, tau2;                     // test (A)'s constant, the ray-side constant of the group inequality, test (B)'s tau^2
-    float* out; uint4* stats;
-    uint32_t diag;
-};
-hipError_t launch_raycast_walk(const WalkLaunch& w, hipStream_t s);
-hipError_t launch_walk_build(const int32_t* map_idx, uint64_t n_cells, uint32_t K, uint32_t T, const uint32_t* newid, const uint4* ctab,
-                             const float* nz_abs, float tau2, float k1, uint32_t c0, uint32_t Y, float cell_size, float shift_x, float shift_y,
-                             uint4* wrec, uint4* wlvl, uint32_t* counts, hipStream_t s);
-#define WALK_C0_F32 0u      // (unused: the levels carry their complement's weakest cone code)
-#define WALK_C0_F16 0u
-#define WALK_LEVELS_N 12u
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches);
 
 // n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own
@@ -227,10 +204,8 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
                              int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
                              float4* far_h, float* nz_scratch, uint32_t* counts, CullProofH ph, uint32_t Y, float cell_size, float shift_x,
-                             float shift_y, uint4* wrec, uint4* wlvl, uint4* wrec_h, uint4* wlvl_h, hipStream_t s);
+                             float shift_y, hipStream_t s);
 float cull_far_k2(int half, CullProofH ph);
-float cull_c_a(int half, CullProofH ph);
-float cull_tau2(int half, CullProofH ph);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,
                                 hipStream_t s);

@@ -143,46 +143,6 @@ __device__ __forceinline__ float cast_pairs(const CellRegs<NP>& t, f2 sx, f2 sy,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ONE triangle per lane (the walked ray cast's exact phase, rover_walk.hip: a lane = one (ray, triangle) candidate).  Element for
-// element the operation sequence of set_pair / cast_pairs / div3_ieee above in plain f32 instructions — the same bits (a packed
-// instruction is its two halves), half the issue time of a packed instruction each.
-// ---------------------------------------------------------------------------------------------------
-struct Tri1 { float ax, ay, az, bx, by, bz, cx, cy, cz, nx, ny, nz; };
-
-__device__ __forceinline__ void set_one(Tri1& t, const float (&v)[9]) {
-    t.ax = v[6]; t.ay = v[7]; t.az = v[8];                                   // a = v2
-    t.bx = v[3] - t.ax; t.by = v[4] - t.ay; t.bz = v[5] - t.az;              // b = v1 - a
-    t.cx = v[0] - t.ax; t.cy = v[1] - t.ay; t.cz = v[2] - t.az;              // c = v0 - a
-    t.nx = t.by * t.cz - t.bz * t.cy;                                        // b x c
-    t.ny = t.bz * t.cx - t.bx * t.cz;
-    t.nz = t.bx * t.cy - t.by * t.cx;
-}
-
-__device__ __forceinline__ float div1_ieee(float det, float r, float num) {  // one quotient of div3_ieee (r: the refined reciprocal)
-    float t = num * r;
-    float rem = __builtin_fmaf(-det, t, num);
-    t = __builtin_fmaf(rem, r, t);
-    rem = __builtin_fmaf(-det, t, num);
-    return __builtin_fmaf(rem, r, t);
-}
-
-// ray_casting.py:37-59 for one triangle: k if the reference accepts it, 11.0 otherwise
-__device__ __forceinline__ float cast_one(const Tri1& t, float sx, float sy, float sz, float dx, float dy, float dz) {
-    const float gx = sx - t.ax, gy = sy - t.ay, gz = sz - t.az;                                           // :37
-    const float det = t.nx * dx + t.ny * dy + t.nz * dz;                                                  // :41
-    const float gcx = gy * t.cz - gz * t.cy, gcy = gz * t.cx - gx * t.cz, gcz = gx * t.cy - gy * t.cx;
-    const float nn = gcx * dx + gcy * dy + gcz * dz;                                                      // :44-45
-    const float bgx = t.by * gz - t.bz * gy, bgy = t.bz * gx - t.bx * gz, bgz = t.bx * gy - t.by * gx;
-    const float mn = bgx * dx + bgy * dy + bgz * dz;                                                      // :49-50
-    const float kn = t.nx * gx + t.ny * gy + t.nz * gz;                                                   // :54-55
-    float r = __builtin_amdgcn_rcpf(det);
-    const float e = __builtin_fmaf(-det, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    const float n = div1_ieee(det, r, nn), m = div1_ieee(det, r, mn), k = div1_ieee(det, r, kn);
-    return accept1(n, m, k, det);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // The same arithmetic as ATen evaluates it on float16 tensors (the reference AS SHIPPED, Camera.dtype = float16): every
 // elementwise op of ray_casting.py:31-59 rounds its result to fp16 (packed fp16 instructions, no contraction); the three
 // quotients are taken in f32 (IEEE, shared reciprocal) and rounded to fp16, which equals the fp16 quotient (24 >= 2 * 11 + 2 bits).
@@ -252,35 +212,6 @@ __device__ __forceinline__ float cast_pairs_h(const CellRegsH<NP>& t, h2 sx, h2 
         best = __builtin_fminf(best, __builtin_fminf(r0, r1));
     }
     return best;
-}
-
-// one triangle per lane in the as-shipped fp16 arithmetic: element for element set_pair_h / cast_pairs_h (v_*_f16 instead of v_pk_*_f16)
-struct Tri1H { _Float16 ax, ay, az, bx, by, bz, cx, cy, cz, nx, ny, nz; };
-
-__device__ __forceinline__ void set_one_h(Tri1H& t, const _Float16 (&v)[9]) {
-    t.ax = v[6]; t.ay = v[7]; t.az = v[8];
-    t.bx = v[3] - t.ax; t.by = v[4] - t.ay; t.bz = v[5] - t.az;
-    t.cx = v[0] - t.ax; t.cy = v[1] - t.ay; t.cz = v[2] - t.az;
-    t.nx = t.by * t.cz - t.bz * t.cy;
-    t.ny = t.bz * t.cx - t.bx * t.cz;
-    t.nz = t.bx * t.cy - t.by * t.cx;
-}
-
-__device__ __forceinline__ float cast_one_h(const Tri1H& t, _Float16 sx, _Float16 sy, _Float16 sz, _Float16 dx, _Float16 dy, _Float16 dz) {
-    const _Float16 gx = sx - t.ax, gy = sy - t.ay, gz = sz - t.az;
-    const _Float16 det = t.nx * dx + t.ny * dy + t.nz * dz;
-    const _Float16 gcx = gy * t.cz - gz * t.cy, gcy = gz * t.cx - gx * t.cz, gcz = gx * t.cy - gy * t.cx;
-    const _Float16 nn = gcx * dx + gcy * dy + gcz * dz;
-    const _Float16 bgx = t.by * gz - t.bz * gy, bgy = t.bz * gx - t.bx * gz, bgz = t.bx * gy - t.by * gx;
-    const _Float16 mn = bgx * dx + bgy * dy + bgz * dz;
-    const _Float16 kn = t.nx * gx + t.ny * gy + t.nz * gz;
-    const float detf = (float)det;
-    float r = __builtin_amdgcn_rcpf(detf);
-    const float e = __builtin_fmaf(-detf, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    const _Float16 n = (_Float16)div1_ieee(detf, r, (float)nn), m = (_Float16)div1_ieee(detf, r, (float)mn), k = (_Float16)div1_ieee(detf, r, (float)kn);
-    const _Float16 nm = n + m;                                                   // fp16 sum, then compared (ray_casting.py:59)
-    return accept1((float)n, (float)m, (float)k, detf, (float)nm);
 }
 
 }  // namespace rover

@@ -35,7 +35,7 @@ def test_full_size_invariants(full):
     a = _run(scene, distn, st, variant=3)
     # (1) three independent ray-cast algorithms (culled: conservative sphere / normal test + exact candidates; binned:
     #     register-resident cells, every triangle evaluated; env-order streaming) agree bit for bit
-    for other in (4, 2, 1):
+    for other in (2, 1):
         b = _run(scene, distn, st, variant=other)
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} vs variant {other}")
@@ -133,7 +133,7 @@ def test_full_size_config4_dense_rays_and_goal_validation():
     distn = synth.ray_distribution("120")
     st = synth.make_states(E, CELLS * 0.1, seed=9)
     outs = {}
-    for variant in (3, 2, 1, 4):
+    for variant in (3, 2, 1):
         eng = make_engine(scene, distn, E, variant=variant)
         outs[variant] = hip_step(eng, st)
         if variant != 3:
@@ -144,7 +144,6 @@ def test_full_size_config4_dense_rays_and_goal_validation():
     for k in a:
         np.testing.assert_array_equal(a[k], outs[1][k], err_msg=k)
         np.testing.assert_array_equal(a[k], outs[2][k], err_msg=k)
-        np.testing.assert_array_equal(a[k], outs[4][k], err_msg=k)
     assert a["obs_buf"].shape == (E, 124)
     np.testing.assert_array_equal(a["obs_buf"][:, 4:], a["ray_dist"] / 2.0)
     idx = np.random.default_rng(2).choice(E, 128, replace=False)
@@ -219,9 +218,6 @@ def _all_envs_vs_oracle(scene, distn, st, label):
     n = st["pos"].shape[0]
     t, r = _oracle_maps(scene)
     got = _run(scene, distn, st, variant=None)                       # the library's own choice of ray-cast kernel
-    walked = _run(scene, distn, st, variant=4)
-    for k in got:
-        np.testing.assert_array_equal(walked[k], got[k], err_msg=f"{label} fp32: {k}, walked vs the auto choice")
     want = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp32")
     g = dict(got)
     np.testing.assert_array_equal(g.pop("reset_ids"), np.nonzero(got["reset_buf"])[0])      # compaction of the flags the step itself set
@@ -233,7 +229,7 @@ def _all_envs_vs_oracle(scene, distn, st, label):
     assert float((got["rock_collision"] != want["rock_collision"]).mean()) < 1e-4
 
     outs = {}
-    for variant in (4, 3, 2):
+    for variant in (3, 2):
         from hip_helpers import hip_step, make_engine
         eng = make_engine(scene, distn, n, variant=variant)
         eng.set_option("ray_precision", 2)
@@ -242,7 +238,6 @@ def _all_envs_vs_oracle(scene, distn, st, label):
         eng.close()
     for k in outs[3]:
         np.testing.assert_array_equal(outs[3][k], outs[2][k], err_msg=f"{label} as shipped: {k}, culled vs every-triangle kernel")
-        np.testing.assert_array_equal(outs[4][k], outs[2][k], err_msg=f"{label} as shipped: {k}, walked vs every-triangle kernel")
     want16 = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp16_as_shipped")
     for k in ("ray_dist", "wheel_dist", "body_dist"):
         bad = float((outs[3][k] != want16[k]).mean())

@@ -33,7 +33,7 @@ def test_step_matches_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("name,precision", [("step_lattice_fp32", "fp32"), ("step_lattice_fp16_as_shipped", "fp16_as_shipped")])
-@pytest.mark.parametrize("variant", [4, 3, 2, 1])
+@pytest.mark.parametrize("variant", [3, 2, 1])
 def test_exact_ties_follow_the_reference(name, precision, variant):
     """The lattice fixture (exact threshold / det-guard / degenerate-triangle hits, see tests/test_oracle_golden.py):
     on its rounding-free envs the HIP ray casts equal the reference bit for bit, in both kernels."""
@@ -87,7 +87,7 @@ def test_raycast_variants_bit_identical(dist_name, num_envs, k):
     st = synth.make_states(num_envs, 6.4, seed=21)
     ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
     for variant, run, early_out in ((2, 1, 1), (2, 5, 0), (2, 16, 1), (2, 16, 0), (2, 64, 1),
-                                    (3, 1, 1), (3, 5, 1), (3, 32, 1), (3, 64, 1), (3, 200, 1), (4, 64, 1), (4, 7, 1), (4, 200, 1)):
+                                    (3, 1, 1), (3, 5, 1), (3, 32, 1), (3, 64, 1), (3, 200, 1)):
         eng = make_engine(scene, distn, num_envs, variant=variant, run=run)
         eng.set_option("raycast_early_out", early_out)       # conservative whole-pair rejection: same bits on or off
         assert eng.info().raycast_variant == variant
@@ -109,7 +109,7 @@ def test_crowded_cell_variants_bit_identical():
     one = synth.make_states(2, 6.4, seed=5)
     st = {k: v[torch.arange(num_envs) % 2].clone() for k, v in one.items()}
     ref = hip_step(make_engine(scene, distn, num_envs, variant=1), st)
-    for variant in (4, 3, 2):
+    for variant in (3, 2):
         eng = make_engine(scene, distn, num_envs, variant=variant)
         got = hip_step(eng, st)
         for key in ref:
@@ -138,7 +138,7 @@ def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [4, 3, 2])
+@pytest.mark.parametrize("variant", [3, 2])
 @pytest.mark.parametrize("name", STEP_FIXTURES_AS_SHIPPED)
 def test_as_shipped_fp16_mode_is_bit_identical_to_the_reference(name, variant):
     """ray_precision 2: the reference AS SHIPPED (Camera.dtype = float16).  Ray distances, wheel / body distances, the
@@ -209,7 +209,7 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
     r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices, shift=shift[0:2])
     want = orc.step(t, r, st, *distn)
     results = []
-    for variant in (4, 3, 2, 1):
+    for variant in (3, 2, 1):
         eng = _lib.Engine(num_envs, device=0)
         eng.set_scene(scene, distn)
         eng.set_option("raycast_variant", variant)
@@ -273,10 +273,10 @@ def test_culled_raycast_changes_no_bit(k, cells):
         eng.set_option("raycast_early_out", 0)
         ref = hip_step(eng, st)
         eng.close()
-        for variant, run in ((3, 0), (3, 7), (3, 64), (4, 0), (4, 13)):      # culled: auto / odd / longest runs of sorted rays per wave; walked
-            eng = make_engine(scene, distn, n, variant=variant, run=run or None)
+        for run in (0, 7, 64):                       # auto / odd / longest runs of sorted rays per wave
+            eng = make_engine(scene, distn, n, variant=3, run=run or None)
             eng.set_option("ray_precision", precision)
-            assert eng.info().raycast_variant == variant
+            assert eng.info().raycast_variant == 3
             got = hip_step(eng, st)
             got2 = hip_step(eng, st)                 # and again on the same engine (queue regions are reused)
             eng.close()
@@ -301,7 +301,7 @@ def test_irregular_mesh_and_k200_all_variants(name, precision):
     st = states_of(fx)
     distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
     outs = {}
-    for variant in (4, 3, 2, 1):
+    for variant in (3, 2, 1):
         if precision == 2 and variant == 1:
             continue                                  # the env-order kernel has no as-shipped fp16 arithmetic
         eng = make_engine(scene, distn, st["pos"].shape[0], variant=variant)
@@ -370,21 +370,6 @@ def test_culled_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine
         most = 0
         # (lazy: the scan kernel that fetches a bin's far records on demand — chosen by the library for small ray sets on meshes whose
         #  cells mostly have a far bound, which this one is not; forced here through the experiment variable, read at rover_create)
-        # the walked ray cast (variant 4: a lane per ray, front entries + levels)
-        eng = make_engine(scene, distn, n, variant=4)
-        eng.set_option("ray_precision", precision)
-        assert eng.info().raycast_variant == 4
-        got = hip_step(eng, st)
-        got2 = hip_step(eng, st)
-        ci = eng.cull_info()
-        eng.close()
-        for key in ref:
-            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} walked precision={precision}")
-            np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} walked precision={precision} (second step)")
-        # the paths a regular mesh never takes: front entries (always-candidates, steep triangles), rays off the all-(B) path,
-        # runs that queue more than the LDS queue holds (cast in segments)
-        assert ci["walk_front_entries"][0] > 0 and ci["rays_both_tests"] > 0 and ci["max_pairs_per_run"] > 1152, ci
-        assert ci["rays"] == n * (distn[0].shape[0] + 26)
         for run, queue_mb, lazy in ((0, None, None), (7, None, "1"), (64, None, "1"), (64, None, "0"), (64, 1, None)):
             if lazy is not None:
                 os.environ["ROVER_CULL_LAZY"] = lazy
@@ -460,7 +445,7 @@ def _ray_sort_layouts(n):
     eng = make_engine(scene, distn, n, variant=1)
     ref = hip_step(eng, st)
     eng.close()
-    for variant in (4, 3, 2):
+    for variant in (3, 2):
         for low_bits in (None, 12, 8):
             eng = make_engine(scene, distn, n, variant=variant)
             if low_bits:
@@ -710,7 +695,7 @@ def test_cell_index_mode_cuda_rcp_matches_oracle_and_differs_on_ties():
     n = st["pos"].shape[0]
     got, want = {}, {}
     for mode, name in ((0, "cpu_div"), (1, "cuda_rcp")):
-        for variant in (4, 3, 2, 1):
+        for variant in (3, 2, 1):
             eng = make_engine(scene, distn, n, variant=variant)
             eng.set_option("cell_index_mode", mode)
             got[(mode, variant)] = hip_step(eng, st)
@@ -720,7 +705,7 @@ def test_cell_index_mode_cuda_rcp_matches_oracle_and_differs_on_ties():
             want[mode] = orc.step(t, r, st, *distn)
         finally:
             orc.set_cell_index_mode("cpu_div")
-        for variant in (4, 3, 2, 1):
+        for variant in (3, 2, 1):
             g = got[(mode, variant)]
             # tie envs: identity orientation -> no trig ulps between OCML and glibc -> the terrain ray must agree bit for bit
             np.testing.assert_array_equal(g["ray_dist"][tie_envs], want[mode]["ray_dist"][tie_envs], err_msg=f"{name} v{variant}")
