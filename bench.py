@@ -88,6 +88,10 @@ def parse(argv=None):
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the ray-cast launch of every n-th timed step with HIP events (roofline.avg_launch_ms is their mean): "
                          "an event pair costs the stream ~12 us around the kernel, 1.8 %% of a step if every step carried one")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` object of the default N = 1 run: the same 65 536-env batch on the irregular (decimated-style) mesh "
+                         "and in the reference's as-shipped fp16 arithmetic, timed in the same process after the headline pass")
+    ap.add_argument("--also-steps", type=int, default=50, help="timed steps of each `also` workload (>= 20)")
     ap.add_argument("--rank-timeout-s", type=float, default=900.0,
                     help="N > 1 self-launch: kill every rank and exit 124 when the run has not finished after this many seconds")
     return ap.parse_args(argv)
@@ -388,6 +392,74 @@ def _checksums(torch, obs, rew, done):
                         done.sum(dtype=torch.int64)))
 
 
+def measure_also(args, device, local_rank, **override):
+    """One more workload in THIS process (N = 1): the same batch size, ray set and maps as the headline with `override` applied
+    (mesh="irregular" / ray_precision="fp16_as_shipped"): scene, engine, four resident state batches, the headline's warm-up rule
+    (clocks are already up: no pre-roll), >= 20 timed steps between device synchronisations, the ray-cast launch bracketed by HIP
+    events on every `--event-every`-th step.  Returns the line's sub-object (value, ms_per_step, ray-cast ms, its own roofline)."""
+    import argparse as _ap
+    import numpy as np
+    import torch
+    from isaac_rover_amd import _lib, synth
+    a = _ap.Namespace(**vars(args))
+    for k, v in override.items():
+        setattr(a, k, v)
+    E = a.envs_per_gpu
+    scene, zf = load_scene(a, device, local_rank)
+    distn = synth.ray_distribution(a.rays)
+    n_rays = int(distn[0].shape[0])
+    eng = _make_engine(E, local_rank, E, 0)
+    eng.set_scene(scene, distn)
+    eng.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[a.ray_precision])
+    eng.set_option("cell_index_mode", {"cpu_div": 0, "cuda_rcp": 1}[a.cell_index_mode])
+    info = eng.info()
+    W = eng.num_observations
+    f, i64 = torch.float32, torch.int64
+    batches = []
+    for b in range(4):
+        st = synth.make_states(E, a.cells * 0.1, seed=b, heightfn=zf)
+        batches.append({k: v.to(device) for k, v in st.items()})
+    obs = torch.zeros(E, W, device=device)
+    rew = torch.zeros(E, device=device)
+    done = torch.zeros(E, dtype=torch.uint8, device=device)
+    reset = torch.ones(E, dtype=i64, device=device)
+    rock = torch.zeros(E, dtype=i64, device=device)
+    extras = {k: torch.zeros(E, dtype=(i64 if k == "collision_penalty" else f), device=device) for k in _lib.EXTRAS}
+    reset_ids = torch.zeros(E, dtype=i64, device=device)
+    n_reset = torch.zeros(1, dtype=torch.int32, device=device)
+    stone = torch.zeros(E, dtype=i64, device=device)
+    sout = eng.make_out(obs, rew=rew, reset=reset, rock_collision=rock, extras=extras, reset_ids=reset_ids, n_reset=n_reset,
+                        stone_collision=stone, stone_margin=0.0, done_u8=done)
+    sins = [eng.make_in(b["pos"], b["quat"], b["joints"], b["target"], b["lin_hist"], b["ang_hist"], b["euler_pre"], b["progress"])
+            for b in batches]
+    steps = max(20, int(a.also_steps))
+    eng.set_profiling(True)
+    for i in range(max(10, a.warmup)):
+        eng.step(sins[i % 4], sout, increment_progress=True, compact=True)
+    _sync()
+    eng.set_profiling(True, every=a.event_every)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.step(sins[i % 4], sout, increment_progress=True, compact=True)
+    _sync()
+    elapsed = time.perf_counter() - t0
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    out = {"value": E * steps / elapsed, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+           "raycast_ms": prof.raycast_ms / max(prof.launches, 1), "dtype": "f16" if a.ray_precision == "fp16_as_shipped" else "f32",
+           "workload": f"{E} envs x ({a.rays} + 26) rays, K={a.k}, {a.cells}x{a.cells} cells, mesh={a.mesh}, ray_precision={a.ray_precision}, "
+                       f"cell_index_mode={a.cell_index_mode}",
+           "roofline": roofline(a, E, n_rays, prof, info, _lib_version())}
+    if info.raycast_variant == 3:
+        ci = eng.cull_info()
+        out["cull"] = {"candidate_pairs_per_ray": ci["pairs_per_ray"], "rays_with_both_tests": ci["rays_both_tests"] / max(ci["rays"], 1),
+                       "rays_far_skipped": ci["rays_far_skipped"] / max(ci["rays"], 1), "triangles": ci["triangles"]}
+    eng.close()
+    del batches, sins, sout, obs
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_rank(args):
     import numpy as np
     import torch
@@ -469,12 +541,15 @@ def run_rank(args):
     def one_step(i, overlap, timed=False):
         b = i % len(batches)
         d = i % depth
-        e0 = _gpu_event() if (timed and world > 1) else None
+        # (timing events on the compute stream cost it ~6 us each: like the in-library ray-cast events they bracket every
+        #  --event-every-th step only, and the waits they measure are scaled up — the N > 1 headline then carries what the N = 1 one does)
+        sampled = timed and world > 1 and (i % max(1, args.event_every)) == 0
+        e0 = _gpu_event() if sampled else None
         gather.wait(d)                       # overlapped mode: the transfer that last read buffer set d must be through
         if e0 is not None:
             wait_events.append((e0, _gpu_event()))
         launch_step(b, d)
-        e0 = _gpu_event() if (timed and world > 1 and not overlap) else None
+        e0 = _gpu_event() if (sampled and not overlap) else None
         gather.gather(d, wait=not overlap)   # (obs, rew, done) of this step to the learner rank
         if e0 is not None:
             wait_events.append((e0, _gpu_event()))
@@ -536,7 +611,7 @@ def run_rank(args):
         per_rank = None
         if world > 1:
             # per rank: its own elapsed time and the time its compute stream spent waiting for (obs, rew, done) transfers
-            waited = sum(a.elapsed_time(b) for a, b in wait_events if a is not None and b is not None) * 1e-3
+            waited = sum(a.elapsed_time(b) for a, b in wait_events if a is not None and b is not None) * 1e-3 * max(1, args.event_every)
             mine = torch.tensor([elapsed, waited], dtype=torch.float64, device=device)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
@@ -629,6 +704,16 @@ def run_rank(args):
                 rc = 3
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, scene, distn, batches[0])
+        default_workload = (world == 1 and args.mesh == "grid" and args.ray_precision == "fp32" and args.rays == "37"
+                            and not args.validate_goals and not args.graph and E == 65536)
+        if default_workload and not args.no_also:
+            # the representative workloads under the same clock: the geometry the reference's real terrain has (a decimated mesh,
+            # utils/terrain_utils/terrain_generation.py:217-243) and its real arithmetic (fp16, camera.py:55) — headline fields unchanged
+            eng.close()
+            del sins, souts, batches
+            torch.cuda.empty_cache()
+            line["also"] = {"mesh_irregular": measure_also(args, device, local_rank, mesh="irregular"),
+                            "fp16_as_shipped": measure_also(args, device, local_rank, ray_precision="fp16_as_shipped")}
         print(json.dumps(line), flush=True)
         if line["lib_built_from_tree"] is False:
             # a number measured on a library built from OTHER sources than the ones next to it is not a number of this tree

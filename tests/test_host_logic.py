@@ -206,6 +206,65 @@ def test_gather_world_size_2_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+_DEPTH2_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ROVER_ROOT"])
+from isaac_rover_amd.distributed import StepGather
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+E, W, STEPS = 512, 41, 9
+g = StepGather(E, W, torch.device("cpu"), world, rank, depth=2)
+def value(step, r):          # what rank r's shard holds after step `step`
+    return 1000.0 * step + 10.0 * r
+seen = []
+for i in range(STEPS):
+    d = i % 2
+    g.wait(d)                                    # the transfer that last read / filled set d (step i - 2) must be through ...
+    if rank == 0 and i >= 2:                     # ... and then the root holds step i - 2 of EVERY shard, whatever happened to the other set since
+        O, R, D = g.global_views(d)
+        for r in range(world):
+            s = slice(r * E, (r + 1) * E)
+            assert torch.all(O[s] == value(i - 2, r)), (i, r, O[s][0, 0].item())
+            assert torch.all(R[s] == value(i - 2, r) + 1.0) and torch.all(D[s] == (i - 2 + r) % 2)
+        seen.append(i - 2)
+    o, rw, dn = g.local_views(d)                 # "the step kernels" of step i write set d
+    o.fill_(value(i, rank)); rw.fill_(value(i, rank) + 1.0); dn.fill_((i + rank) % 2)
+    # injected skew: the sender runs ahead of a slow root on some steps, the root ahead of a slow sender on others, so that a
+    # transfer of set d is still in flight while the other set is being overwritten by the next step
+    if (rank == 0 and i % 3 == 1) or (rank == 1 and i % 3 == 2):
+        time.sleep(0.15)
+    g.gather(d, wait=False)
+for d in range(2):
+    g.wait(d)
+if rank == 0:
+    for i in (STEPS - 2, STEPS - 1):
+        O, R, D = g.global_views(i % 2)
+        for r in range(world):
+            assert torch.all(O[r * E:(r + 1) * E] == value(i, r)), (i, r)
+    assert seen == list(range(STEPS - 2))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gather_depth_2_delivers_every_step_under_skew_gloo(tmp_path):
+    """The overlapped gather of bench.py's N > 1 loop (StepGather(depth=2): the transfer of step i runs while step i + 1 writes the
+    other buffer set; wait(d) before set d is written again): with sleeps injected on alternating sides the root must still find
+    step i - 2 of BOTH shards in set d when it comes back to it — an ordering bug here would be silent on hardware."""
+    script = tmp_path / "worker_depth2.py"
+    script.write_text(_DEPTH2_WORKER)
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ROVER_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
 _BENCH_WORKER = r"""
 import os, sys, json, types, torch
 root = os.environ["ROVER_ROOT"]
