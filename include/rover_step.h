@@ -287,8 +287,8 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        (16 B per triangle, built at rover_set_knn_map) first proves for most (ray, triangle) pairs that ray_casting.py:59
  *        rejects them, and only the remaining candidates get the exact arithmetic (csrc/rover_cull.hip) — in f32 or, with
  *        ray_precision = 2, in the reference's as-shipped fp16 arithmetic (its own, wider proof margins).
- *        All give bit-identical results; auto picks 3 when a step casts more than 131 072 rays (below that the binning passes
- *        cost more than they save: 1, or 2 with ray_precision = 2).
+ *        All give bit-identical results; auto picks 3 when a step casts more than 49 152 rays (24 576 with ray_precision = 2); below
+ *        that the binning passes cost more than the culling saves: 1, or 2 with ray_precision = 2.
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
  *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
  *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.

@@ -162,13 +162,18 @@ static void dfree(T*& p) {
 
 static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_envs * (26u + (uint64_t)c->P); }
 
-// Auto choice, measured on MI355X at K = 200 (tools/ab_raycast.py --step): below ~128 k rays fewer than one ray shares a
-// cell, so the binning passes cost more than they save and the env-order kernel wins (1 024 envs: 72 vs 84 us per step).
+// Auto choice, measured on MI355X at K = 200, 37 + 26 rays (round 4, one call per size, whole step): the culled ray cast passes the
+// env-order kernel between 512 and 1 024 envs (32 k / 64 k rays: 9.8 vs 11.0 M env-steps/s at 512 — the four sort launches cost more than
+// the culling saves —, 16.5 vs 14.6 M at 1 024, 25.8 vs 17.0 M at 2 048); in the as-shipped fp16 arithmetic it is ahead of the binned
+// kernel from 512 envs on (9.1 vs 8.1, 14.0 vs 12.4, 20.6 vs 17.2 M).  (Until round 4 the switch sat at 131 072 rays: round 2's
+// measurement, when the ray cast behind the sort was the every-triangle kernel.)
+#define ROVER_AUTO_CULL_RAYS_F32 49152u
+#define ROVER_AUTO_CULL_RAYS_F16 24576u
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
-    if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= 131072u) return 1;
-    if (c->variant == 0 && c->precision == 2 && c->have_dist && valid_rays(c) <= 131072u) return 2;      // small batches, as shipped: binned
+    if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= ROVER_AUTO_CULL_RAYS_F32) return 1;
+    if (c->variant == 0 && c->precision == 2 && c->have_dist && valid_rays(c) <= ROVER_AUTO_CULL_RAYS_F16) return 2;      // small batches, as shipped: binned
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
@@ -183,7 +188,20 @@ static uint32_t effective_run(const rover_ctx* c) {
     const uint64_t r = valid_rays(c) / 65536u;
     // the culled ray cast (round 3, one call each: 4 096 envs run 4 / 8 / 16 / 32 -> 0.155 / 0.151 / 0.161 / 0.173 ms per step;
     // 8 192 envs 0.246 / 0.227 / 0.236 / 0.249; 16 384 envs 0.407 / 0.335 / 0.331 / 0.343): small batches want many short-lived waves
-    if (effective_variant(c) == 3) return r < 12 ? 8u : (r < 24 ? 16u : (r < 48 ? 32u : 64u));        // powers of two: 63 instead of 64 cost 6 %
+    // (round 4, on the final kernels, whole step in M env-steps/s at 37 + 26 rays, one call: 1 024 envs run 4 / 8 / 16 / 32 -> 16.0 / 16.5 / 16.2 /
+    //  13.4; 2 048: 23.9 / 25.9 / 25.7 / 24.0; 4 096 run 8 / 16 / 32: 37.0 / 37.9 / 36.5; 8 192 run 8 / 16 / 32 / 64: 49.0 / 52.4 / 52.8 / 51.4;
+    //  16 384 run 16 / 32 / 64: 68.8 / 71.9 / 72.3; 32 768 run 32 / 64: 96.0 / 97.9; 49 152: 109.1 / 112.5 — since the one-wave workgroups
+    //  and the LDS-first queue of round 3 longer runs win earlier than the table above, measured before them, said)
+    //  A wave's life is longer where a ray has more candidates — an irregular mesh (8.6 pairs per ray against 3.6), the as-shipped fp16
+    //  arithmetic (8.1) — and there shorter runs still balance better (irregular mesh, run 8 / 16 / 32 / 64: 4 096 envs 30.2 / 29.5 / 27.1 / 25.6;
+    //  8 192: 39.0 / 39.7 / 37.8 / 36.7; 16 384: 49.1 / 53.0 / 52.7 / 51.3; 32 768: 58.8 / 66.0 / 68.2 / 67.2; 65 536: 66.0 / 77.7 / 82.4 / 81.8;
+    //  fp16 at 8 192 envs: 36.3 / 36.0 / 34.8 / 34.1): they keep the older table.  The native ray set on the regular mesh: 512 envs run 16 / 32 /
+    //  64 -> 2.56 / 2.61 / 2.46, 1 024 envs 3.10 / 3.33 / 3.32.)
+    if (effective_variant(c) == 3) {
+        const bool quick_rays = c->precision != 2 && 2 * c->cull_farok[0] >= c->cull_cells[0];      // regular mesh (most cells have a far bound), f32 arithmetic
+        if (quick_rays) return r < 3 ? 8u : (r < 6 ? 16u : (r < 20 ? 32u : 64u));                   // powers of two: 63 instead of 64 cost 6 %
+        return r < 12 ? 8u : (r < 24 ? 16u : (r < 48 ? 32u : 64u));
+    }
     return (uint32_t)(r < 4 ? 4 : (r > 32 ? 32 : r));
 }
 
@@ -385,7 +403,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
-    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 2) ? x : 0; }
+    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 3) ? x : 0; }
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }

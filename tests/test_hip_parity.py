@@ -491,8 +491,8 @@ def test_rays_that_clear_their_cell_are_not_scanned():
 
 
 def test_auto_variant_and_run_selection():
-    """raycast_variant 0 (auto): the env-order kernel below ~128 k rays per step, the culled kernel above (the binned one
-    whenever the as-shipped fp16 maths are asked for); K8 > 256 always falls back to the env-order kernel."""
+    """raycast_variant 0 (auto): the env-order kernel up to 49 152 rays per step, the culled kernel above (as shipped: the binned
+    kernel up to 24 576 rays, the culled one above); K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=16, n_stones=8)
@@ -501,6 +501,12 @@ def test_auto_variant_and_run_selection():
     assert small.info().raycast_variant == 1
     small.set_option("ray_precision", 2)
     assert small.info().raycast_variant == 2
+    for n, want32, want16 in ((512, 1, 3), (1024, 3, 3)):          # 32 256 / 64 512 rays: either side of the f32 switch, both above the fp16 one
+        mid = make_engine(scene, distn, n, variant=None)
+        assert mid.info().raycast_variant == want32
+        mid.set_option("ray_precision", 2)
+        assert mid.info().raycast_variant == want16
+        mid.close()
     big = make_engine(scene, distn, 4096, variant=None)
     assert big.info().raycast_variant == 3
     big.set_option("ray_precision", 2)
