@@ -64,7 +64,6 @@ struct rover_ctx {
     float* d_euler = nullptr;       // [E,3]
     float* d_heading = nullptr;     // [E]
     int64_t* d_ids_work = nullptr;  // [E]
-    float* d_env_rec = nullptr;     // [15][E] float4 chunks (ENV_CHUNKS, rover_kernels.hip)
     uint32_t* d_goal_work = nullptr;// [2][E] work lists of generate_goals
     uint32_t* d_block_cnt = nullptr;// [ceil(E/256)]
     // ray binning (raycast variant 2)
@@ -265,7 +264,7 @@ static int alloc_cull_queue(rover_ctx* c) {
 static int alloc_workspace(rover_ctx* c) {
     c->ws_ok = false;
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_sorted);
-    dfree(c->d_env_rec); dfree(c->d_bins); dfree(c->d_pairs);
+    dfree(c->d_bins); dfree(c->d_pairs);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
     c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
     const uint64_t n = E * c->R8;
@@ -275,12 +274,11 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_euler, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_heading, E * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_env_rec, E * 60 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_bins, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_pairs, n * sizeof(uint2)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
-    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (64 * sizeof(float) + sizeof(int64_t));
+    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (4 * sizeof(float) + sizeof(int64_t));
     c->rays_valid = false;
     c->ws_ok = true;
     return alloc_bins(c);
@@ -428,7 +426,7 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_stones);
     { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); float4* q = const_cast<float4*>(c->sgrid.stone_xyr); dfree(q); }
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
-    dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted); dfree(c->d_env_rec);
+    dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted);
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
     dfree(c->d_cull_queue); dfree(c->d_cull_stats); dfree(c->d_mlp_scratch);
@@ -693,7 +691,11 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     // The kernel that fetches a bin's far records only when a ray needs them pays where most bins skip them: small ray sets (few rays
     // per bin) on a terrain map whose cells mostly have a useful far bound (a regular grid: all of them; an irregular mesh with
     // triangles that span many cells: few — there the second, dependent round of gathers cost 3 %).
-    const bool lazy_auto = 26 + c->P < 100 && 2 * c->cull_farok[0] >= c->cull_cells[0];
+    // (round 4: what decides is the rays per bin, not the size of the ray set — 120 + 26 rays at 16 384 / 4 096 envs hold 5.8 / 2.1 rays per
+    //  bin and gain 2.8 / 3.7 % from the on-demand kernel; the estimate is heightmap rays per terrain cell for rovers spread over the map.
+    //  The native 1 634-point set is dense — 3.2 rays per bin already at 512 envs — and keeps the eager kernel: -1 ... -5 % otherwise.)
+    const bool few_per_bin = c->P <= 260 && (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 8ull * (uint64_t)c->cull_cells[0];
+    const bool lazy_auto = (26 + c->P < 100 || few_per_bin) && 2 * c->cull_farok[0] >= c->cull_cells[0];
     a.lazy_far = (c->cull_lazy < 0 ? lazy_auto : c->cull_lazy != 0) ? 1 : 0;
     // rays that clear their whole cell are left out of the scan where some do: a mesh whose cells mostly have a usable bound, and rock
     // rays (the ones that qualify) at least a tenth of the ray set (120 + 26 rays: 12 % of the rays, +3.8 %; the native 1 634 + 26: none)
@@ -717,7 +719,7 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     p.E = E; p.P = (uint32_t)c->P; p.R8 = c->R8;
     p.pos = pos; p.quat = quat; p.joints = joints; p.target = target; p.euler_in = euler_in;
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
-    p.rays = c->d_rays; p.euler = euler_in ? nullptr : c->d_euler; p.heading = euler_in ? nullptr : c->d_heading; p.env_rec = c->d_env_rec;
+    p.rays = c->d_rays; p.euler = euler_in ? nullptr : c->d_euler; p.heading = euler_in ? nullptr : c->d_heading;
     const int variant = effective_variant(c);
     // (the queue is sized by every call that changes its size — never here: no hipMalloc inside a step / a stream capture)
     if (variant == 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))

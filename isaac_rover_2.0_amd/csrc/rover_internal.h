@@ -45,7 +45,6 @@ struct PrepArgs {
     KnnDev terrain, rocks;
     RayRec* rays;                // [E*R8]
     float *euler, *heading;      // [E,3], [E]
-    float* env_rec;              // [15][E] float4: per-env euler / heading / sin-cos record (prep_env_kernel)
     uint32_t* bin_out;           // optional [E*R8]: bin = (map, cell) key of every slot for the bucket sort (binned ray cast)
     uint32_t rocks_bin_offset;   // first bin of the rocks map (= terrain X*Y)
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)

@@ -13,8 +13,8 @@
 //
 // Kernels (one step = the ten launches marked *):
 //   repack_knn_kernel        init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8], near/far halves per lane
-// * prep_env_kernel          1 thread / (env, part): quat -> euler, heading, every sin/cos of the pose and joint chain
-// * prep_rays_kernel         1 thread / (env, ray slot): ray origin, unit direction, cell id, bin key               (A4, A6)
+// * prep_rays_kernel         1 thread / (env, ray slot): quat -> euler, heading and the pose's sin/cos per block of 64 envs, then ray
+//                            origin, unit direction, cell id, bin key                                              (A2, A4, A6)
 // * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell) without global atomics
 // * raycast_binned_kernel    1 wave / run of sorted rays, 4 triangles per lane in registers, conservative early out  (A4, A5) <- roofline kernel
 //   raycast_binned_h_kernel  the same in the reference's as-shipped fp16 arithmetic (ray_precision 2)
@@ -157,64 +157,17 @@ __constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0,
                                   {0, 0, 0.03}, {0, 0, 0.03}};
 __constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
 
-// per env: quaternion -> euler, heading, and every sin/cos the ray transforms need — fifteen float4 chunks per env, stored
-// chunk-major ([ENV_CHUNKS][E] float4): a store instruction of prep_env_kernel then writes 1 KB in a row (env-major, each of its
-// 46 dword stores touched 64 cache lines: 3 M partial-line writes per launch, 13 us), and prep_rays_kernel reads four chunks.
-//   chunk 0        roll, pitch, yaw, heading_diff
-//   chunk 1, 2     sin/cos of -roll, -pitch | -yaw, 0, 0 (Trig6)
-//   chunk 3 + 2w   wheel w: sin/cos(-steer), sin/cos(susX)       chunk 4 + 2w: sin/cos(susY), 0, 0   (rock_detect.py:248-272)
-#define ENV_CHUNKS 15
-// One thread per (env, part): part 0 (blockIdx.y) the pose — quaternion -> euler, heading, the body trig — parts 1..3 two wheels each.
-// (One thread per env did all ~36 sin / cos / atan2 calls in a row with a single wave on each SIMD: 10.4 us, nearly all of it
-//  dependent arithmetic; as four waves of a third of the work each the same instructions overlap.)  Loads first, stores last
-// (the compiler may not move a load above a store it cannot prove disjoint).
-__global__ void __launch_bounds__(256) prep_env_kernel(PrepArgs a) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= a.E) return;
-    float4* r = reinterpret_cast<float4*>(a.env_rec) + e;      // chunk k of this env: r[k * E]
-    const size_t E = a.E;
-    if (blockIdx.y == 0u) {
-        // (rover_get_depths: the pose comes as euler angles — camera.py:60 takes `rotations` — and there is no quaternion / target)
-        const float* qp = a.euler_in ? a.euler_in : a.quat + 4ull * e;
-        const float q[4] = {qp[0], qp[1], qp[2], a.euler_in ? 0.0f : qp[3]};
-        const float* tp = a.target ? a.target : a.pos;
-        const float tx = tp[3ull * e] - a.pos[3ull * e], ty = tp[3ull * e + 1] - a.pos[3ull * e + 1];
-        float roll, pitch, yaw;
-        quat_to_euler(q, roll, pitch, yaw);
-        if (a.euler_in) { roll = a.euler_in[3ull * e]; pitch = a.euler_in[3ull * e + 1]; yaw = a.euler_in[3ull * e + 2]; }
-        float hx = cosf(yaw), hy = sinf(yaw);                                           // heading_diff, rover.py:279-283
-        float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
-        Trig6 t = euler_trig(roll, pitch, yaw);
-        if (a.euler) { a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw; }
-        if (a.heading) a.heading[e] = hd;
-        r[0] = make_float4(roll, pitch, yaw, hd);
-        r[1 * E] = make_float4(t.sx, t.cx, t.sy, t.cy);
-        r[2 * E] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
-        return;
-    }
-    const float* j = a.joints ? a.joints + 13ull * e : nullptr;        // (null: rover_get_depths casts the heightmap rays only; joints at rest)
-    const float j0 = j ? j[0] : 0.0f, j1 = j ? j[1] : 0.0f, j2 = j ? j[2] : 0.0f, j4 = j ? j[4] : 0.0f, j6 = j ? j[6] : 0.0f,
-                j7 = j ? j[7] : 0.0f, j8 = j ? j[8] : 0.0f;
-#pragma unroll
-    for (int w = 0; w < 6; ++w) {
-        if ((uint32_t)(w >> 1) + 1u != blockIdx.y) continue;
-        float steer = (w == 0) ? j4 : (w == 1) ? j6 : (w == 4) ? -j7 : (w == 5) ? j8 : 0.0f;            // :248
-        float susY = (w == 0 || w == 2) ? -j0 : (w == 1 || w == 3) ? j1 : 0.0f;                          // :263
-        float susX = (w >= 4) ? -j2 : 0.0f;                                                              // :264
-        const float4 c0 = make_float4(sinf(-steer), cosf(-steer), sinf(susX), cosf(susX));
-        const float4 c1 = make_float4(sinf(susY), cosf(susY), 0.0f, 0.0f);
-        r[(3 + 2 * w) * E] = c0;
-        r[(4 + 2 * w) * E] = c1;
-    }
-}
-
 // per (env, slot): ray origin, unit direction, cell id, bin key.
 // A workgroup takes 64 envs x 8 ray slots: wave w works on ONE slot (slot0 + w) of 64 consecutive envs, so the three kinds of slot —
 // wheel rays (f32 joint chain), body rays, heightmap rays (f64 transform) — never share a wave.  (One wave per env, lane = slot, ran all
 // three branches in every wave: 373 VALU instructions for work of ~120, 46 us, and neither its stores (-5 us without any) nor the f64
-// arithmetic (f32 instead: no change) were what it waited for.)  The env-record chunks load coalesced (chunk-major: 64 consecutive envs),
-// the slot's constants are wave-uniform.  The 64 x 8 records leave through LDS: per env the 8 slots are 256 contiguous bytes.
+// arithmetic (f32 instead: no change) were what it waited for.)  The slot's constants are wave-uniform.  The 64 x 8 records leave through LDS: per env the 8 slots are 256 contiguous bytes.
 #define PREP_SLOTS 8
+// The block first builds what it needs of its 64 envs' poses (round 4; until then a kernel of its own, prep_env_kernel, wrote a 240-byte
+// record per env that this kernel read back: one launch more — 5 us at 512 envs, where every launch of the step sits on the launch floor,
+// 4 us at 65 536): wave 0 the quaternion -> euler angles, the heading and the body's six sin / cos (the block of slot group 0 also
+// writes euler / heading out), waves 1 and 2 the six sin / cos of the two wheels the block's slots belong to (slot groups 0..2:
+// steer, suspension — rock_detect.py:248-272); one barrier.
 __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a) {
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t e0 = blockIdx.x * 64u, slot0 = blockIdx.y * PREP_SLOTS;
@@ -226,12 +179,45 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a) 
     const uint32_t n_real = 26u + a.P;
     // every load of the slot's branch is issued here, from clamped (always valid) addresses
     const uint32_t ec = min(e, a.E - 1u);
-    const float4* er = reinterpret_cast<const float4*>(a.env_rec) + ec;                  // chunk k of the env: er[k * E]
-    const size_t EE = a.E;
-    const uint32_t wq = min(slot >> 2, 5u);                                              // wheel of slots 0..23
     const uint32_t pq = (slot >= 26u) ? min(slot - 26u, a.P - 1u) : 0u;                  // distribution point of slots 26..
     const float px = a.pos[3ull * ec], py = a.pos[3ull * ec + 1], pz = a.pos[3ull * ec + 2];
-    const float4 c1 = er[EE], c2 = er[2 * EE], cw = er[(3u + 2u * wq) * EE], cv = er[(4u + 2u * wq) * EE];
+    float4 c1, c2, cw, cv;
+    {
+        __shared__ float4 s_body[2][64];            // Trig6 of the 64 envs (chunks 1, 2 of the env record)
+        __shared__ float4 s_wheel[2][2][64];        // [wheel of the slot group][chunk][env]
+        if (w == 0u) {
+            const float* qp = a.euler_in ? a.euler_in : a.quat + 4ull * ec;
+            const float q[4] = {qp[0], qp[1], qp[2], a.euler_in ? 0.0f : qp[3]};
+            const float* tp = a.target ? a.target : a.pos;
+            const float tx = tp[3ull * ec] - px, ty = tp[3ull * ec + 1] - py;
+            float roll, pitch, yaw;
+            quat_to_euler(q, roll, pitch, yaw);
+            if (a.euler_in) { roll = a.euler_in[3ull * ec]; pitch = a.euler_in[3ull * ec + 1]; yaw = a.euler_in[3ull * ec + 2]; }
+            const float hx = cosf(yaw), hy = sinf(yaw);                                   // heading_diff, rover.py:279-283
+            const float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
+            const Trig6 t = euler_trig(roll, pitch, yaw);
+            if (blockIdx.y == 0u && live) {
+                if (a.euler) { a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw; }
+                if (a.heading) a.heading[e] = hd;
+            }
+            s_body[0][lane] = make_float4(t.sx, t.cx, t.sy, t.cy);
+            s_body[1][lane] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
+        } else if (w <= 2u && slot0 < 24u) {
+            const uint32_t wh = (slot0 >> 2) + (w - 1u);                                  // wheels 2 g, 2 g + 1 of slot group g
+            const float* j = a.joints ? a.joints + 13ull * ec : nullptr;
+            const float j0 = j ? j[0] : 0.0f, j1 = j ? j[1] : 0.0f, j2 = j ? j[2] : 0.0f, j4 = j ? j[4] : 0.0f, j6 = j ? j[6] : 0.0f,
+                        j7 = j ? j[7] : 0.0f, j8 = j ? j[8] : 0.0f;
+            const float steer = (wh == 0) ? j4 : (wh == 1) ? j6 : (wh == 4) ? -j7 : (wh == 5) ? j8 : 0.0f;         // :248
+            const float susY = (wh == 0 || wh == 2) ? -j0 : (wh == 1 || wh == 3) ? j1 : 0.0f;                      // :263
+            const float susX = (wh >= 4) ? -j2 : 0.0f;                                                           // :264
+            s_wheel[w - 1u][0][lane] = make_float4(sinf(-steer), cosf(-steer), sinf(susX), cosf(susX));
+            s_wheel[w - 1u][1][lane] = make_float4(sinf(susY), cosf(susY), 0.0f, 0.0f);
+        }
+        __syncthreads();
+        c1 = s_body[0][lane]; c2 = s_body[1][lane];
+        const uint32_t wsel = (slot >> 2) & 1u;                                           // which of the group's two wheels the slot is on
+        cw = s_wheel[wsel][0][lane]; cv = s_wheel[wsel][1][lane];                          // (read by slots >= 24 too: unused there)
+    }
     const float2 t01 = make_float2(c1.x, c1.y), t23 = make_float2(c1.z, c1.w), t45 = make_float2(c2.x, c2.y);
     const float2 q01 = make_float2(cw.x, cw.y), q23 = make_float2(cw.z, cw.w), q45 = make_float2(cv.x, cv.y);
     const double dpx = a.dist[3ull * pq], dpy = a.dist[3ull * pq + 1], dpz = a.dist[3ull * pq + 2];
@@ -1561,7 +1547,6 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 }
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(prep_env_kernel, dim3(blocks_for(a.E, 256), 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(a.E, 64), a.R8 / PREP_SLOTS), dim3(64 * PREP_SLOTS), 0, s, a);       // (R8 is a multiple of 8)
     return hipGetLastError();
 }
