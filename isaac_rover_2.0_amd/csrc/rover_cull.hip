@@ -671,8 +671,8 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // The cell's record (far_build_kernel): the bound of its far pairs and its normal cone, ONE gather per lane.
     // conemask bit i: the cone of ray i's cell covers the ray (the ray's own bound: flags bits 16..31) — test (B) holds for every triangle
     // of the cell, the scan runs test (A) only.  farskip bit i: ray i clears every FAR triangle of its cell (slot 1 of every lane) at
-    // once, so on the cone path its scan skips slot 1 altogether (f32 proof only: with the fp16 proof's c_a the bound rarely holds,
-    // and its kernel has no registers to spare).
+    // once, so on the cone path its scan skips slot 1 altogether (the fp16 proof's kernels: the SKIP ones only — with that proof's c_a the
+    // bound holds for 39 % of the rays instead of 84 %).
     const float4* fr = (kmap ? far1 : far0) + 2ull * kcell;
     const float4 fb = fr[1];                                                  // {Cx, Cy, q16, -}
     const uint64_t conemask = __builtin_amdgcn_ballot_w64(__float_as_uint(fb.z) >= (rflags >> 16));
@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // with 120 + 26); on the irregular mesh 1 % qualify and dropping dead bins / walking live rays costs 2 % (6 % before the per-lane word).
     constexpr bool SKIP = SKIPT != 0;
     uint64_t farskip = 0, skipall = 0;
-    if (!H) {
+    if (!H || SKIP) {
         const float4 fa = fr[0];                                              // {G, z0, z1, rho_out} of the far pairs
         // (hardware square roots, 1 ulp, and no division — the inequality is multiplied through by |d_z| — the margins are 1e-4)
         const float ox = rsa.x - fb.x, oy = rsa.y - fb.y, o = __builtin_amdgcn_sqrtf(ox * ox + oy * oy);
@@ -914,6 +914,9 @@ static void cull_far_consts(double c_a, double dd, float* k1, float* k2) {
 float cull_far_k2(int half, CullProofH ph) {
     float k1, k2;
     if (half) cull_far_consts(ph.c_a, 1.004, &k1, &k2); else cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    // (the scan kernel bounds |h . d| with the ray's direction as stored; the derivation's a is the axial part along the UNIT direction,
+    //  and the fp16-normalised d of the as-shipped arithmetic has |d|^2 >= 0.996: a <= |h . d| / 0.998)
+    if (half) k2 *= 1.0021f;
     return k2;
 }
 
@@ -985,7 +988,8 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     // of the slot list, one launch each on the same stream, re-using the regions
     for (uint32_t j0 = 0; j0 < slots; j0 += per) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
-        auto kern = a.half ? cull_scan_kernel<1, 0, 0> : (a.lazy_far ? cull_scan_kernel<0, 1, 1> : (a.skip_clear ? cull_scan_kernel<0, 0, 1> : cull_scan_kernel<0, 0, 0>));
+        auto kern = a.half ? (a.skip_clear ? (a.lazy_far ? cull_scan_kernel<1, 1, 1> : cull_scan_kernel<1, 0, 1>) : cull_scan_kernel<1, 0, 0>)
+                           : (a.lazy_far ? cull_scan_kernel<0, 1, 1> : (a.skip_clear ? cull_scan_kernel<0, 0, 1> : cull_scan_kernel<0, 0, 0>));
         hipLaunchKernelGGL(kern, dim3(n * 8u * (4u / CULL_WPB)), dim3(64 * CULL_WPB), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
