@@ -36,18 +36,28 @@ namespace rover {
 // shared device maths (same operation order as oracle/rover_oracle.c, which cites the reference lines)
 // ---------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void quat_to_euler(const float* __restrict__ q, float& roll, float& pitch, float& yaw) {
-    const float half_pi = 3.1415927410125732f / 2.0f;
+// tensor_quat_to_euler.py:17-29, one angle at a time (prep_rays_kernel gives each to a wave of its own)
+__device__ __forceinline__ float quat_roll(const float* __restrict__ q) {
     float w = q[0], x = q[1], y = q[2], z = q[3];
     float sinr = 2.0f * (w * x + y * z);
     float cosr = 1.0f - (2.0f * (x * x + y * y));
-    roll = atan2f(sinr, cosr);
+    return atan2f(sinr, cosr);
+}
+__device__ __forceinline__ float quat_pitch(const float* __restrict__ q) {
+    const float half_pi = 3.1415927410125732f / 2.0f;
+    float w = q[0], x = q[1], y = q[2], z = q[3];
     float sinp = 2.0f * (w * y - z * x);
     float t = sinp - 1.0f;
-    pitch = (t >= 0.0f) ? copysignf(half_pi, sinp) : asinf(sinp);
+    return (t >= 0.0f) ? copysignf(half_pi, sinp) : asinf(sinp);
+}
+__device__ __forceinline__ float quat_yaw(const float* __restrict__ q) {
+    float w = q[0], x = q[1], y = q[2], z = q[3];
     float siny = 2.0f * (w * z + x * y);
     float cosy = 1.0f - (2.0f * (y * y + z * z));
-    yaw = atan2f(siny, cosy);
+    return atan2f(siny, cosy);
+}
+__device__ __forceinline__ void quat_to_euler(const float* __restrict__ q, float& roll, float& pitch, float& yaw) {
+    roll = quat_roll(q); pitch = quat_pitch(q); yaw = quat_yaw(q);
 }
 
 struct Trig6 { float sx, cx, sy, cy, sz, cz; };
@@ -165,9 +175,9 @@ __constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
 #define PREP_SLOTS 8
 // The block first builds what it needs of its 64 envs' poses (round 4; until then a kernel of its own, prep_env_kernel, wrote a 240-byte
 // record per env that this kernel read back: one launch more — 5 us at 512 envs, where every launch of the step sits on the launch floor,
-// 4 us at 65 536): wave 0 the quaternion -> euler angles, the heading and the body's six sin / cos (the block of slot group 0 also
-// writes euler / heading out), waves 1 and 2 the six sin / cos of the two wheels the block's slots belong to (slot groups 0..2:
-// steer, suspension — rock_detect.py:248-272); one barrier.
+// 4 us at 65 536): waves 0, 1, 2 one euler angle each with its sin / cos (wave 2 also the heading; the block of slot group 0 writes
+// euler / heading out), waves 3 and 4 the six sin / cos of the two wheels the block's slots belong to (slot groups 0..2: steer,
+// suspension — rock_detect.py:248-272); one barrier.
 __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a) {
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t e0 = blockIdx.x * 64u, slot0 = blockIdx.y * PREP_SLOTS;
@@ -183,38 +193,39 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a) 
     const float px = a.pos[3ull * ec], py = a.pos[3ull * ec + 1], pz = a.pos[3ull * ec + 2];
     float4 c1, c2, cw, cv;
     {
-        __shared__ float4 s_body[2][64];            // Trig6 of the 64 envs (chunks 1, 2 of the env record)
-        __shared__ float4 s_wheel[2][2][64];        // [wheel of the slot group][chunk][env]
-        if (w == 0u) {
+        __shared__ float2 s_trig[3][64];            // (sin, cos) of -roll, -pitch, -yaw of the block's 64 envs
+        __shared__ float4 s_wheel[2][2][64];        // [wheel of the slot group][sin / cos of -steer, susX | susY][env]
+        if (w < 3u) {
+            // waves 0, 1, 2: roll, pitch, yaw — each one atan2 / asin and one sin / cos pair (wave 2 also the heading): a third of the
+            // dependent chain each (one wave doing all three angles kept the other seven waiting 1.5 us at the barrier)
             const float* qp = a.euler_in ? a.euler_in : a.quat + 4ull * ec;
             const float q[4] = {qp[0], qp[1], qp[2], a.euler_in ? 0.0f : qp[3]};
-            const float* tp = a.target ? a.target : a.pos;
-            const float tx = tp[3ull * ec] - px, ty = tp[3ull * ec + 1] - py;
-            float roll, pitch, yaw;
-            quat_to_euler(q, roll, pitch, yaw);
-            if (a.euler_in) { roll = a.euler_in[3ull * ec]; pitch = a.euler_in[3ull * ec + 1]; yaw = a.euler_in[3ull * ec + 2]; }
-            const float hx = cosf(yaw), hy = sinf(yaw);                                   // heading_diff, rover.py:279-283
-            const float hd = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
-            const Trig6 t = euler_trig(roll, pitch, yaw);
+            float ang = w == 0u ? quat_roll(q) : (w == 1u ? quat_pitch(q) : quat_yaw(q));
+            if (a.euler_in) ang = a.euler_in[3ull * ec + w];
+            s_trig[w][lane] = make_float2(sinf(-ang), cosf(-ang));
             if (blockIdx.y == 0u && live) {
-                if (a.euler) { a.euler[3ull * e] = roll; a.euler[3ull * e + 1] = pitch; a.euler[3ull * e + 2] = yaw; }
-                if (a.heading) a.heading[e] = hd;
+                if (a.euler) a.euler[3ull * e + w] = ang;
+                if (w == 2u && a.heading) {
+                    const float* tp = a.target ? a.target : a.pos;
+                    const float tx = tp[3ull * ec] - px, ty = tp[3ull * ec + 1] - py;
+                    const float hx = cosf(ang), hy = sinf(ang);                           // heading_diff, rover.py:279-283
+                    a.heading[e] = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
+                }
             }
-            s_body[0][lane] = make_float4(t.sx, t.cx, t.sy, t.cy);
-            s_body[1][lane] = make_float4(t.sz, t.cz, 0.0f, 0.0f);
-        } else if (w <= 2u && slot0 < 24u) {
-            const uint32_t wh = (slot0 >> 2) + (w - 1u);                                  // wheels 2 g, 2 g + 1 of slot group g
+        } else if (w <= 4u && slot0 < 24u) {
+            const uint32_t wh = (slot0 >> 2) + (w - 3u);                                  // wheels 2 g, 2 g + 1 of slot group g
             const float* j = a.joints ? a.joints + 13ull * ec : nullptr;
             const float j0 = j ? j[0] : 0.0f, j1 = j ? j[1] : 0.0f, j2 = j ? j[2] : 0.0f, j4 = j ? j[4] : 0.0f, j6 = j ? j[6] : 0.0f,
                         j7 = j ? j[7] : 0.0f, j8 = j ? j[8] : 0.0f;
             const float steer = (wh == 0) ? j4 : (wh == 1) ? j6 : (wh == 4) ? -j7 : (wh == 5) ? j8 : 0.0f;         // :248
             const float susY = (wh == 0 || wh == 2) ? -j0 : (wh == 1 || wh == 3) ? j1 : 0.0f;                      // :263
             const float susX = (wh >= 4) ? -j2 : 0.0f;                                                           // :264
-            s_wheel[w - 1u][0][lane] = make_float4(sinf(-steer), cosf(-steer), sinf(susX), cosf(susX));
-            s_wheel[w - 1u][1][lane] = make_float4(sinf(susY), cosf(susY), 0.0f, 0.0f);
+            s_wheel[w - 3u][0][lane] = make_float4(sinf(-steer), cosf(-steer), sinf(susX), cosf(susX));
+            s_wheel[w - 3u][1][lane] = make_float4(sinf(susY), cosf(susY), 0.0f, 0.0f);
         }
         __syncthreads();
-        c1 = s_body[0][lane]; c2 = s_body[1][lane];
+        const float2 tr = s_trig[0][lane], tp2 = s_trig[1][lane], ty2 = s_trig[2][lane];
+        c1 = make_float4(tr.x, tr.y, tp2.x, tp2.y); c2 = make_float4(ty2.x, ty2.y, 0.0f, 0.0f);
         const uint32_t wsel = (slot >> 2) & 1u;                                           // which of the group's two wheels the slot is on
         cw = s_wheel[wsel][0][lane]; cv = s_wheel[wsel][1][lane];                          // (read by slots >= 24 too: unused there)
     }
