@@ -954,7 +954,8 @@ static CullGrid cull_grid(uint32_t n_sorted, uint32_t n_terrain, uint32_t run) {
     // the sorted list is all terrain rays, then all rock rays: blocks [0, split) are (but for a few rays) terrain
     // The rocks part comes last on every XCD and drains the launch: with runs of 32 there its waves live half as long and the
     // machine empties faster at the end (last workgroup start to kernel end was 70 us of 580) — 0.575 -> 0.570 ms; 16: 0.581
-    g.run_r = run >= 64u ? 32u : run;
+    // (round 4: runs of 32 take 16 there too — 8 192 envs 53.7 -> 54.9 M env-steps/s, 12 288 envs 63.5 -> 64.2, 16 384 envs the same; 8: slower)
+    g.run_r = run >= 32u ? run / 2u : run;
     g.split = blocks_for(blocks_for(n_terrain, run), 4);
     const uint64_t covered = (uint64_t)g.split * 4u * run;
     if (covered >= n_sorted) { g.split = blocks_for(blocks_for(n_sorted, run), 4); g.n_blocks = g.split; }
@@ -1002,7 +1003,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run) {
     if (run > CULL_RUNMAX) run = CULL_RUNMAX;
     if (run == 0) run = 1;
-    const uint32_t rr = run >= 64u ? 32u : run;                     // the rocks part walks shorter runs (cull_grid)
+    const uint32_t rr = run >= 32u ? run / 2u : run;                // the rocks part walks shorter runs (cull_grid)
     return (uint32_t)(4u * ((n_rays / rr + 4u) / 4u + 3u));
 }
 
