@@ -51,6 +51,41 @@ def test_wrong_tensor_shapes_are_refused_on_the_host():
     eng.close()
 
 
+def test_get_depths_argument_checks():
+    """rover_get_depths: null poses and a ctx without its tables are refused; wrong shapes are refused on the host; the call leaves
+    the observation state of the ctx (euler / heading of the last step) alone."""
+    from isaac_rover_amd import _lib, synth
+    eng, scene = _engine(16)
+    lib, dev = eng.lib, eng.device
+    assert lib.rover_get_depths(eng._h, None, None, None, None, None, None) == -1
+    assert b"positions and rotations" in lib.rover_last_error(eng._h)
+    with pytest.raises(_lib.RoverError, match="rotations"):
+        eng.get_depths(torch.zeros(16, 3, device=dev), torch.zeros(16, 4, device=dev))
+    bare = _lib.Engine(16, device=0)
+    with pytest.raises(_lib.RoverError, match="maps must be set"):
+        bare.get_depths(torch.zeros(16, 3, device=dev), torch.zeros(16, 3, device=dev))
+    bare.close()
+    # a step, then get_depths on OTHER poses, then the metrics of the step: the heading the metrics read is still the step's
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from hip_helpers import hip_step
+    st = synth.make_states(16, 3.2, seed=4)
+    a = hip_step(eng, st, fused=False)
+    d = {k: v.to(dev).contiguous() for k, v in st.items()}
+    sin = eng.make_in(d["pos"], d["quat"], d["joints"], d["target"], d["lin_hist"], d["ang_hist"], d["euler_pre"], d["progress"].clone())
+    obs = torch.zeros(16, eng.num_observations, device=dev)
+    rew = torch.zeros(16, device=dev); rock = torch.zeros(16, dtype=torch.int64, device=dev)
+    sout = eng.make_out(obs, rew=rew, reset=torch.ones(16, dtype=torch.int64, device=dev), rock_collision=rock)
+    eng.get_observations(sin, sout)
+    dist, pts, src = eng.get_depths(torch.zeros(16, 3, device=dev) + 1.0, torch.zeros(16, 3, device=dev))
+    eng.calculate_metrics(sin, sout)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rew.cpu().numpy(), a["rew_buf"])
+    assert dist.shape == (16, 9) and pts.shape == (16, 9, 3) and torch.isfinite(dist).all()
+    np.testing.assert_allclose(src[:, :, 2].cpu().numpy(), 1.0 - 0.26878, atol=1e-6)      # identity pose: the distribution's z below the rover
+    eng.close()
+
+
 def test_c_level_argument_checks():
     from isaac_rover_amd import _lib
     eng, _ = _engine(16)

@@ -56,6 +56,22 @@ def test_post_physics_step_matches_reference(name, fused):
     env.close()
 
 
+def test_camera_get_depths_on_the_task():
+    """The drop-in task's `self.Camera.get_depths(positions, rotations)` (camera.py:60, bound by rover.py:286): the reference's triple
+    on the reference's own inputs (tests/golden/get_depths_e64_p37.npz)."""
+    fx = load_golden("get_depths_e64_p37")
+    step_fx = load_golden("step_e64_p37_fp32")
+    task, env = _make_task(step_fx, True)
+    dev = task.device
+    d, pt, src = task.Camera.get_depths(torch.from_numpy(fx["in_pos"]).to(dev), torch.from_numpy(fx["in_euler"]).to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(src.cpu().numpy(), fx["out_fp32_src"], rtol=1e-6, atol=2e-6)
+    close = np.abs(d.cpu().numpy() - fx["out_fp32_dist"]) <= 2e-3
+    assert close.mean() >= 0.999
+    np.testing.assert_allclose(pt.cpu().numpy()[close], fx["out_fp32_pt"][close], rtol=0, atol=2.5e-3)
+    env.close()
+
+
 def test_native_observation_layout():
     """1634 rays -> 1750-float observation = [4 | 634 sparse | 1112 dense] (learning/model.py:186-192)."""
     fx = load_golden("step_e8_native_fp32")
