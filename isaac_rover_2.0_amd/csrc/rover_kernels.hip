@@ -11,16 +11,19 @@
 // evaluation order, so that given identical rays the ray kernel agrees bit for bit with the CPU oracle and
 // differs from the reference's fp32 mode only through sin/cos/atan2/asin ulps.
 //
-// Kernels (one step = the ten launches marked *):
+// Kernels (one fused step = the eight launches marked *; the ray cast of full batches is rover_cull.hip's):
 //   repack_knn_kernel        init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8], near/far halves per lane
 // * prep_rays_kernel         1 thread / (env, ray slot): quat -> euler, heading and the pose's sin/cos per block of 64 envs, then ray
 //                            origin, unit direction, cell id, bin key                                              (A2, A4, A6)
-// * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell) without global atomics
-// * raycast_binned_kernel    1 wave / run of sorted rays, 4 triangles per lane in registers, conservative early out  (A4, A5) <- roofline kernel
+// * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell) without global atomics (4 launches)
+// * cull_scan_kernel         (rover_cull.hip) the culled ray cast: 1 wave / run of sorted rays                      (A4, A5) <- roofline kernel
+//   raycast_binned_kernel    variant 2: 1 wave / run of sorted rays, 4 triangles per lane in registers, every triangle evaluated,
+//                            conservative early out (round 1's roofline kernel; the bit-for-bit reference of the culled one)
 //   raycast_binned_h_kernel  the same in the reference's as-shipped fp16 arithmetic (ray_precision 2)
-//   raycast_kernel           env order, half-wave per ray, streams the cell blocks (small batches, K8 > 256)
-// * assemble_obs_kernel      1 thread / obs element, coalesced row writes                                           (A1)
-// * metrics_done_kernel      1 thread / env: collision mask, stone mask, reward, extras, done, done count           (A7, A8, A10)
+//   raycast_kernel           variant 1: env order, half-wave per ray, streams the cell blocks (small batches, K8 > 256)
+// * obs_metrics_kernel       assemble_obs (1 thread / 4 obs elements, coalesced rows) + metrics_done (1 thread / env: collision mask,
+//                            stone mask, reward, extras, done, done count) in one launch                            (A1, A7, A8, A10)
+//   assemble_obs_kernel / metrics_done_kernel   the same two passes on their own (the reference's method split)
 // * compact_write_kernel     ballot/popc ordered stream compaction of the reset ids                                 (A12)
 //   clearance / shift_spawns / sample_height / goals_draw / goals_env0 / reset_envs kernels                          (A9, f-2)
 //   pre_physics / ackermann / quat_to_euler kernels                                                                  (f-1)
