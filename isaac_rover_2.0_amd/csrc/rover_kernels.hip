@@ -171,165 +171,206 @@ __constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0,
 __constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
 
 // per (env, slot): ray origin, unit direction, cell id, bin key.
-// A workgroup takes 64 envs x 8 ray slots: wave w works on ONE slot (slot0 + w) of 64 consecutive envs, so the three kinds of slot —
-// wheel rays (f32 joint chain), body rays, heightmap rays (f64 transform) — never share a wave.  (One wave per env, lane = slot, ran all
-// three branches in every wave: 373 VALU instructions for work of ~120, 46 us, and neither its stores (-5 us without any) nor the f64
-// arithmetic (f32 instead: no change) were what it waited for.)  The slot's constants are wave-uniform.  The 64 x 8 records leave through LDS: per env the 8 slots are 256 contiguous bytes.
+// A workgroup takes 64 envs and a range of slot groups (8 slots each): in a group wave w works on ONE slot (8 g + w) of the 64 envs, so the
+// three kinds of slot — wheel rays (f32 joint chain), body rays, heightmap rays (f64 transform) — never share a wave and the slot's constants
+// are wave-uniform.  (One wave per env, lane = slot, ran all three branches in every wave: 373 VALU instructions for work of ~120, 46 us.)
+// The 64 x 8 records of a group leave through LDS: per env the 8 slots are 256 contiguous bytes.
+//
+// What depends on the POSE only is built once per block, before the loop over its slot groups (the kernel is bound by its arithmetic —
+// 20 M VALU instructions per launch at 65 536 envs x 64 slots when every block of 8 slots rebuilt it, 37 us; its stores are not what it
+// waits for: 16-byte records made it 1 us faster):
+//  phase 1  the tasks {roll, pitch, yaw (+ heading), one per wheel the block's slots touch} dealt over the 8 waves: an euler angle
+//           (tensor_quat_to_euler.py:17-29) with its sin / cos, or the six sin / cos of a wheel's steer / suspension joints
+//           (rock_detect.py:248-272); the block of slot range 0 writes euler / heading out.  (Until round 4 a kernel of its own,
+//           prep_env_kernel, wrote a 240-byte record per env that this kernel read back: one launch more.)
+//  phase 2  a ray's DIRECTION is its kind's — the four rays of a wheel share one (rock_detect.py:305-319), the two body rays one
+//           (:356-371), all heightmap rays of a rover one (camera.py:179-181,202-212): wave k < 6 builds wheel k's, wave 6 the body
+//           rays', wave 7 the heightmap rays' record — un-normalised direction, the fp16 rounding of the as-shipped modes, -normalize
+//           (ray_casting.py:31), the ray's normal-cone bound for the culled ray cast.
+//  phase 3  per slot group: origin, cell, bin key; the records leave through LDS.
 #define PREP_SLOTS 8
-// The block first builds what it needs of its 64 envs' poses (round 4; until then a kernel of its own, prep_env_kernel, wrote a 240-byte
-// record per env that this kernel read back: one launch more — 5 us at 512 envs, where every launch of the step sits on the launch floor,
-// 4 us at 65 536): waves 0, 1, 2 one euler angle each with its sin / cos (wave 2 also the heading; the block of slot group 0 writes
-// euler / heading out), waves 3 and 4 the six sin / cos of the two wheels the block's slots belong to (slot groups 0..2: steer,
-// suspension — rock_detect.py:248-272); one barrier.
-__global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a) {
+__global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, uint32_t groups_per_block) {
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t e0 = blockIdx.x * 64u, slot0 = blockIdx.y * PREP_SLOTS;
-    const uint32_t e = e0 + lane, slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 + w));
+    const uint32_t e0 = blockIdx.x * 64u, e = e0 + lane;
+    const uint32_t n_groups = a.R8 / PREP_SLOTS, g0 = blockIdx.y * groups_per_block, g1 = min(g0 + groups_per_block, n_groups);
+    const uint32_t s_lo = g0 * PREP_SLOTS, s_hi = g1 * PREP_SLOTS;                        // the block's slots
+    const uint32_t wh_lo = min(6u, s_lo >> 2), wh_hi = min(6u, s_hi >> 2);                // the wheels they touch
     const bool live = e < a.E;
-    RayRec rec;
-    rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
-    uint32_t bin = 0xffffffffu;
     const uint32_t n_real = 26u + a.P;
-    // every load of the slot's branch is issued here, from clamped (always valid) addresses
-    const uint32_t ec = min(e, a.E - 1u);
-    const uint32_t pq = (slot >= 26u) ? min(slot - 26u, a.P - 1u) : 0u;                  // distribution point of slots 26..
+    const uint32_t ec = min(e, a.E - 1u);                                                 // loads come from clamped (always valid) addresses
     const float px = a.pos[3ull * ec], py = a.pos[3ull * ec + 1], pz = a.pos[3ull * ec + 2];
-    float4 c1, c2, cw, cv;
-    {
-        __shared__ float2 s_trig[3][64];            // (sin, cos) of -roll, -pitch, -yaw of the block's 64 envs
-        __shared__ float4 s_wheel[2][2][64];        // [wheel of the slot group][sin / cos of -steer, susX | susY][env]
-        if (w < 3u) {
-            // waves 0, 1, 2: roll, pitch, yaw — each one atan2 / asin and one sin / cos pair (wave 2 also the heading): a third of the
-            // dependent chain each (one wave doing all three angles kept the other seven waiting 1.5 us at the barrier)
+    // the distribution point of a heightmap slot: a SCALAR load (the address is wave-uniform) — as a vector load its s_waitcnt vmcnt
+    // would also wait for the previous slot group's stores to be acknowledged
+    auto dist_of = [&](uint32_t slot, double& x, double& y, double& z) {
+        const double* p = a.dist + 3ull * (slot - 26u);
+        asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dwordx2 %2, %3, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(x), "=&s"(y), "=&s"(z) : "s"(p) : "memory");
+    };
+    __shared__ float2 s_trig[3][64];            // (sin, cos) of -roll, -pitch, -yaw of the block's 64 envs
+    __shared__ float2 s_wheel[6][3][64];        // [wheel][(sin, cos) of -steer | susX | susY][env]
+    __shared__ float4 s_dir[8][64];             // [kind] {dx, dy, dz, flags: map | valid << 1 | cone bound << 16}
+    const uint32_t n_tasks = 3u + (wh_hi - wh_lo);
+    for (uint32_t task = w; task < n_tasks; task += PREP_SLOTS) {
+        if (task < 3u) {
+            // one atan2 / asin and one sin / cos pair (yaw: also the heading): a third of the dependent chain each (one wave doing all
+            // three angles kept the other seven waiting 1.5 us at the barrier)
             const float* qp = a.euler_in ? a.euler_in : a.quat + 4ull * ec;
             const float q[4] = {qp[0], qp[1], qp[2], a.euler_in ? 0.0f : qp[3]};
-            float ang = w == 0u ? quat_roll(q) : (w == 1u ? quat_pitch(q) : quat_yaw(q));
-            if (a.euler_in) ang = a.euler_in[3ull * ec + w];
-            s_trig[w][lane] = make_float2(sinf(-ang), cosf(-ang));
+            float ang = task == 0u ? quat_roll(q) : (task == 1u ? quat_pitch(q) : quat_yaw(q));
+            if (a.euler_in) ang = a.euler_in[3ull * ec + task];
+            s_trig[task][lane] = make_float2(sinf(-ang), cosf(-ang));
             if (blockIdx.y == 0u && live) {
-                if (a.euler) a.euler[3ull * e + w] = ang;
-                if (w == 2u && a.heading) {
+                if (a.euler) a.euler[3ull * e + task] = ang;
+                if (task == 2u && a.heading) {
                     const float* tp = a.target ? a.target : a.pos;
                     const float tx = tp[3ull * ec] - px, ty = tp[3ull * ec + 1] - py;
                     const float hx = cosf(ang), hy = sinf(ang);                           // heading_diff, rover.py:279-283
                     a.heading[e] = -atan2f(tx * hy - ty * hx, tx * hx + ty * hy);
                 }
             }
-        } else if (w <= 4u && slot0 < 24u) {
-            const uint32_t wh = (slot0 >> 2) + (w - 3u);                                  // wheels 2 g, 2 g + 1 of slot group g
+        } else {
+            const uint32_t wh = wh_lo + (task - 3u);
             const float* j = a.joints ? a.joints + 13ull * ec : nullptr;
             const float j0 = j ? j[0] : 0.0f, j1 = j ? j[1] : 0.0f, j2 = j ? j[2] : 0.0f, j4 = j ? j[4] : 0.0f, j6 = j ? j[6] : 0.0f,
                         j7 = j ? j[7] : 0.0f, j8 = j ? j[8] : 0.0f;
             const float steer = (wh == 0) ? j4 : (wh == 1) ? j6 : (wh == 4) ? -j7 : (wh == 5) ? j8 : 0.0f;         // :248
             const float susY = (wh == 0 || wh == 2) ? -j0 : (wh == 1 || wh == 3) ? j1 : 0.0f;                      // :263
             const float susX = (wh >= 4) ? -j2 : 0.0f;                                                           // :264
-            s_wheel[w - 3u][0][lane] = make_float4(sinf(-steer), cosf(-steer), sinf(susX), cosf(susX));
-            s_wheel[w - 3u][1][lane] = make_float4(sinf(susY), cosf(susY), 0.0f, 0.0f);
+            s_wheel[wh][0][lane] = make_float2(sinf(-steer), cosf(-steer));
+            s_wheel[wh][1][lane] = make_float2(sinf(susX), cosf(susX));
+            s_wheel[wh][2][lane] = make_float2(sinf(susY), cosf(susY));
         }
-        __syncthreads();
-        const float2 tr = s_trig[0][lane], tp2 = s_trig[1][lane], ty2 = s_trig[2][lane];
-        c1 = make_float4(tr.x, tr.y, tp2.x, tp2.y); c2 = make_float4(ty2.x, ty2.y, 0.0f, 0.0f);
-        const uint32_t wsel = (slot >> 2) & 1u;                                           // which of the group's two wheels the slot is on
-        cw = s_wheel[wsel][0][lane]; cv = s_wheel[wsel][1][lane];                          // (read by slots >= 24 too: unused there)
     }
-    const float2 t01 = make_float2(c1.x, c1.y), t23 = make_float2(c1.z, c1.w), t45 = make_float2(c2.x, c2.y);
-    const float2 q01 = make_float2(cw.x, cw.y), q23 = make_float2(cw.z, cw.w), q45 = make_float2(cv.x, cv.y);
-    const double dpx = a.dist[3ull * pq], dpy = a.dist[3ull * pq + 1], dpz = a.dist[3ull * pq + 2];
-    if (live && slot < n_real) {
-        Trig6 t;
-        t.sx = t01.x; t.cx = t01.y; t.sy = t23.x; t.cy = t23.y; t.sz = t45.x; t.cz = t45.y;
-        float sx, sy, sz, ux, uy, uz;      // origin, un-normalised direction
-        const KnnDev* m;
-        if (slot < 24u) {                   // rock_detect.py:160-319
-            uint32_t w = slot >> 2, r = slot & 3u;
-            const float sst = q01.x, cst = q01.y, ssx = q23.x, csx = q23.y, ssy = q45.x, csy = q45.y;
+    __syncthreads();
+    Trig6 t;
+    {
+        const float2 tr = s_trig[0][lane], tp2 = s_trig[1][lane], ty2 = s_trig[2][lane];
+        t.sx = tr.x; t.cx = tr.y; t.sy = tp2.x; t.cy = tp2.y; t.sz = ty2.x; t.cz = ty2.y;
+    }
+    // the pose in float64 for the heightmap rays (camera.py:165-212 works in the distribution tensor's float64; widened where it is
+    // used: eighteen registers held through the loop would cost the kernel its eighth wave per SIMD)
+#define PREP_POSE_F64                                                                                                                    \
+    const double dsx = (double)t.sx, dcx = (double)t.cx, dsy = (double)t.sy, dcy = (double)t.cy, dsz = (double)t.sz, dcz = (double)t.cz; \
+    const double X = (double)px, Y = (double)py, Z = (double)pz
+    if (w < 6u ? (w >= wh_lo && w < wh_hi) : (w == 6u ? (s_lo < 26u && s_hi > 24u) : s_hi > 26u)) {
+        float ux, uy, uz;
+        uint32_t fl;
+        if (w < 6u) {                           // wheel w: rock_detect.py:305-319
+            const float2 d0 = s_wheel[w][0][lane], d1 = s_wheel[w][1][lane], d2 = s_wheel[w][2][lane];
             const float zero3[3] = {0.0f, 0.0f, 0.0f};
-            wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[w], c_wp1[w], sst, cst, ssx, csx,
-                        ssy, csy, t, px, py, pz, sx, sy, sz);
-            wheel_chain(c_wheel_ray[4][0], c_wheel_ray[4][1], c_wheel_ray[4][2], zero3, zero3, sst, cst, ssx, csx,
-                        ssy, csy, t, 0.0f, 0.0f, 0.0f, ux, uy, uz);
-            m = &a.rocks;
-            rec.flags = 3u;
-        } else if (slot < 26u) {            // rock_detect.py:321-371
-            uint32_t r = slot - 24u;
-            body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, px, py, pz, sx, sy, sz);
+            wheel_chain(c_wheel_ray[4][0], c_wheel_ray[4][1], c_wheel_ray[4][2], zero3, zero3, d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, t, 0.0f, 0.0f,
+                        0.0f, ux, uy, uz);
+            fl = 3u;
+        } else if (w == 6u) {                   // the body rays: rock_detect.py:356-371
             float qx, qy, qz;
             body_xf(0.0f, 1.0f, 0.0f, t, px, py, pz, qx, qy, qz);
             ux = qx - px; uy = qy - py; uz = qz - pz;
-            m = &a.rocks;
-            rec.flags = 3u;
-        } else {                            // camera.py:165-212, float64 like the distribution tensor
-            double x = dpx, y = dpy, z = dpz;
-            double dsx = (double)t.sx, dcx = (double)t.cx, dsy = (double)t.sy, dcy = (double)t.cy,
-                   dsz = (double)t.sz, dcz = (double)t.cz;
-            double X = (double)px, Y = (double)py, Z = (double)pz;
-            {
-                double A = y * dcx + z * dsx, C = z * dcx - y * dsx, B = x * dcy - dsy * C;
-                sx = (float)(X + dsz * A + dcz * B);
-                sy = (float)(Y + dcz * A - dsz * B);
-                sz = (float)(Z + x * dsy + dcy * C);
-            }
-            {   // the appended (0,0,-1) point, camera.py:179-181,202-204
-                double xn = 0.0, yn = 0.0, zn = -1.0;
-                double A = yn * dcx + zn * dsx, C = zn * dcx - yn * dsx, B = xn * dcy - dsy * C;
-                ux = (float)((X + dsz * A + dcz * B) - X);
-                uy = (float)((Y + dcz * A - dsz * B) - Y);
-                uz = (float)((Z + xn * dsy + dcy * C) - Z);
-            }
-            m = &a.terrain;
-            rec.flags = 2u;
+            fl = 3u;
+        } else {                                // the heightmap rays: the appended (0,0,-1) point, camera.py:179-181,202-204, float64
+            PREP_POSE_F64;
+            const double xn = 0.0, yn = 0.0, zn = -1.0;
+            const double A = yn * dcx + zn * dsx, C = zn * dcx - yn * dsx, B = xn * dcy - dsy * C;
+            ux = (float)((X + dsz * A + dcz * B) - X);
+            uy = (float)((Y + dcz * A - dsz * B) - Y);
+            uz = (float)((Z + xn * dsy + dcy * C) - Z);
+            fl = 2u;
         }
-        if (a.precision >= 1) {         // sources.type(float16), rover_dir.type(float16): camera.py:212, rock_detect.py:319,371
-            sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz;
-            ux = (float)(_Float16)ux; uy = (float)(_Float16)uy; uz = (float)(_Float16)uz;
-        }
-        rec.sx = sx; rec.sy = sy; rec.sz = sz;
+        if (a.precision >= 1) { ux = (float)(_Float16)ux; uy = (float)(_Float16)uy; uz = (float)(_Float16)uz; }      // rover_dir.type(float16): camera.py:212, rock_detect.py:319,371
+        float dx, dy, dz;
         if (a.precision == 2) {         // F.normalize on a float16 tensor: f32-accumulated norm rounded to fp16, fp16 division
             float nrm = (float)(_Float16)sqrtf(ux * ux + uy * uy + uz * uz);     // (eps 1e-12 is 0 in fp16)
-            rec.dx = -(float)(_Float16)(ux / nrm); rec.dy = -(float)(_Float16)(uy / nrm); rec.dz = -(float)(_Float16)(uz / nrm);
+            dx = -(float)(_Float16)(ux / nrm); dy = -(float)(_Float16)(uy / nrm); dz = -(float)(_Float16)(uz / nrm);
         } else {
-            neg_normalize(ux, uy, uz, rec.dx, rec.dy, rec.dz);
+            neg_normalize(ux, uy, uz, dx, dy, dz);
         }
-        {   // the ray's normal-cone bound for the culled ray cast (rover_cull.hip), a 16-bit fraction rounded up, 0xffff = none.
-            // f32 proof: a cell whose triangles all have |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole.
-            // As-shipped fp16 arithmetic: (B)'s threshold is per triangle, the cell stores the largest angle from the vertical a ray
-            // may have (as a fraction of pi / 2) and the ray its angle beta (d is normalised in fp16 there: re-normalised here).
-            uint32_t qq = 0xffffu;
-            if (a.precision == 2) {
-                const float inv = 1.0f / sqrtf(rec.dx * rec.dx + rec.dy * rec.dy + rec.dz * rec.dz);
-                const float beta = acosf(fminf(1.0f, fabsf(rec.dz) * inv)) * 0.63661977f + 4.0e-5f;      // / (pi / 2), rounded up
-                if (beta < 0.9999f) qq = (uint32_t)ceilf(beta * 65535.0f);                                // NaN -> 0xffff
-            } else {
-                const float qm = 3.5e-3f * fabsf(rec.dz) + sqrtf(rec.dx * rec.dx + rec.dy * rec.dy) + 2.0e-5f;
-                if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                    // NaN -> 0xffff
-            }
-            rec.flags |= qq << 16;
+        // the ray's normal-cone bound for the culled ray cast (rover_cull.hip), a 16-bit fraction rounded up, 0xffff = none.
+        // f32 proof: a cell whose triangles all have |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole.
+        // As-shipped fp16 arithmetic: (B)'s threshold is per triangle, the cell stores the largest angle from the vertical a ray
+        // may have (as a fraction of pi / 2) and the ray its angle beta (d is normalised in fp16 there: re-normalised here).
+        uint32_t qq = 0xffffu;
+        if (a.precision == 2) {
+            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            const float beta = acosf(fminf(1.0f, fabsf(dz) * inv)) * 0.63661977f + 4.0e-5f;      // / (pi / 2), rounded up
+            if (beta < 0.9999f) qq = (uint32_t)ceilf(beta * 65535.0f);                            // NaN -> 0xffff
+        } else {
+            const float qm = 3.5e-3f * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
+            if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                // NaN -> 0xffff
         }
-        uint32_t ix = cell_coord(sx, m->shift_x, m->cell, m->inv_cell, a.cell_rcp, m->X);
-        uint32_t iy = cell_coord(sy, m->shift_y, m->cell, m->inv_cell, a.cell_rcp, m->X);
-        if (iy > (uint32_t)(m->Y - 1)) iy = (uint32_t)(m->Y - 1);      // memory safety only
-        rec.cell = ix * (uint32_t)m->Y + iy;
-        bin = ((rec.flags & 1u) ? a.rocks_bin_offset : 0u) + rec.cell;
-
+        s_dir[w][lane] = make_float4(dx, dy, dz, __uint_as_float(fl | (qq << 16)));
     }
-    // The block's 64 x 8 records and bin keys, env-major through LDS (rows of 17 float4 / 9 dwords: a wave's 64 rows spread over the banks):
+    // The group's 64 x 8 records and bin keys, env-major through LDS (rows of 17 float4 / 9 dwords: a wave's 64 rows spread over the banks):
     // a store instruction then writes four envs' 256-byte groups — whole lines — instead of 64 records 2 KB apart.
     __shared__ float4 s_t[64 * (2 * PREP_SLOTS + 1)];
     __shared__ uint32_t s_b[64 * (PREP_SLOTS + 1)];
-    s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
-    s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
-    s_b[lane * (PREP_SLOTS + 1) + w] = bin;                  // key of the bucket sort; 0xffffffff for padding slots
-    __syncthreads();
     float4* const rays4 = reinterpret_cast<float4*>(a.rays);
+    const Trig6& t_ = t;
+    const float px_ = px, py_ = py, pz_ = pz;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint32_t slot0 = g * PREP_SLOTS, slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 + w));
+        RayRec rec;
+        rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
+        uint32_t bin = 0xffffffffu;
+        const bool real = live && slot < n_real;
+        uint32_t kind = 0u;
+        if (real) {
+            float sx, sy, sz;                  // origin
+            const bool rk = slot < 26u;         // the ray's map: rocks, or the terrain
+            const float m_shift_x = rk ? a.rocks.shift_x : a.terrain.shift_x, m_shift_y = rk ? a.rocks.shift_y : a.terrain.shift_y;
+            const float m_cell = rk ? a.rocks.cell : a.terrain.cell, m_inv_cell = rk ? a.rocks.inv_cell : a.terrain.inv_cell;
+            const int32_t m_X = rk ? a.rocks.X : a.terrain.X, m_Y = rk ? a.rocks.Y : a.terrain.Y;
+            if (slot < 24u) {                   // rock_detect.py:160-319
+                const uint32_t wh = slot >> 2, r = slot & 3u;
+                const float2 d0 = s_wheel[wh][0][lane], d1 = s_wheel[wh][1][lane], d2 = s_wheel[wh][2][lane];
+                wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[wh], c_wp1[wh], d0.x, d0.y, d1.x, d1.y,
+                            d2.x, d2.y, t, px, py, pz, sx, sy, sz);
+                kind = wh;
+            } else if (slot < 26u) {            // rock_detect.py:321-371
+                const uint32_t r = slot - 24u;
+                body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, px, py, pz, sx, sy, sz);
+                kind = 6u;
+            } else {                            // camera.py:165-212, float64 like the distribution tensor
+                Trig6 t = t_;                   // (opaque copies: hoisted out of the loop the widened pose is those eighteen registers)
+                float px = px_, py = py_, pz = pz_;
+                asm volatile("" : "+v"(t.sx), "+v"(t.cx), "+v"(t.sy), "+v"(t.cy), "+v"(t.sz), "+v"(t.cz), "+v"(px), "+v"(py), "+v"(pz));
+                PREP_POSE_F64;
+                double x, y, z;
+                dist_of(slot, x, y, z);
+                const double A = y * dcx + z * dsx, C = z * dcx - y * dsx, B = x * dcy - dsy * C;
+                sx = (float)(X + dsz * A + dcz * B);
+                sy = (float)(Y + dcz * A - dsz * B);
+                sz = (float)(Z + x * dsy + dcy * C);
+                kind = 7u;
+            }
+            if (a.precision >= 1) { sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz; }      // sources.type(float16): camera.py:212
+            rec.sx = sx; rec.sy = sy; rec.sz = sz;
+            uint32_t ix = cell_coord(sx, m_shift_x, m_cell, m_inv_cell, a.cell_rcp, m_X);
+            uint32_t iy = cell_coord(sy, m_shift_y, m_cell, m_inv_cell, a.cell_rcp, m_X);
+            if (iy > (uint32_t)(m_Y - 1)) iy = (uint32_t)(m_Y - 1);        // memory safety only
+            rec.cell = ix * (uint32_t)m_Y + iy;
+            bin = (rk ? a.rocks_bin_offset : 0u) + rec.cell;
+        }
+        // the direction records are written (first group: the waves that did not build one have worked on their origins meanwhile);
+        // the previous group's records have left s_t / s_b
+        __syncthreads();
+        if (real) {
+            const float4 dr = s_dir[kind][lane];
+            rec.dx = dr.x; rec.dy = dr.y; rec.dz = dr.z; rec.flags = __float_as_uint(dr.w);
+        }
+        s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
+        s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
+        s_b[lane * (PREP_SLOTS + 1) + w] = bin;                  // key of the bucket sort; 0xffffffff for padding slots
+        __syncthreads();
 #pragma unroll
-    for (uint32_t r = 0; r < 2u; ++r) {
-        const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
-        if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
+        for (uint32_t r = 0; r < 2u; ++r) {
+            const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
+            if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
+        }
+        {       // (four groups' keys gathered in LDS and written as whole 128-byte lines: 45 KB of LDS, three blocks per CU, +2.6 us)
+            const uint32_t el = threadIdx.x / PREP_SLOTS, q = threadIdx.x % PREP_SLOTS;
+            if (a.bin_out && e0 + el < a.E) a.bin_out[(size_t)(e0 + el) * a.R8 + slot0 + q] = s_b[el * (PREP_SLOTS + 1) + q];
+        }
     }
-    {
-        const uint32_t el = threadIdx.x / PREP_SLOTS, q = threadIdx.x % PREP_SLOTS;
-        if (a.bin_out && e0 + el < a.E) a.bin_out[(size_t)(e0 + el) * a.R8 + slot0 + q] = s_b[el * (PREP_SLOTS + 1) + q];
-    }
+#undef PREP_POSE_F64
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1561,7 +1602,12 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 }
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(prep_rays_kernel, dim3(blocks_for(a.E, 64), a.R8 / PREP_SLOTS), dim3(64 * PREP_SLOTS), 0, s, a);       // (R8 is a multiple of 8)
+    // 64 envs x a range of slot groups per block: as many groups as still leave ~1 024 blocks (the pose work is per block; 65 536 envs x
+    // 64 slots: 31.1 us with 1 024 or 2 048 blocks, 36.9 when every block of 8 slots rebuilt the pose; 4 096 envs: one group per block)
+    const uint32_t target = 1024u;
+    const uint32_t xb = blocks_for(a.E, 64), n_groups = a.R8 / PREP_SLOTS;                // (R8 is a multiple of 8)
+    const uint32_t yb = max(1u, min(n_groups, (target + xb - 1u) / xb)), gpb = (n_groups + yb - 1u) / yb;
+    hipLaunchKernelGGL(prep_rays_kernel, dim3(xb, (n_groups + gpb - 1u) / gpb), dim3(64 * PREP_SLOTS), 0, s, a, gpb);
     return hipGetLastError();
 }
 
