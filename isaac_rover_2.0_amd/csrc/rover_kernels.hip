@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include "rover_internal.h"
 #include "rover_raymath.h"
+#include "rover_rayrec.h"
 
 namespace rover {
 
@@ -63,40 +64,12 @@ __device__ __forceinline__ void quat_to_euler(const float* __restrict__ q, float
     roll = quat_roll(q); pitch = quat_pitch(q); yaw = quat_yaw(q);
 }
 
-struct Trig6 { float sx, cx, sy, cy, sz, cz; };
-
 __device__ __forceinline__ Trig6 euler_trig(float roll, float pitch, float yaw) {
     Trig6 t;
     t.sx = sinf(-roll);  t.cx = cosf(-roll);
     t.sy = sinf(-pitch); t.cy = cosf(-pitch);
     t.sz = sinf(-yaw);   t.cz = cosf(-yaw);
     return t;
-}
-
-// rock_detect.py:305-307 / :356-358 — f32 body transform
-__device__ __forceinline__ void body_xf(float x, float y, float z, const Trig6& t, float px, float py, float pz,
-                                        float& ox, float& oy, float& oz) {
-    float A = y * t.cx + z * t.sx;
-    float C = z * t.cx - y * t.sx;
-    float B = x * t.cy - t.sy * C;
-    ox = px + t.sz * A + t.cz * B;
-    oy = py + t.cz * A - t.sz * B;
-    oz = pz + x * t.sy + t.cy * C;
-}
-
-// rock_detect.py:256-258,275-277 then body_xf: wheel-local point -> world (translations zeroed for directions)
-__device__ __forceinline__ void wheel_chain(float x, float y, float z, const float* t0, const float* t1,
-                                            float sst, float cst, float ssx, float csx, float ssy, float csy,
-                                            const Trig6& t, float px, float py, float pz,
-                                            float& ox, float& oy, float& oz) {
-    float x1 = t0[0] + x * cst + y * sst;
-    float y1 = t0[1] + y * cst - x * sst;
-    float z1 = t0[2] + z;
-    float c1 = z1 * csx - y1 * ssx;
-    float x2 = t1[0] + x1 * csy - ssy * c1;
-    float y2 = t1[1] + y1 * csx + z1 * ssx;
-    float z2 = t1[2] + x1 * ssy + csy * c1;
-    body_xf(x2, y2, z2, t, px, py, pz, ox, oy, oz);
 }
 
 // camera.py:241-253: clamp bound is the dim-0 size for both axes; torch.round is half-to-even.
@@ -162,14 +135,6 @@ __global__ void __launch_bounds__(256) repack_knn_kernel(const int32_t* __restri
 // prep: one thread per (env, slot).  slots 0..23 wheel rays, 24..25 body rays, 26..26+P-1 terrain rays,
 // rest padding to a multiple of 8 (a ray-cast workgroup then never straddles two envs).
 // ---------------------------------------------------------------------------------------------------
-__constant__ float c_wheel_ray[5][3] = {{0.215 / 2, 0.130 / 2, 0.1}, {0.215 / 2, -0.130 / 2, 0.1},
-                                        {-0.215 / 2, 0.130 / 2, 0.1}, {-0.215 / 2, -0.130 / 2, 0.1}, {0, 0, -1}};
-__constant__ float c_wp0[6][3] = {{0.286, 0.385, -0.197}, {0.286, -0.385, -0.197}, {-0.146, 0.447, -0.197},
-                                  {-0.146, -0.447, -0.197}, {-0.440, 0.385, -0.197}, {-0.440, -0.385, -0.197}};
-__constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, -0.0, 0.03},
-                                  {0, 0, 0.03}, {0, 0, 0.03}};
-__constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
-
 // per (env, slot): ray origin, unit direction, cell id, bin key.
 // A workgroup takes 64 envs and a range of slot groups (8 slots each): in a group wave w works on ONE slot (8 g + w) of the 64 envs, so the
 // three kinds of slot — wheel rays (f32 joint chain), body rays, heightmap rays (f64 transform) — never share a wave and the slot's constants
@@ -209,6 +174,10 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
     __shared__ float2 s_trig[3][64];            // (sin, cos) of -roll, -pitch, -yaw of the block's 64 envs
     __shared__ float2 s_wheel[6][3][64];        // [wheel][(sin, cos) of -steer | susX | susY][env]
     __shared__ float4 s_dir[8][64];             // [kind] {dx, dy, dz, flags: map | valid << 1 | cone bound << 16}
+    // optionally the first pass of the bucket sort (launch_bin_rays): the block's keys counted per coarse bucket in LDS, then added to the
+    // row of the sort tile the block's 64 envs lie in (a few blocks per row; the table is all zero when the kernel starts)
+    extern __shared__ uint32_t s_hist[];        // [a.hist_buckets] when a.hist
+    if (a.hist) for (uint32_t i = threadIdx.x; i < a.hist_buckets; i += 64u * PREP_SLOTS) s_hist[i] = 0u;
     const uint32_t n_tasks = 3u + (wh_hi - wh_lo);
     for (uint32_t task = w; task < n_tasks; task += PREP_SLOTS) {
         if (task < 3u) {
@@ -239,6 +208,11 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             s_wheel[wh][0][lane] = make_float2(sinf(-steer), cosf(-steer));
             s_wheel[wh][1][lane] = make_float2(sinf(susX), cosf(susX));
             s_wheel[wh][2][lane] = make_float2(sinf(susY), cosf(susY));
+            if (a.wheel_tab && live) {          // (a wheel belongs to one slot group: one block writes it)
+                const float2 u0 = s_wheel[wh][0][lane], u1 = s_wheel[wh][1][lane], u2 = s_wheel[wh][2][lane];
+                a.wheel_tab[(6ull * e + wh) * 2u] = make_float4(u0.x, u0.y, u1.x, u1.y);
+                a.wheel_tab[(6ull * e + wh) * 2u + 1u] = make_float4(u2.x, u2.y, 0.0f, 0.0f);
+            }
         }
     }
     __syncthreads();
@@ -246,12 +220,12 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
     {
         const float2 tr = s_trig[0][lane], tp2 = s_trig[1][lane], ty2 = s_trig[2][lane];
         t.sx = tr.x; t.cx = tr.y; t.sy = tp2.x; t.cy = tp2.y; t.sz = ty2.x; t.cz = ty2.y;
+        if (a.pose_tab && blockIdx.y == 0u && w == 0u && live) {
+            a.pose_tab[3ull * e] = make_float4(tr.x, tr.y, tp2.x, tp2.y);
+            a.pose_tab[3ull * e + 1u] = make_float4(ty2.x, ty2.y, px, py);
+            a.pose_tab[3ull * e + 2u] = make_float4(pz, 0.0f, 0.0f, 0.0f);
+        }
     }
-    // the pose in float64 for the heightmap rays (camera.py:165-212 works in the distribution tensor's float64; widened where it is
-    // used: eighteen registers held through the loop would cost the kernel its eighth wave per SIMD)
-#define PREP_POSE_F64                                                                                                                    \
-    const double dsx = (double)t.sx, dcx = (double)t.cx, dsy = (double)t.sy, dcy = (double)t.cy, dsz = (double)t.sz, dcz = (double)t.cz; \
-    const double X = (double)px, Y = (double)py, Z = (double)pz
     if (w < 6u ? (w >= wh_lo && w < wh_hi) : (w == 6u ? (s_lo < 26u && s_hi > 24u) : s_hi > 26u)) {
         float ux, uy, uz;
         uint32_t fl;
@@ -267,7 +241,7 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             ux = qx - px; uy = qy - py; uz = qz - pz;
             fl = 3u;
         } else {                                // the heightmap rays: the appended (0,0,-1) point, camera.py:179-181,202-204, float64
-            PREP_POSE_F64;
+            ROVER_POSE_F64(t, px, py, pz);
             const double xn = 0.0, yn = 0.0, zn = -1.0;
             const double A = yn * dcx + zn * dsx, C = zn * dcx - yn * dsx, B = xn * dcy - dsy * C;
             ux = (float)((X + dsz * A + dcz * B) - X);
@@ -296,15 +270,18 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             const float qm = 3.5e-3f * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
             if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                // NaN -> 0xffff
         }
-        s_dir[w][lane] = make_float4(dx, dy, dz, __uint_as_float(fl | (qq << 16)));
+        const float4 dr = make_float4(dx, dy, dz, __uint_as_float(fl | (qq << 16)));
+        s_dir[w][lane] = dr;
+        // (the body rays' and the heightmap rays' record: written by the block that holds their first slot)
+        if (a.dir_tab && live && (w < 6u || (w == 6u ? (s_lo <= 24u && s_hi > 24u) : (s_lo <= 26u && s_hi > 26u)))) a.dir_tab[8ull * e + w] = dr;
     }
     // The group's 64 x 8 records and bin keys, env-major through LDS (rows of 17 float4 / 9 dwords: a wave's 64 rows spread over the banks):
     // a store instruction then writes four envs' 256-byte groups — whole lines — instead of 64 records 2 KB apart.
     __shared__ float4 s_t[64 * (2 * PREP_SLOTS + 1)];
     __shared__ uint32_t s_b[64 * (PREP_SLOTS + 1)];
     float4* const rays4 = reinterpret_cast<float4*>(a.rays);
-    const Trig6& t_ = t;
-    const float px_ = px, py_ = py, pz_ = pz;
+    // (blocks starting at different groups of their range, so that those running together do not all write the same 256-byte residue
+    //  class of the 2-KB rows: no change, 36.7 / 36.8 us on a box where the kernel is bound by its stores at 4.7 TB/s)
     for (uint32_t g = g0; g < g1; ++g) {
         const uint32_t slot0 = g * PREP_SLOTS, slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 + w));
         RayRec rec;
@@ -318,29 +295,17 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             const float m_shift_x = rk ? a.rocks.shift_x : a.terrain.shift_x, m_shift_y = rk ? a.rocks.shift_y : a.terrain.shift_y;
             const float m_cell = rk ? a.rocks.cell : a.terrain.cell, m_inv_cell = rk ? a.rocks.inv_cell : a.terrain.inv_cell;
             const int32_t m_X = rk ? a.rocks.X : a.terrain.X, m_Y = rk ? a.rocks.Y : a.terrain.Y;
-            if (slot < 24u) {                   // rock_detect.py:160-319
-                const uint32_t wh = slot >> 2, r = slot & 3u;
-                const float2 d0 = s_wheel[wh][0][lane], d1 = s_wheel[wh][1][lane], d2 = s_wheel[wh][2][lane];
-                wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[wh], c_wp1[wh], d0.x, d0.y, d1.x, d1.y,
-                            d2.x, d2.y, t, px, py, pz, sx, sy, sz);
-                kind = wh;
-            } else if (slot < 26u) {            // rock_detect.py:321-371
-                const uint32_t r = slot - 24u;
-                body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, px, py, pz, sx, sy, sz);
-                kind = 6u;
-            } else {                            // camera.py:165-212, float64 like the distribution tensor
-                Trig6 t = t_;                   // (opaque copies: hoisted out of the loop the widened pose is those eighteen registers)
-                float px = px_, py = py_, pz = pz_;
-                asm volatile("" : "+v"(t.sx), "+v"(t.cx), "+v"(t.sy), "+v"(t.cy), "+v"(t.sz), "+v"(t.cz), "+v"(px), "+v"(py), "+v"(pz));
-                PREP_POSE_F64;
-                double x, y, z;
-                dist_of(slot, x, y, z);
-                const double A = y * dcx + z * dsx, C = z * dcx - y * dsx, B = x * dcy - dsy * C;
-                sx = (float)(X + dsz * A + dcz * B);
-                sy = (float)(Y + dcz * A - dsz * B);
-                sz = (float)(Z + x * dsy + dcy * C);
-                kind = 7u;
+            float2 d0 = make_float2(0.0f, 0.0f), d1 = d0, d2 = d0;
+            double x = 0.0, y = 0.0, z = 0.0;
+            if (slot < 24u) { const uint32_t wh = slot >> 2; d0 = s_wheel[wh][0][lane]; d1 = s_wheel[wh][1][lane]; d2 = s_wheel[wh][2][lane]; }
+            else if (slot >= 26u) dist_of(slot, x, y, z);
+            {
+                Trig6 tq = t;                   // (opaque copies: hoisted out of the loop the pose widened to f64 is eighteen registers,
+                float qx = px, qy = py, qz = pz;  //  the kernel's eighth wave per SIMD)
+                asm volatile("" : "+v"(tq.sx), "+v"(tq.cx), "+v"(tq.sy), "+v"(tq.cy), "+v"(tq.sz), "+v"(tq.cz), "+v"(qx), "+v"(qy), "+v"(qz));
+                ray_origin(slot, tq, qx, qy, qz, d0, d1, d2, x, y, z, sx, sy, sz);
             }
+            kind = ray_kind(slot);
             if (a.precision >= 1) { sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz; }      // sources.type(float16): camera.py:212
             rec.sx = sx; rec.sy = sy; rec.sz = sz;
             uint32_t ix = cell_coord(sx, m_shift_x, m_cell, m_inv_cell, a.cell_rcp, m_X);
@@ -348,29 +313,41 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             if (iy > (uint32_t)(m_Y - 1)) iy = (uint32_t)(m_Y - 1);        // memory safety only
             rec.cell = ix * (uint32_t)m_Y + iy;
             bin = (rk ? a.rocks_bin_offset : 0u) + rec.cell;
+            if (a.hist) atomicAdd(&s_hist[bin >> a.hist_low_bits], 1u);
         }
         // the direction records are written (first group: the waves that did not build one have worked on their origins meanwhile);
         // the previous group's records have left s_t / s_b
         __syncthreads();
-        if (real) {
-            const float4 dr = s_dir[kind][lane];
-            rec.dx = dr.x; rec.dy = dr.y; rec.dz = dr.z; rec.flags = __float_as_uint(dr.w);
+        if (rays4) {                            // (not for the culled ray cast: its waves rebuild the records of their runs from the tables)
+            if (real) {
+                const float4 dr = s_dir[kind][lane];
+                rec.dx = dr.x; rec.dy = dr.y; rec.dz = dr.z; rec.flags = __float_as_uint(dr.w);
+            }
+            s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
+            s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
         }
-        s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
-        s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
         s_b[lane * (PREP_SLOTS + 1) + w] = bin;                  // key of the bucket sort; 0xffffffff for padding slots
         __syncthreads();
+        if (rays4) {
 #pragma unroll
-        for (uint32_t r = 0; r < 2u; ++r) {
-            const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
-            if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
+            for (uint32_t r = 0; r < 2u; ++r) {
+                const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
+                if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
+            }
         }
         {       // (four groups' keys gathered in LDS and written as whole 128-byte lines: 45 KB of LDS, three blocks per CU, +2.6 us)
             const uint32_t el = threadIdx.x / PREP_SLOTS, q = threadIdx.x % PREP_SLOTS;
             if (a.bin_out && e0 + el < a.E) a.bin_out[(size_t)(e0 + el) * a.R8 + slot0 + q] = s_b[el * (PREP_SLOTS + 1) + q];
         }
     }
-#undef PREP_POSE_F64
+    if (a.hist) {
+        __syncthreads();
+        uint32_t* const row = a.hist + (size_t)(blockIdx.x / a.hist_blocks_per_tile) * a.hist_buckets;
+        for (uint32_t i = threadIdx.x; i < a.hist_buckets; i += 64u * PREP_SLOTS) {
+            const uint32_t v = s_hist[i];
+            if (v) atomicAdd(row + i, v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1254,12 +1231,17 @@ __global__ void __launch_bounds__(NT) bucket_scatter_kernel(const uint32_t* __re
 
 template <bool PACKED, int NT, int IPT>      // IPT: items a thread may hold (buckets of up to NT x IPT entries take the one-pass path)
 __global__ void __launch_bounds__(NT) bucket_sort_kernel(const uint2* __restrict__ pairs2, const uint32_t* __restrict__ bucket_base,
-                                                          uint32_t low_bits, uint32_t* __restrict__ sorted) {
+                                                          uint32_t low_bits, uint32_t* __restrict__ sorted, uint32_t* __restrict__ zero,
+                                                          uint32_t n_zero) {
     typedef BktEntry<PACKED> En;
     const typename En::T* __restrict__ pairs = reinterpret_cast<const typename En::T*>(pairs2);
     extern __shared__ uint32_t bkt_lds[];        // sized by the launch: 2^low_bits + BKT_STAGE dwords
     __shared__ uint32_t wl[NT / 64];
     const uint32_t b = blockIdx.x, tid = threadIdx.x, nl = 1u << low_bits;
+    if (zero) {      // the count table is spent (the scatter has run): cleared for the next step's prep_rays_kernel, a share per block
+        const uint32_t per = (n_zero + gridDim.x - 1u) / gridDim.x, z1 = min(n_zero, (b + 1u) * per);
+        for (uint32_t i = b * per + tid; i < z1; i += NT) zero[i] = 0u;
+    }
     uint32_t* const h = bkt_lds;
     uint32_t* const stage = bkt_lds + nl;
     const uint32_t s0 = bucket_base[b], s1 = bucket_base[b + 1u];
@@ -1604,10 +1586,10 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
     // 64 envs x a range of slot groups per block: as many groups as still leave ~1 024 blocks (the pose work is per block; 65 536 envs x
     // 64 slots: 31.1 us with 1 024 or 2 048 blocks, 36.9 when every block of 8 slots rebuilt the pose; 4 096 envs: one group per block)
-    const uint32_t target = 1024u;
+    const uint32_t target = (a.hist && a.hist_buckets > 576u) ? 2048u : 1024u;        // (more than 576 buckets: three blocks per CU, not four)
     const uint32_t xb = blocks_for(a.E, 64), n_groups = a.R8 / PREP_SLOTS;                // (R8 is a multiple of 8)
     const uint32_t yb = max(1u, min(n_groups, (target + xb - 1u) / xb)), gpb = (n_groups + yb - 1u) / yb;
-    hipLaunchKernelGGL(prep_rays_kernel, dim3(xb, (n_groups + gpb - 1u) / gpb), dim3(64 * PREP_SLOTS), 0, s, a, gpb);
+    hipLaunchKernelGGL(prep_rays_kernel, dim3(xb, (n_groups + gpb - 1u) / gpb), dim3(64 * PREP_SLOTS), a.hist ? a.hist_buckets * 4u : 0u, s, a, gpb);
     return hipGetLastError();
 }
 
@@ -1620,32 +1602,49 @@ hipError_t launch_raycast(const RayRec* rays, uint32_t n_rays, const uint16_t* t
 
 hipError_t launch_scan_exclusive(uint32_t* data, uint32_t n, uint32_t* block_sums, hipStream_t s);
 
-// sort the valid ray slots by bin; work = [counts/offsets table | pairs]; returns hipErrorInvalidValue when the bin space is too large
-hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_valid, uint32_t n_bins, uint32_t low_bits,
-                           uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, hipStream_t s) {
-    const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
-    if (low_bits < 8u || low_bits > 12u || n_buckets > BKT_MAX) return hipErrorInvalidValue;
-    // tile of the first two passes: 4 096 slots per 256-thread block; from 2 M slots 16 384 per 1 024-thread block — a (block, bucket)
-    // run of the scatter is then ~23 entries instead of ~6 (its partial-line writes were 9 of its 21 us at 65 536 envs) and the count
-    // table a quarter of the rows; small batches keep the small tile (more blocks than CUs matter more there)
+// tile of the sort's first two passes: 4 096 slots per 256-thread block; from 2 M slots 16 384 per 1 024-thread block — a (block, bucket)
+// run of the scatter is then ~23 entries instead of ~6 (its partial-line writes were 9 of its 21 us at 65 536 envs) and the count
+// table a quarter of the rows; small batches keep the small tile (more blocks than CUs matter more there)
+static inline uint32_t bin_tile_threads(uint32_t n_slots, uint32_t low_bits, bool* packed_out) {
     const bool big = n_slots >= (2u << 20);
     const bool packed = (uint64_t)n_slots <= (1ull << (32u - low_bits));          // slot ids leave room for the low bin bits: one dword per entry
-    const uint32_t nt = big ? (packed ? 1024u : 512u) : 256u, tile = nt * BKT_ITEMS;      // (two-dword entries: 12 bytes of LDS per slot, 8 192 slots)
+    if (packed_out) *packed_out = packed;
+    return big ? (packed ? 1024u : 512u) : 256u;                                  // (two-dword entries: 12 bytes of LDS per slot, 8 192 slots)
+}
+
+bool bin_hist_fused(uint32_t n_slots, uint32_t R8, uint32_t n_bins, uint32_t low_bits, uint32_t* blocks_per_tile) {
+    const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
+    const uint32_t tile = bin_tile_threads(n_slots, low_bits, nullptr) * BKT_ITEMS, keys = 64u * R8;      // keys of a prep_rays block's 64 envs
+    if (low_bits < 8u || low_bits > 12u || n_buckets > 1024u || keys > tile || tile % keys != 0u) return false;
+    *blocks_per_tile = tile / keys;
+    return true;
+}
+
+// sort the valid ray slots by bin; work = [counts/offsets table | pairs]; returns hipErrorInvalidValue when the bin space is too large
+hipError_t launch_bin_rays(const uint32_t* bins, uint32_t n_slots, uint32_t n_valid, uint32_t n_bins, uint32_t low_bits,
+                           uint32_t* table, uint2* pairs, uint32_t* block_sums, uint32_t* sorted, bool hist_done, hipStream_t s) {
+    const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
+    if (low_bits < 8u || low_bits > 12u || n_buckets > BKT_MAX) return hipErrorInvalidValue;
+    const bool big = n_slots >= (2u << 20);
+    bool packed;
+    const uint32_t nt = bin_tile_threads(n_slots, low_bits, &packed), tile = nt * BKT_ITEMS;
     const uint32_t n_blocks = blocks_for(n_slots, tile);
     uint32_t* bucket_tot = block_sums;                 // [BKT_MAX]
+    uint32_t* const zero = hist_done ? table : nullptr;         // counted by prep_rays_kernel: the table has to be zero again after this sort
+    const uint32_t n_zero = n_blocks * n_buckets;
     uint32_t* bucket_base = block_sums + BKT_MAX;      // [BKT_MAX + 1]
     const uint32_t scatter_lds = (2u * n_buckets + (packed ? 2u : 3u) * tile + 2u) * 4u, sort_lds = ((1u << low_bits) + BKT_STAGE) * 4u;
 #define BKT_LAUNCH(PK, NT)                                                                                                            \
     do {                                                                                                                              \
-        hipLaunchKernelGGL(bucket_hist_kernel<NT>, dim3(n_blocks), dim3(NT), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table); \
+        if (!hist_done) hipLaunchKernelGGL(bucket_hist_kernel<NT>, dim3(n_blocks), dim3(NT), 0, s, bins, n_slots, low_bits, n_buckets, n_blocks, table); \
         hipLaunchKernelGGL(bucket_rowscan_kernel, dim3(blocks_for(n_buckets, 16)), dim3(64 * RSCAN_WAVES), 0, s, table, n_blocks, n_buckets, bucket_tot); \
         hipLaunchKernelGGL((bucket_scatter_kernel<PK, NT>), dim3(n_blocks), dim3(NT), scatter_lds, s, bins, n_slots, low_bits, n_buckets, n_blocks, \
                            table, bucket_tot, bucket_base, pairs);                                                                   \
         /* buckets of <= 16 384 entries: 512 threads x 32; mean bucket above 8 192 (dense ray sets: the terrain buckets of 65 536 envs x 120 rays hold 22 k): 1 024 x 32 */ \
         if ((uint64_t)n_valid > 8192ull * n_buckets)                                                                                  \
-            hipLaunchKernelGGL((bucket_sort_kernel<PK, 1024, 32>), dim3(n_buckets), dim3(1024), sort_lds, s, pairs, bucket_base, low_bits, sorted); \
+            hipLaunchKernelGGL((bucket_sort_kernel<PK, 1024, 32>), dim3(n_buckets), dim3(1024), sort_lds, s, pairs, bucket_base, low_bits, sorted, zero, n_zero); \
         else                                                                                                                          \
-            hipLaunchKernelGGL((bucket_sort_kernel<PK, 512, 32>), dim3(n_buckets), dim3(512), sort_lds, s, pairs, bucket_base, low_bits, sorted);     \
+            hipLaunchKernelGGL((bucket_sort_kernel<PK, 512, 32>), dim3(n_buckets), dim3(512), sort_lds, s, pairs, bucket_base, low_bits, sorted, zero, n_zero);     \
     } while (0)
     if (big) {      // more than 64 KB of dynamic LDS: the kernel has to be told (once per size)
         static uint32_t raised_of[64][2] = {};       // per device: the attribute belongs to the function on the current device
