@@ -59,8 +59,7 @@ struct rover_ctx {
     bool have_stones = false;
     // per-step workspace
     uint32_t R8 = 0;
-    RayRec* d_rays = nullptr;           // [E*R8] ray records: in slot order (prep_rays_kernel; variants 1, 2, the hit-point exports), or in sorted order (the culled ray cast's own)
-    float4 *d_pose_tab = nullptr, *d_wheel_tab = nullptr, *d_dir_tab = nullptr;      // per-env tables the culled ray cast builds its records from (PrepArgs)
+    RayRec* d_rays = nullptr;
     float* d_dist_out = nullptr;    // [E*R8]
     float* d_euler = nullptr;       // [E,3]
     float* d_heading = nullptr;     // [E]
@@ -91,10 +90,7 @@ struct rover_ctx {
     size_t mlp_scratch_floats = 0;
     uint64_t workspace_bytes = 0;
     bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
-    RayRec* d_rays2 = nullptr;   // DIAG
-    bool rays_valid = false;            // a step has run: euler / heading / distances are there
-    bool records_valid = false;         // d_rays holds the last step's records in slot order
-    bool tables_valid = false;          // the per-env tables hold the last step's poses
+    bool rays_valid = false;
     // in-situ ray-cast timing (rover_set_profiling)
     bool profiling = false;
     int32_t prof_every = 1;             // time every prof_every-th ray-cast launch (an event pair costs ~12 us of stream time)
@@ -272,7 +268,7 @@ static int alloc_cull_queue(rover_ctx* c) {
 static int alloc_workspace(rover_ctx* c) {
     c->ws_ok = false;
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_sorted);
-    dfree(c->d_bins); dfree(c->d_pairs); dfree(c->d_pose_tab); dfree(c->d_wheel_tab); dfree(c->d_dir_tab);
+    dfree(c->d_bins); dfree(c->d_pairs);
     const uint64_t E = (uint64_t)c->cfg.num_envs;
     c->R8 = (uint32_t)(((26 + c->P) + 7) / 8 * 8);
     const uint64_t n = E * c->R8;
@@ -284,13 +280,10 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_sorted, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_bins, n * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_pairs, n * sizeof(uint2)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_pose_tab, E * 3 * sizeof(float4)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_wheel_tab, E * 12 * sizeof(float4)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_dir_tab, E * 8 * sizeof(float4)));
     HIP_TRY(c, hipMemset(c->d_euler, 0, E * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
-    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (4 * sizeof(float) + sizeof(int64_t) + 23 * sizeof(float4));
-    c->rays_valid = c->records_valid = c->tables_valid = false;
+    c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (4 * sizeof(float) + sizeof(int64_t));
+    c->rays_valid = false;
     c->ws_ok = true;
     return alloc_bins(c);
 }
@@ -437,7 +430,6 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_stones);
     { uint32_t* p = const_cast<uint32_t*>(c->sgrid.cell_start); dfree(p); float4* q = const_cast<float4*>(c->sgrid.stone_xyr); dfree(q); }
     dfree(c->d_rays); dfree(c->d_dist_out); dfree(c->d_euler); dfree(c->d_heading); dfree(c->d_ids_work);
-    dfree(c->d_pose_tab); dfree(c->d_wheel_tab); dfree(c->d_dir_tab);
     dfree(c->d_bins); dfree(c->d_bkt_table); dfree(c->d_pairs); dfree(c->d_block_sums); dfree(c->d_sorted);
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
@@ -685,13 +677,7 @@ static int check_ready(rover_ctx* c) {
 
 static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     CullArgs a{};
-    a.stage = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
-    a.gen.dist = c->d_dist; a.gen.bins = c->d_bins;
-    a.gen.pose_tab = c->d_pose_tab; a.gen.wheel_tab = c->d_wheel_tab; a.gen.dir_tab = c->d_dir_tab;
-    a.gen.r8_div = make_fastdiv(c->R8); a.gen.R8 = c->R8;
-    a.gen.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
-    a.gen.precision = c->precision;
-    a.gen.diag_recs = c->d_rays2;
+    a.rays = c->d_rays; a.sorted = c->d_sorted; a.n_sorted = n_valid;
     a.n_terrain = (uint32_t)c->cfg.num_envs * (uint32_t)c->P;
     const bool h = c->precision == 2;     // the as-shipped fp16 arithmetic: its own proof tables, the fp16 exact phase
     a.idx0 = c->cull_idx[0]; a.idx1 = c->cull_idx[1];
@@ -734,23 +720,15 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
 // The ray pipeline of a step: env records + ray records, the bucket sort by (map, cell), the ray cast -> d_dist_out [E][R8].
 // euler_in != NULL (rover_get_depths): the poses come as euler angles, quat / joints / target may be NULL, and the ctx's euler / heading
 // state of the last observation is left alone.
-// want_records: the caller reads the ray records in slot order afterwards (ray origins / hit points of export_dist_kernel) — the culled
-// ray cast does not need them (its waves rebuild the records of their runs from the per-env tables), prep_rays_kernel then writes none.
 static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const float* joints, const float* target, const float* euler_in,
-                     bool want_records, hipStream_t s) {
+                     hipStream_t s) {
     const uint32_t E = (uint32_t)c->cfg.num_envs;
     PrepArgs p{};
     p.E = E; p.P = (uint32_t)c->P; p.R8 = c->R8;
     p.pos = pos; p.quat = quat; p.joints = joints; p.target = target; p.euler_in = euler_in;
     p.dist = c->d_dist; p.terrain = c->map[0]; p.rocks = c->map[1];
-    p.euler = euler_in ? nullptr : c->d_euler; p.heading = euler_in ? nullptr : c->d_heading;
+    p.rays = c->d_rays; p.euler = euler_in ? nullptr : c->d_euler; p.heading = euler_in ? nullptr : c->d_heading;
     const int variant = effective_variant(c);
-    // The culled ray cast writes its own (sorted) records into d_rays: records in slot order that a caller wants go there AFTER it.
-    const bool records = variant != 3;
-    p.rays = records ? c->d_rays : nullptr;
-    if (getenv("ROVER_DIAG_RECS") && !c->d_rays2) { if (hipMalloc((void**)&c->d_rays2, (size_t)E * c->R8 * sizeof(RayRec)) != hipSuccess) return fail(c, ROVER_E_NOMEM, "diag"); }
-    if (c->d_rays2) p.rays = c->d_rays2;
-    if (variant == 3) { p.pose_tab = c->d_pose_tab; p.wheel_tab = c->d_wheel_tab; p.dir_tab = c->d_dir_tab; }
     // (the queue is sized by every call that changes its size — never here: no hipMalloc inside a step / a stream capture)
     if (variant == 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
         return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
@@ -793,16 +771,6 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     c->last_variant = variant;
     c->sorted_valid = variant >= 2;
     c->rays_valid = true;
-    c->records_valid = records;
-    c->tables_valid = variant == 3;
-    if (want_records && !records) {     // (rare: the optional ray_src / hit_pt outputs, rover_get_depths' points / sources)
-        PrepArgs q = p;
-        q.rays = c->d_rays; q.bin_out = nullptr; q.hist = nullptr; q.euler = nullptr; q.heading = nullptr;
-        q.pose_tab = q.wheel_tab = q.dir_tab = nullptr;
-        HIP_TRY(c, launch_prep(q, s));
-        c->records_valid = true;
-        c->sorted_valid = false;        // (d_rays no longer holds the culled ray cast's sorted records: no replay of it)
-    }
     return ROVER_OK;
 }
 
@@ -813,7 +781,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     const uint32_t E = (uint32_t)c->cfg.num_envs, W = (uint32_t)(4 + c->Ns + c->Nd);
     const int64_t stride = out->obs_stride ? out->obs_stride : (int64_t)W;
     if (stride < (int64_t)W) return fail(c, ROVER_E_INVALID, "obs_stride %lld < row width %u", (long long)stride, W);
-    if (int r = cast_rays(c, in->pos, in->quat, in->joints, in->target, nullptr, out->ray_src || out->hit_pt, s)) return r;
+    if (int r = cast_rays(c, in->pos, in->quat, in->joints, in->target, nullptr, s)) return r;
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
@@ -905,7 +873,7 @@ int rover_get_depths(rover_ctx* c, const float* positions, const float* rotation
     if (int r = check_ready(c)) return r;
     USE_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
-    if (int r = cast_rays(c, positions, nullptr, nullptr, nullptr, rotations_euler, points || sources, s)) return r;
+    if (int r = cast_rays(c, positions, nullptr, nullptr, nullptr, rotations_euler, s)) return r;
     if (distances || points || sources)
         HIP_TRY(c, launch_export_dist(c->d_dist_out, c->d_rays, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, c->precision, distances,
                                       nullptr, nullptr, sources, points, s));
@@ -1399,9 +1367,6 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     USE_DEVICE(c);
     int v = effective_variant(c);
     if (v >= 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
-    if (v == 3 ? !c->tables_valid : !c->records_valid)
-        return fail(c, ROVER_E_STATE, "replay_raycast: the last step ran another ray-cast variant (the culled one keeps per-env tables, the others "
-                                      "ray records): run a step with the variant in force first");
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
     if (v == 3) {

@@ -36,7 +36,6 @@
 #include <stdlib.h>
 #include "rover_internal.h"
 #include "rover_raymath.h"
-#include "rover_rayrec.h"
 
 namespace rover {
 
@@ -471,9 +470,9 @@ __device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane /* wave-u
 // phases of others — as a second kernel (or on a second stream) the two phases only ran one after the other.
 // ---------------------------------------------------------------------------------------------------
 template <int H>
-__device__ __forceinline__ void cull_exact(const RayRec* rays /* the run's records, by run position */, const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
+__device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rtab0, const RawTri* __restrict__ rtab1,
                                            const uint2* lq, uint32_t lcap, const uint2* qw, uint32_t n,
-                                           uint32_t lane, uint32_t* bk) {
+                                           uint32_t gid /* per lane: ray id of run position `lane` */, uint32_t lane, uint32_t* bk) {
     // entry i of the wave's queue: the first lcap in LDS, the rest in its global region
     auto entry = [&](uint32_t i) { return i < lcap ? lq[i] : qw[i - lcap]; };
     // The queue entries are read one round ahead: a round then waits for ONE memory round trip (the gathers its entries
@@ -487,7 +486,8 @@ __device__ __forceinline__ void cull_exact(const RayRec* rays /* the run's recor
         const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
         const RawTri* rt = map ? rtab1 : rtab0;
         const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
-        const float4* rp = reinterpret_cast<const float4*>(rays + pos);
+        const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
+        const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
         if (base + 64u < n) en_next = entry(min(base + 64u + lane, n - 1u));
         float best;
@@ -578,7 +578,7 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 #define CULL_QCAP 1024u              // entries of a wave's queue (LDS part + global region).  A ray adds at most 128, so a wave that finds more than
                                      // CULL_QCAP - 128 entries after a ray finishes (exact phase) what it has and scans on from the next ray
 #define CULL_SCAN_ARGS                                                                                                          \
-    RayRec *stage, CullRayGen gen, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
+    const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const int4 *__restrict__ idx0,     \
         const int4 *__restrict__ idx1, const uint4 *__restrict__ ctab0, const uint4 *__restrict__ ctab1,                         \
         uint32_t kp01 /* K8 of map 0 | K8 of map 1 << 16 */, uint32_t run, uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr /* chs | chr << 8 */, uint32_t run_r, uint2 *__restrict__ queue,                                      \
         const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, float *__restrict__ out, uint4 *__restrict__ stats, uint32_t j0, float c_a_h, float tau2_h, const float4 *__restrict__ far0, const float4 *__restrict__ far1, float k2_far, const float4 *__restrict__ near0, const float4 *__restrict__ near1
@@ -640,62 +640,6 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // The run's ray ids, one per lane.  The rays' parameters come by scalar loads (s_load_dwordx8 through the ray id of lane r),
     // requested one ray ahead so that their latency passes under the previous ray's arithmetic.
     const uint32_t gid = sorted[i0 + (lane < n_run ? lane : n_run - 1u)];
-    // The run's ray records {origin, cell | direction, flags}, rebuilt by the wave from the per-env tables of prep_rays_kernel — the pose's
-    // sin / cos, the wheels' joint sin / cos, the direction record of the ray's kind — with the arithmetic prep_rays_kernel derived the
-    // ray's cell from (rover_rayrec.h), and written to stage[i0 ..]: the records in SORTED order, 2 KB per wave that nobody else touches.
-    // (Until round 4 prep_rays_kernel wrote a record per ray slot — 134 MB at 65 536 envs, the kernel bound by its stores — and the waves
-    //  gathered them back, 32 bytes from anywhere in those 134 MB per ray.)
-    RayRec* const srun_w = stage + i0;
-    float4 rec_a, rec_b;                        // this lane's record (run position `lane`, the last ray's past the end of the run)
-    if (gen.diag_recs) {
-        const float4* rp = reinterpret_cast<const float4*>(gen.diag_recs + gid);
-        rec_a = rp[0]; rec_b = rp[1];
-        if (lane < n_run) { float4* o = reinterpret_cast<float4*>(srun_w + lane); o[0] = rec_a; o[1] = rec_b; }
-    } else {
-        const uint32_t e = gen.r8_div.div(gid);
-        const uint32_t slot = gid - e * gen.R8;
-        const uint32_t bin = gen.bins[gid];
-        const float4 T0 = gen.pose_tab[3ull * e], T1 = gen.pose_tab[3ull * e + 1u];
-        const float px = T1.z, py = T1.w, pz = gen.pose_tab[3ull * e + 2u].x;
-        const float4 D = gen.dir_tab[8ull * e + ray_kind(slot)];
-        float2 d0 = make_float2(0.0f, 0.0f), d1 = d0, d2 = d0;
-        double x = 0.0, y = 0.0, z = 0.0;
-        if (slot < 24u) {
-            const float4* wp = gen.wheel_tab + (6ull * e + (slot >> 2)) * 2u;
-            const float4 W0 = wp[0], W1 = wp[1];
-            d0 = make_float2(W0.x, W0.y); d1 = make_float2(W0.z, W0.w); d2 = make_float2(W1.x, W1.y);
-        } else if (slot >= 26u) {
-            const double* dp = gen.dist + 3ull * (slot - 26u);
-            x = dp[0]; y = dp[1]; z = dp[2];
-        }
-        Trig6 t;
-        t.sx = T0.x; t.cx = T0.y; t.sy = T0.z; t.cy = T0.w; t.sz = T1.x; t.cz = T1.y;
-        float sx, sy, sz;
-        ray_origin(slot, t, px, py, pz, d0, d1, d2, x, y, z, sx, sy, sz);
-        if (gen.precision >= 1) { sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz; }      // sources.type(float16): camera.py:212
-        const uint32_t cell = bin - (slot < 26u ? gen.rocks_bin_offset : 0u);
-        rec_a = make_float4(sx, sy, sz, __uint_as_float(cell)); rec_b = D;
-        if (lane < n_run) {
-            float4* o = reinterpret_cast<float4*>(srun_w + lane);
-            o[0] = rec_a;
-            o[1] = rec_b;
-        }
-    }
-    // Nobody waits for these stores here: the wave's first segment works on the records in its registers, and the first SCALAR read of a
-    // record (a ray's parameters, in the ray loop) comes after the s_waitcnt vmcnt(0) that opens the first bin (vector memory operations
-    // retire in order: the id row it waits for was requested after the stores).  The reads go through a pointer in the constant address
-    // space that the compiler cannot connect with the stores: wave-uniform reads then are scalar loads (s_load_dwordx8), as they were from
-    // prep_rays_kernel's read-only records.  (Waiting for the acknowledgement right here, one more round trip per wave in a kernel
-    // that is bound by such latencies: 0.507 ms instead of 0.448.)
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(4))) f4v cf4v;
-    cf4v* srun;                                 // record r of the run: srun[2 r], srun[2 r + 1]
-    {
-        const RayRec* sr = srun_w;
-        asm volatile("" : "+s"(sr) :: "memory");
-        srun = (cf4v*)sr;
-    }
-    auto ld4 = [](cf4v* p) { const f4v v = *p; return make_float4(v.x, v.y, v.z, v.w); };
     wave_lds_sync();
     bk[lane] = fkey(RAY_MISS);                 // 11.0 where a ray has no candidate at all (a culled triangle contributes exactly that)
     uint32_t ctot = 0, n_both = 0, n_bins = 0, n_fskip = 0, n_askip = 0; // queue entries / rays that ran both tests / bins walked / rays that skipped the far pairs / rays not scanned at all (rover_get_cull_info)
@@ -707,15 +651,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     while (r_next < n_run) {
     // The run's (map, cell) keys, one per lane, in ONE round of loads: the wave then knows its bins and can request their
     // id rows ahead.
-    // (through an opaque copy of the run position: everything below is invariant across segments, and hoisted out of this loop by the
+    // (through an opaque copy of the ray id: everything below is invariant across segments, and hoisted out of this loop by the
     //  compiler it would stay in registers through the scan AND the exact phase — 76 VGPRs instead of 62)
-    float4 rsa = rec_a, rsb = rec_b;
-    if (r_next != 0u) {                         // (a later segment: the records are long in memory)
-        uint32_t rpos = lane < n_run ? lane : n_run - 1u;
-        asm volatile("" : "+v"(rpos));
-        rsa = ld4(srun + 2u * rpos); rsb = ld4(srun + 2u * rpos + 1u);
-    }
-    rec_a = rec_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // (dead from here on: not held through the exact phase)
+    uint32_t gid_s = gid;
+    asm volatile("" : "+v"(gid_s));
+    const float4 rsa = reinterpret_cast<const float4*>(rays + gid_s)[0], rsb = reinterpret_cast<const float4*>(rays + gid_s)[1];
     const uint32_t rflags = __float_as_uint(rsb.w);
     const uint32_t key = __float_as_uint(rsa.w) | (rflags << 31);                      // cell | map << 31
     const uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ? lane - 1u : 0u) << 2), (int)key);
@@ -778,7 +718,8 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
             const uint64_t above = live & (~1ull << lane);                 // (per lane)
             nxt = above ? (uint32_t)__builtin_ctzll(above) : lane;
         }
-        nxw = nxt | ((uint32_t)((conemask >> lane) & 1ull) << 31) | ((uint32_t)((farskip >> lane) & 1ull) << 30);
+        const uint32_t gnx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)gid);
+        nxw = (gnx & 0x3fffffffu) | ((uint32_t)((conemask >> lane) & 1ull) << 31) | ((uint32_t)((farskip >> lane) & 1ull) << 30);
     }
     const uint64_t hm_all = (heads | (1ull << r_next)) & (~0ull << r_next);
     uint64_t hm = SKIP ? 0ull : hm_all;
@@ -808,10 +749,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
         if (pf_heads) prefetch_row();
     uint32_t cused = 0;
     auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
-        a4 = ld4(srun + 2u * r); b4 = ld4(srun + 2u * r + 1u);
+        const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
+        a4 = rp[0]; b4 = rp[1];
     };
-    float4 nxa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nxb = nxa;
-    bool first_bin = true;
+    float4 nxa, nxb;
+    load_ray(live ? (uint32_t)__builtin_ctzll(live) : r_next, nxa, nxb);       // the segment's first live ray
     bool full = false;
     while (hm && !full) {                      // one (map, cell) bin of the run: rays [i, i_end)
         const uint32_t i = (uint32_t)__builtin_ctzll(hm);
@@ -826,15 +768,6 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
         const uint32_t map = (uint32_t)__builtin_amdgcn_readlane((int)rowm, (int)i) & 1u;
         // the bin's id row, requested CULL_RING bins ago (8 waves per SIMD cover what is left of its latency)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (first_bin) {                        // the segment's first live ray (its record is in memory now: see above)
-            {                                   // (the pointer passes through a wait of its own: no scalar read can be scheduled above it)
-                const RayRec* sr = srun_w;
-                asm volatile("s_waitcnt vmcnt(0)" : "+s"(sr) :: "memory");
-                srun = (cf4v*)sr;
-            }
-            load_ray(live ? (uint32_t)__builtin_ctzll(live) : r_next, nxa, nxb);
-            first_bin = false;
-        }
         wave_lds_sync();
         const int4 id4 = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(&s_ids[tw][use_n % CULL_RING][0]) + lane_off(map));
         ++use_n;
@@ -893,8 +826,8 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
             const float4 ra = nxa, rb = nxb;
             const uint32_t xr = (uint32_t)__builtin_amdgcn_readlane((int)nxw, (int)r);
             {
-                const uint32_t rn = xr & 0x3fffffffu;                                            // the next (live) ray, of this bin or a later one
-                nxa = ld4(srun + 2u * rn); nxb = ld4(srun + 2u * rn + 1u);
+                const float4* rp = reinterpret_cast<const float4*>(rays + (xr & 0x3fffffffu));      // the next (live) ray, of this bin or a later one
+                nxa = rp[0]; nxb = rp[1];
             }
             const sgpr2 sxy = sgpr_pair(ra.x, ra.y), szc = sgpr_pair(ra.z, ra.w), dxy = sgpr_pair(rb.x, rb.y), dzf = sgpr_pair(rb.z, rb.w);
             uint64_t any[2];
@@ -952,7 +885,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // The wait also retires id-row loads of bins this segment did not reach (the ring restarts with the next segment).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
-    cull_exact<H>(reinterpret_cast<const RayRec*>((const f4v*)srun), rtab0, rtab1, lq, LCAP, qw, cused, lane, bk);
+    cull_exact<H>(rays, rtab0, rtab1, lq, LCAP, qw, cused, gid, lane, bk);
     ctot += cused;
     }
     wave_lds_sync();
@@ -1058,7 +991,7 @@ hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
         const uint32_t n = slots - j0 < per ? slots - j0 : per;
         auto kern = a.half ? (a.skip_clear ? (a.lazy_far ? cull_scan_kernel<1, 1, 1> : cull_scan_kernel<1, 0, 1>) : cull_scan_kernel<1, 0, 0>)
                            : (a.lazy_far ? cull_scan_kernel<0, 1, 1> : (a.skip_clear ? cull_scan_kernel<0, 0, 1> : cull_scan_kernel<0, 0, 0>));
-        hipLaunchKernelGGL(kern, dim3(n * 8u * (4u / CULL_WPB)), dim3(64 * CULL_WPB), 0, s, a.stage, a.gen, a.sorted, a.n_sorted,
+        hipLaunchKernelGGL(kern, dim3(n * 8u * (4u / CULL_WPB)), dim3(64 * CULL_WPB), 0, s, a.rays, a.sorted, a.n_sorted,
                            reinterpret_cast<const int4*>(a.idx0), reinterpret_cast<const int4*>(a.idx1), a.ctab0, a.ctab1,
                            a.kp0 | (a.kp1 << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8), g.run_r, a.queue,
                            reinterpret_cast<const RawTri*>(a.rtab0), reinterpret_cast<const RawTri*>(a.rtab1), a.out, a.stats, j0, a.c_a_h, a.tau2_h, a.far0, a.far1, a.k2_far, a.near0, a.near1);

@@ -50,10 +50,6 @@ struct PrepArgs {
     int32_t precision;           // 0 fp32 mode; 1 fp16-rounded ray origins / directions; 2 as shipped (fp16 ray maths too)
     int32_t cell_rcp;            // cell_index_mode: 0 = (v - shift) / cell (ATen CPU), 1 = (v - shift) * (1 / cell) (ATen CUDA)
     const float* euler_in;       // optional [E,3]: the pose's euler angles as given (rover_get_depths) instead of quat -> euler
-    // optional: the per-env tables the culled ray cast rebuilds its ray records from (rover_rayrec.h; `rays` may then be NULL)
-    float4* pose_tab;            // [E][3]   {sin, cos of -roll | -pitch}, {sin, cos of -yaw, x, y}, {z, -, -, -}
-    float4* wheel_tab;           // [E][6][2] per wheel {sin, cos of -steer | susX}, {sin, cos of susY, -, -}
-    float4* dir_tab;             // [E][8]   per direction kind (wheels 0..5, body, heightmap) {dx, dy, dz, flags} as in RayRec
     // optional: the first pass of the bucket sort (bin_hist_fused) — counts[tile][bucket] += the block's keys per coarse bucket
     uint32_t* hist;              // [tiles][hist_buckets], all zero when the kernel starts (bucket_sort_kernel clears it again)
     uint32_t hist_low_bits, hist_buckets, hist_blocks_per_tile;     // a tile of the sort = the keys of this many 64-env blocks
@@ -63,42 +59,9 @@ struct PrepArgs {
 struct CullProofH { double kappa, c_rho; float c_a, tau2; };
 CullProofH cull_proof_h(double eta);
 
-// n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own
-// expansion of a division by a run-time value is ~30 (32-bit) / ~110 (64-bit) dependent instructions per thread.
-struct FastDiv {
-    uint32_t m, s1, s2;
-#if defined(__HIPCC__)
-    __device__ __forceinline__ uint32_t div(uint32_t n) const {
-        const uint32_t t = __umulhi(m, n);
-        return (t + ((n - t) >> s1)) >> s2;
-    }
-#endif
-};
-inline FastDiv make_fastdiv(uint32_t d) {           // d >= 1
-    uint32_t L = 0;
-    while (L < 32 && (1ull << L) < d) ++L;
-    FastDiv f;
-    f.m = (uint32_t)((((1ull << L) - d) << 32) / d + 1ull);
-    f.s1 = L < 1 ? L : 1; f.s2 = L > 1 ? L - 1 : 0;
-    return f;
-}
-
-// What a wave of the culled ray cast rebuilds the ray records of its run from (rover_rayrec.h): prep_rays_kernel then writes three small
-// per-env tables and the bin keys instead of a 32-byte record per ray slot.
-struct CullRayGen {
-    const double* dist;          // [P][3] heightmap distribution
-    const uint32_t* bins;        // [E*R8] (map, cell) key of every ray slot
-    const float4 *pose_tab, *wheel_tab, *dir_tab;      // PrepArgs
-    FastDiv r8_div;              // ray id -> env
-    uint32_t R8, rocks_bin_offset;
-    int32_t precision;
-    const RayRec* diag_recs;     // DIAG
-};
-
 // raycast_culled_kernel (rover_cull.hip)
 struct CullArgs {
-    RayRec* stage;               // [n_sorted] the ray records in SORTED order, written and read by the wave that owns the run
-    CullRayGen gen;
+    const RayRec* rays;
     const uint32_t* sorted;      // ray slots sorted by (map, cell)
     uint32_t n_sorted;
     uint32_t n_terrain;          // the first n_terrain sorted rays are terrain rays (bins are (map, cell): terrain first)
@@ -121,6 +84,25 @@ struct CullArgs {
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches);
 
+// n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own
+// expansion of a division by a run-time value is ~30 (32-bit) / ~110 (64-bit) dependent instructions per thread.
+struct FastDiv {
+    uint32_t m, s1, s2;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+#endif
+};
+inline FastDiv make_fastdiv(uint32_t d) {           // d >= 1
+    uint32_t L = 0;
+    while (L < 32 && (1ull << L) < d) ++L;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << L) - d) << 32) / d + 1ull);
+    f.s1 = L < 1 ? L : 1; f.s2 = L > 1 ? L - 1 : 0;
+    return f;
+}
 
 struct ObsArgs {
     uint32_t E, W, R8;

@@ -32,7 +32,6 @@
 #include <stdint.h>
 #include "rover_internal.h"
 #include "rover_raymath.h"
-#include "rover_rayrec.h"
 
 namespace rover {
 
@@ -64,12 +63,40 @@ __device__ __forceinline__ void quat_to_euler(const float* __restrict__ q, float
     roll = quat_roll(q); pitch = quat_pitch(q); yaw = quat_yaw(q);
 }
 
+struct Trig6 { float sx, cx, sy, cy, sz, cz; };
+
 __device__ __forceinline__ Trig6 euler_trig(float roll, float pitch, float yaw) {
     Trig6 t;
     t.sx = sinf(-roll);  t.cx = cosf(-roll);
     t.sy = sinf(-pitch); t.cy = cosf(-pitch);
     t.sz = sinf(-yaw);   t.cz = cosf(-yaw);
     return t;
+}
+
+// rock_detect.py:305-307 / :356-358 — f32 body transform
+__device__ __forceinline__ void body_xf(float x, float y, float z, const Trig6& t, float px, float py, float pz,
+                                        float& ox, float& oy, float& oz) {
+    float A = y * t.cx + z * t.sx;
+    float C = z * t.cx - y * t.sx;
+    float B = x * t.cy - t.sy * C;
+    ox = px + t.sz * A + t.cz * B;
+    oy = py + t.cz * A - t.sz * B;
+    oz = pz + x * t.sy + t.cy * C;
+}
+
+// rock_detect.py:256-258,275-277 then body_xf: wheel-local point -> world (translations zeroed for directions)
+__device__ __forceinline__ void wheel_chain(float x, float y, float z, const float* t0, const float* t1,
+                                            float sst, float cst, float ssx, float csx, float ssy, float csy,
+                                            const Trig6& t, float px, float py, float pz,
+                                            float& ox, float& oy, float& oz) {
+    float x1 = t0[0] + x * cst + y * sst;
+    float y1 = t0[1] + y * cst - x * sst;
+    float z1 = t0[2] + z;
+    float c1 = z1 * csx - y1 * ssx;
+    float x2 = t1[0] + x1 * csy - ssy * c1;
+    float y2 = t1[1] + y1 * csx + z1 * ssx;
+    float z2 = t1[2] + x1 * ssy + csy * c1;
+    body_xf(x2, y2, z2, t, px, py, pz, ox, oy, oz);
 }
 
 // camera.py:241-253: clamp bound is the dim-0 size for both axes; torch.round is half-to-even.
@@ -135,6 +162,14 @@ __global__ void __launch_bounds__(256) repack_knn_kernel(const int32_t* __restri
 // prep: one thread per (env, slot).  slots 0..23 wheel rays, 24..25 body rays, 26..26+P-1 terrain rays,
 // rest padding to a multiple of 8 (a ray-cast workgroup then never straddles two envs).
 // ---------------------------------------------------------------------------------------------------
+__constant__ float c_wheel_ray[5][3] = {{0.215 / 2, 0.130 / 2, 0.1}, {0.215 / 2, -0.130 / 2, 0.1},
+                                        {-0.215 / 2, 0.130 / 2, 0.1}, {-0.215 / 2, -0.130 / 2, 0.1}, {0, 0, -1}};
+__constant__ float c_wp0[6][3] = {{0.286, 0.385, -0.197}, {0.286, -0.385, -0.197}, {-0.146, 0.447, -0.197},
+                                  {-0.146, -0.447, -0.197}, {-0.440, 0.385, -0.197}, {-0.440, -0.385, -0.197}};
+__constant__ float c_wp1[6][3] = {{0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, 0, 0.03}, {0.153, -0.0, 0.03},
+                                  {0, 0, 0.03}, {0, 0, 0.03}};
+__constant__ float c_body_pt[2][3] = {{0.340, 0, -0.01}, {-0.485, 0, -0.01}};
+
 // per (env, slot): ray origin, unit direction, cell id, bin key.
 // A workgroup takes 64 envs and a range of slot groups (8 slots each): in a group wave w works on ONE slot (8 g + w) of the 64 envs, so the
 // three kinds of slot — wheel rays (f32 joint chain), body rays, heightmap rays (f64 transform) — never share a wave and the slot's constants
@@ -208,11 +243,6 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             s_wheel[wh][0][lane] = make_float2(sinf(-steer), cosf(-steer));
             s_wheel[wh][1][lane] = make_float2(sinf(susX), cosf(susX));
             s_wheel[wh][2][lane] = make_float2(sinf(susY), cosf(susY));
-            if (a.wheel_tab && live) {          // (a wheel belongs to one slot group: one block writes it)
-                const float2 u0 = s_wheel[wh][0][lane], u1 = s_wheel[wh][1][lane], u2 = s_wheel[wh][2][lane];
-                a.wheel_tab[(6ull * e + wh) * 2u] = make_float4(u0.x, u0.y, u1.x, u1.y);
-                a.wheel_tab[(6ull * e + wh) * 2u + 1u] = make_float4(u2.x, u2.y, 0.0f, 0.0f);
-            }
         }
     }
     __syncthreads();
@@ -220,12 +250,12 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
     {
         const float2 tr = s_trig[0][lane], tp2 = s_trig[1][lane], ty2 = s_trig[2][lane];
         t.sx = tr.x; t.cx = tr.y; t.sy = tp2.x; t.cy = tp2.y; t.sz = ty2.x; t.cz = ty2.y;
-        if (a.pose_tab && blockIdx.y == 0u && w == 0u && live) {
-            a.pose_tab[3ull * e] = make_float4(tr.x, tr.y, tp2.x, tp2.y);
-            a.pose_tab[3ull * e + 1u] = make_float4(ty2.x, ty2.y, px, py);
-            a.pose_tab[3ull * e + 2u] = make_float4(pz, 0.0f, 0.0f, 0.0f);
-        }
     }
+    // the pose in float64 for the heightmap rays (camera.py:165-212 works in the distribution tensor's float64; widened where it is
+    // used: eighteen registers held through the loop would cost the kernel its eighth wave per SIMD)
+#define PREP_POSE_F64                                                                                                                    \
+    const double dsx = (double)t.sx, dcx = (double)t.cx, dsy = (double)t.sy, dcy = (double)t.cy, dsz = (double)t.sz, dcz = (double)t.cz; \
+    const double X = (double)px, Y = (double)py, Z = (double)pz
     if (w < 6u ? (w >= wh_lo && w < wh_hi) : (w == 6u ? (s_lo < 26u && s_hi > 24u) : s_hi > 26u)) {
         float ux, uy, uz;
         uint32_t fl;
@@ -241,7 +271,7 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             ux = qx - px; uy = qy - py; uz = qz - pz;
             fl = 3u;
         } else {                                // the heightmap rays: the appended (0,0,-1) point, camera.py:179-181,202-204, float64
-            ROVER_POSE_F64(t, px, py, pz);
+            PREP_POSE_F64;
             const double xn = 0.0, yn = 0.0, zn = -1.0;
             const double A = yn * dcx + zn * dsx, C = zn * dcx - yn * dsx, B = xn * dcy - dsy * C;
             ux = (float)((X + dsz * A + dcz * B) - X);
@@ -270,18 +300,15 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             const float qm = 3.5e-3f * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
             if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                // NaN -> 0xffff
         }
-        const float4 dr = make_float4(dx, dy, dz, __uint_as_float(fl | (qq << 16)));
-        s_dir[w][lane] = dr;
-        // (the body rays' and the heightmap rays' record: written by the block that holds their first slot)
-        if (a.dir_tab && live && (w < 6u || (w == 6u ? (s_lo <= 24u && s_hi > 24u) : (s_lo <= 26u && s_hi > 26u)))) a.dir_tab[8ull * e + w] = dr;
+        s_dir[w][lane] = make_float4(dx, dy, dz, __uint_as_float(fl | (qq << 16)));
     }
     // The group's 64 x 8 records and bin keys, env-major through LDS (rows of 17 float4 / 9 dwords: a wave's 64 rows spread over the banks):
     // a store instruction then writes four envs' 256-byte groups — whole lines — instead of 64 records 2 KB apart.
     __shared__ float4 s_t[64 * (2 * PREP_SLOTS + 1)];
     __shared__ uint32_t s_b[64 * (PREP_SLOTS + 1)];
     float4* const rays4 = reinterpret_cast<float4*>(a.rays);
-    // (blocks starting at different groups of their range, so that those running together do not all write the same 256-byte residue
-    //  class of the 2-KB rows: no change, 36.7 / 36.8 us on a box where the kernel is bound by its stores at 4.7 TB/s)
+    const Trig6& t_ = t;
+    const float px_ = px, py_ = py, pz_ = pz;
     for (uint32_t g = g0; g < g1; ++g) {
         const uint32_t slot0 = g * PREP_SLOTS, slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 + w));
         RayRec rec;
@@ -295,17 +322,29 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
             const float m_shift_x = rk ? a.rocks.shift_x : a.terrain.shift_x, m_shift_y = rk ? a.rocks.shift_y : a.terrain.shift_y;
             const float m_cell = rk ? a.rocks.cell : a.terrain.cell, m_inv_cell = rk ? a.rocks.inv_cell : a.terrain.inv_cell;
             const int32_t m_X = rk ? a.rocks.X : a.terrain.X, m_Y = rk ? a.rocks.Y : a.terrain.Y;
-            float2 d0 = make_float2(0.0f, 0.0f), d1 = d0, d2 = d0;
-            double x = 0.0, y = 0.0, z = 0.0;
-            if (slot < 24u) { const uint32_t wh = slot >> 2; d0 = s_wheel[wh][0][lane]; d1 = s_wheel[wh][1][lane]; d2 = s_wheel[wh][2][lane]; }
-            else if (slot >= 26u) dist_of(slot, x, y, z);
-            {
-                Trig6 tq = t;                   // (opaque copies: hoisted out of the loop the pose widened to f64 is eighteen registers,
-                float qx = px, qy = py, qz = pz;  //  the kernel's eighth wave per SIMD)
-                asm volatile("" : "+v"(tq.sx), "+v"(tq.cx), "+v"(tq.sy), "+v"(tq.cy), "+v"(tq.sz), "+v"(tq.cz), "+v"(qx), "+v"(qy), "+v"(qz));
-                ray_origin(slot, tq, qx, qy, qz, d0, d1, d2, x, y, z, sx, sy, sz);
+            if (slot < 24u) {                   // rock_detect.py:160-319
+                const uint32_t wh = slot >> 2, r = slot & 3u;
+                const float2 d0 = s_wheel[wh][0][lane], d1 = s_wheel[wh][1][lane], d2 = s_wheel[wh][2][lane];
+                wheel_chain(c_wheel_ray[r][0], c_wheel_ray[r][1], c_wheel_ray[r][2], c_wp0[wh], c_wp1[wh], d0.x, d0.y, d1.x, d1.y,
+                            d2.x, d2.y, t, px, py, pz, sx, sy, sz);
+                kind = wh;
+            } else if (slot < 26u) {            // rock_detect.py:321-371
+                const uint32_t r = slot - 24u;
+                body_xf(c_body_pt[r][0], c_body_pt[r][1], c_body_pt[r][2], t, px, py, pz, sx, sy, sz);
+                kind = 6u;
+            } else {                            // camera.py:165-212, float64 like the distribution tensor
+                Trig6 t = t_;                   // (opaque copies: hoisted out of the loop the widened pose is those eighteen registers)
+                float px = px_, py = py_, pz = pz_;
+                asm volatile("" : "+v"(t.sx), "+v"(t.cx), "+v"(t.sy), "+v"(t.cy), "+v"(t.sz), "+v"(t.cz), "+v"(px), "+v"(py), "+v"(pz));
+                PREP_POSE_F64;
+                double x, y, z;
+                dist_of(slot, x, y, z);
+                const double A = y * dcx + z * dsx, C = z * dcx - y * dsx, B = x * dcy - dsy * C;
+                sx = (float)(X + dsz * A + dcz * B);
+                sy = (float)(Y + dcz * A - dsz * B);
+                sz = (float)(Z + x * dsy + dcy * C);
+                kind = 7u;
             }
-            kind = ray_kind(slot);
             if (a.precision >= 1) { sx = (float)(_Float16)sx; sy = (float)(_Float16)sy; sz = (float)(_Float16)sz; }      // sources.type(float16): camera.py:212
             rec.sx = sx; rec.sy = sy; rec.sz = sz;
             uint32_t ix = cell_coord(sx, m_shift_x, m_cell, m_inv_cell, a.cell_rcp, m_X);
@@ -318,28 +357,25 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
         // the direction records are written (first group: the waves that did not build one have worked on their origins meanwhile);
         // the previous group's records have left s_t / s_b
         __syncthreads();
-        if (rays4) {                            // (not for the culled ray cast: its waves rebuild the records of their runs from the tables)
-            if (real) {
-                const float4 dr = s_dir[kind][lane];
-                rec.dx = dr.x; rec.dy = dr.y; rec.dz = dr.z; rec.flags = __float_as_uint(dr.w);
-            }
-            s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
-            s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
+        if (real) {
+            const float4 dr = s_dir[kind][lane];
+            rec.dx = dr.x; rec.dy = dr.y; rec.dz = dr.z; rec.flags = __float_as_uint(dr.w);
         }
+        s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w] = make_float4(rec.sx, rec.sy, rec.sz, __uint_as_float(rec.cell));
+        s_t[lane * (2 * PREP_SLOTS + 1) + 2u * w + 1u] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.flags));
         s_b[lane * (PREP_SLOTS + 1) + w] = bin;                  // key of the bucket sort; 0xffffffff for padding slots
         __syncthreads();
-        if (rays4) {
 #pragma unroll
-            for (uint32_t r = 0; r < 2u; ++r) {
-                const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
-                if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
-            }
+        for (uint32_t r = 0; r < 2u; ++r) {
+            const uint32_t idx = threadIdx.x + r * 64u * PREP_SLOTS, el = idx / (2u * PREP_SLOTS), q = idx % (2u * PREP_SLOTS);
+            if (e0 + el < a.E) rays4[((size_t)(e0 + el) * a.R8 + slot0) * 2u + q] = s_t[el * (2 * PREP_SLOTS + 1) + q];
         }
         {       // (four groups' keys gathered in LDS and written as whole 128-byte lines: 45 KB of LDS, three blocks per CU, +2.6 us)
             const uint32_t el = threadIdx.x / PREP_SLOTS, q = threadIdx.x % PREP_SLOTS;
             if (a.bin_out && e0 + el < a.E) a.bin_out[(size_t)(e0 + el) * a.R8 + slot0 + q] = s_b[el * (PREP_SLOTS + 1) + q];
         }
     }
+#undef PREP_POSE_F64
     if (a.hist) {
         __syncthreads();
         uint32_t* const row = a.hist + (size_t)(blockIdx.x / a.hist_blocks_per_tile) * a.hist_buckets;
@@ -1584,9 +1620,9 @@ hipError_t launch_repack(const int32_t* map_idx, const int32_t* tris, const uint
 }
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
-    // 64 envs x a range of slot groups per block: as many groups as still leave ~1 024 blocks (the pose work is per block; 65 536 envs x
-    // 64 slots: 31.1 us with 1 024 or 2 048 blocks, 36.9 when every block of 8 slots rebuilt the pose; 4 096 envs: one group per block)
-    const uint32_t target = (a.hist && a.hist_buckets > 576u) ? 2048u : 1024u;        // (more than 576 buckets: three blocks per CU, not four)
+    // 64 envs x a range of slot groups per block: as many groups as still leave ~1 024 blocks (the pose work is per block; with the
+    // fused histogram's LDS above 40 KB — more than 576 buckets — three blocks fit a CU, not four: 2 048 blocks then)
+    const uint32_t target = (a.hist && a.hist_buckets > 576u) ? 2048u : 1024u;
     const uint32_t xb = blocks_for(a.E, 64), n_groups = a.R8 / PREP_SLOTS;                // (R8 is a multiple of 8)
     const uint32_t yb = max(1u, min(n_groups, (target + xb - 1u) / xb)), gpb = (n_groups + yb - 1u) / yb;
     hipLaunchKernelGGL(prep_rays_kernel, dim3(xb, (n_groups + gpb - 1u) / gpb), dim3(64 * PREP_SLOTS), a.hist ? a.hist_buckets * 4u : 0u, s, a, gpb);
@@ -1612,6 +1648,10 @@ static inline uint32_t bin_tile_threads(uint32_t n_slots, uint32_t low_bits, boo
     return big ? (packed ? 1024u : 512u) : 256u;                                  // (two-dword entries: 12 bytes of LDS per slot, 8 192 slots)
 }
 
+// The sort's first pass — keys per (tile, coarse bucket) — can run inside prep_rays_kernel when the keys of one of its 64-env blocks lie
+// in ONE tile (the tile is a multiple of 64 x R8 slots: R8 = 64 with the default 37 + 26 rays); the blocks of a tile add their LDS
+// histograms to the tile's row, which therefore has to be zero when the step starts: bucket_sort_kernel, the sort's last pass, clears
+// the table again.  One launch less per step (6.1 us at 65 536 envs, 4.7 at 4 096); other ray counts keep bucket_hist_kernel.
 bool bin_hist_fused(uint32_t n_slots, uint32_t R8, uint32_t n_bins, uint32_t low_bits, uint32_t* blocks_per_tile) {
     const uint32_t n_buckets = (n_bins + (1u << low_bits) - 1u) >> low_bits;
     const uint32_t tile = bin_tile_threads(n_slots, low_bits, nullptr) * BKT_ITEMS, keys = 64u * R8;      // keys of a prep_rays block's 64 envs
