@@ -11,11 +11,12 @@
 // evaluation order, so that given identical rays the ray kernel agrees bit for bit with the CPU oracle and
 // differs from the reference's fp32 mode only through sin/cos/atan2/asin ulps.
 //
-// Kernels (one fused step = the eight launches marked *; the ray cast of full batches is rover_cull.hip's):
+// Kernels (one fused step = the launches marked * — seven with the default 37 + 26 rays, where prep_rays_kernel counts the
+// sort's coarse buckets itself and bucket_hist_kernel is not launched; the ray cast of full batches is rover_cull.hip's):
 //   repack_knn_kernel        init: (map_idx, tris, verts) -> per-cell contiguous fp16 block [cell][9][K8], near/far halves per lane
-// * prep_rays_kernel         1 thread / (env, ray slot): quat -> euler, heading and the pose's sin/cos per block of 64 envs, then ray
-//                            origin, unit direction, cell id, bin key                                              (A2, A4, A6)
-// * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell) without global atomics (4 launches)
+// * prep_rays_kernel         64 envs x a range of ray slots per block: quat -> euler, heading, the pose's and the wheels' sin/cos and the
+//                            direction per ray kind once per block, then per slot origin, cell id, bin key [+ the sort's first pass] (A2, A4, A6)
+// * bucket_hist / rowscan / scatter / sort   bucket sort of the ray slots by (map, cell), LDS atomics only (3 - 4 launches)
 // * cull_scan_kernel         (rover_cull.hip) the culled ray cast: 1 wave / run of sorted rays                      (A4, A5) <- roofline kernel
 //   raycast_binned_kernel    variant 2: 1 wave / run of sorted rays, 4 triangles per lane in registers, every triangle evaluated,
 //                            conservative early out (round 1's roofline kernel; the bit-for-bit reference of the culled one)
@@ -1101,8 +1102,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(uint32_t* __rest
     for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) cnt[base + i] = run; run += v[i]; }
 }
 
-// ---- bucket sort of the ray slots by bin = (map, cell), without global atomics ------------------------------------
-//   bucket_hist_kernel     per 4096-slot block: LDS histogram over the coarse buckets (bin >> low_bits) -> counts[bucket][block]
+// ---- bucket sort of the ray slots by bin = (map, cell), without returning global atomics ---------------------------
+// (the only global atomics are the few per (tile, bucket) of the histogram pass fused into prep_rays_kernel: bin_hist_fused)
+//   bucket_hist_kernel     per 4096-slot block: LDS histogram over the coarse buckets (bin >> low_bits) -> counts[block][bucket]
+//                          (or prep_rays_kernel itself: bin_hist_fused)
 //   bucket_rowscan_kernel  one workgroup per bucket: exclusive prefix along its row of block counts + the bucket total
 //                          (the scan over the bucket totals is redone by every scatter block in LDS: <= 4096 values)
 //   bucket_scatter_kernel  same blocks: (bin, slot) pairs to their bucket range, position from an LDS cursor per bucket
