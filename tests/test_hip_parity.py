@@ -456,6 +456,37 @@ def _ray_sort_layouts(n):
                 np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} variant={variant} bin_low_bits={low_bits}")
 
 
+def test_fused_sort_histogram_survives_option_and_shape_changes():
+    """With 37 + 26 rays prep_rays_kernel counts the sort's coarse buckets itself into a table that has to be all zero when a step starts
+    (bucket_sort_kernel clears it again; bin_hist_fused, rover_kernels.hip).  One engine through everything that changes the table's
+    layout or who fills it — other poses every step, the sorted variants and the env-order one in turn, bin_low_bits 12 / 8 / default
+    (other bucket counts in the same allocation), a ray set that keeps bucket_hist_kernel (120 + 26: R8 = 152) and back — against a fresh
+    env-order engine each time."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 4096
+    scene = synth.make_scene(n_cells=96, k=24, n_stones=12)
+    sparse, dense = synth.ray_distribution("37"), synth.ray_distribution("120")
+    eng = make_engine(scene, sparse, n, variant=3)
+    script = [("variant", 3), ("variant", 3), ("variant", 2), ("bin_low_bits", 12), ("variant", 1), ("variant", 3), ("bin_low_bits", 8),
+              ("dist", dense), ("variant", 2), ("dist", sparse), ("bin_low_bits", 0), ("variant", 3)]
+    cur = sparse
+    for i, (what, val) in enumerate(script):
+        if what == "dist":
+            eng.set_distribution(*val)
+            cur = val
+        else:
+            eng.set_option("raycast_variant" if what == "variant" else what, val)
+        st = synth.make_states(n, 9.6, seed=100 + i)
+        got = hip_step(eng, st)
+        ref = make_engine(scene, cur, n, variant=1)
+        want = hip_step(ref, st)
+        ref.close()
+        for key in want:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} after step {i}: {what}")
+    eng.close()
+
+
 def test_rays_that_clear_their_cell_are_not_scanned():
     """On a regular mesh the scan kernels do not scan rays that provably clear BOTH halves of their cell's triangles — most rock
     rays — and drop bins without a live ray (on an irregular mesh the eager kernel scans everything: test_culled_raycast_changes_no_bit_on_
