@@ -70,7 +70,7 @@ struct rover_ctx {
     uint32_t* d_bins = nullptr;         // [E*R8] bin key per slot
     uint32_t* d_bkt_table = nullptr;    // [n_buckets * n_blocks] counts -> offsets
     size_t bkt_table_bytes = 0;
-    bool bkt_table_dirty = true;        // not known to be all zero (what prep_rays_kernel's fused histogram starts from)
+    bool bkt_table_dirty = true;        // not known to be all zero (what prep_rays_kernel's fused histogram starts from): a step failed half way
     uint2* d_pairs = nullptr;           // [E*R8] (bin, slot) after the coarse partition
     uint32_t low_bits = 10;             // bins per sort bucket = 2^low_bits, in force (alloc_bins)
     uint32_t low_bits_opt = 0;          // option "bin_low_bits": 0 = chosen by the library, else 8..12
@@ -233,7 +233,10 @@ static int alloc_bins(rover_ctx* c) {
         const uint64_t n_blocks = ((uint64_t)c->cfg.num_envs * c->R8 + 4095) / 4096;
         c->bkt_table_bytes = ((uint64_t)bucket_count(c) * n_blocks + 1) * sizeof(uint32_t);
         HIP_TRY(c, hipMalloc((void**)&c->d_bkt_table, c->bkt_table_bytes));
-        c->bkt_table_dirty = true;
+        // zero from the start, here and not in the first step: a first step that is only CAPTURED (hipGraph) would record the clearing
+        // without running it, and an eager step after it would count into whatever the allocation held
+        HIP_TRY(c, hipMemset(c->d_bkt_table, 0, c->bkt_table_bytes));
+        c->bkt_table_dirty = false;
         c->bins_ok = true;
     }
     return alloc_cull_queue(c);       // sized here, not in the step: hipMalloc is not allowed while a stream is capturing

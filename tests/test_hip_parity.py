@@ -487,6 +487,55 @@ def test_fused_sort_histogram_survives_option_and_shape_changes():
     eng.close()
 
 
+def test_step_captured_in_a_graph_first_then_eager_and_replayed():
+    """The fused sort histogram needs its count table zero at the start of every step and leaves it zero (bucket_sort_kernel).  A step
+    that is only CAPTURED (torch.cuda.graph = hipGraph) on a fresh engine runs nothing: the eager step after it, the replays after that
+    and another eager step must all see a zero table — each compared with a fresh env-order engine on the same poses."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 4096
+    scene = synth.make_scene(n_cells=96, k=24, n_stones=12)
+    distn = synth.ray_distribution("37")
+    dev = torch.device("cuda:0")
+    eng = make_engine(scene, distn, n, variant=3)
+    states = [synth.make_states(n, 9.6, seed=200 + i) for i in range(4)]
+    keys = ("pos", "quat", "joints", "target", "lin_hist", "ang_hist", "euler_pre")
+    stat = {k: states[0][k].to(dev).contiguous().clone() for k in keys}
+    progress = states[0]["progress"].to(dev).clone()
+    sin = eng.make_in(*(stat[k] for k in keys), progress)
+    obs = torch.zeros(n, eng.num_observations, device=dev)
+    bufs = dict(rew=torch.zeros(n, device=dev), reset=torch.ones(n, dtype=torch.int64, device=dev),
+                rock_collision=torch.zeros(n, dtype=torch.int64, device=dev),
+                reset_ids=torch.full((n,), -1, dtype=torch.int64, device=dev), n_reset=torch.zeros(1, dtype=torch.int32, device=dev),
+                ray_dist=torch.zeros(n, eng.P, device=dev), wheel_dist=torch.zeros(n, 24, device=dev), body_dist=torch.zeros(n, 2, device=dev))
+    sout = eng.make_out(obs, **bufs)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):                                       # captured, not run
+        eng.step(sin, sout, increment_progress=False, compact=True)
+
+    def check(i, how):
+        torch.cuda.synchronize()
+        ref = make_engine(scene, distn, n, variant=1)
+        want = hip_step(ref, states[i])
+        ref.close()
+        np.testing.assert_array_equal(obs.cpu().numpy(), want["obs_buf"], err_msg=f"obs, {how}")
+        np.testing.assert_array_equal(bufs["ray_dist"].cpu().numpy(), want["ray_dist"], err_msg=f"ray_dist, {how}")
+        np.testing.assert_array_equal(bufs["wheel_dist"].cpu().numpy(), want["wheel_dist"], err_msg=f"wheel_dist, {how}")
+        np.testing.assert_array_equal(bufs["rock_collision"].cpu().numpy(), want["rock_collision"], err_msg=f"rock_collision, {how}")
+
+    def load(i):
+        for k in keys:
+            stat[k].copy_(states[i][k].to(dev))
+        progress.copy_(states[i]["progress"].to(dev))
+
+    load(0); eng.step(sin, sout, increment_progress=False, compact=True); check(0, "eager step after a capture")
+    load(1); g.replay(); check(1, "first replay")
+    load(2); g.replay(); check(2, "second replay")
+    load(3); eng.step(sin, sout, increment_progress=False, compact=True); check(3, "eager step after the replays")
+    eng.close()
+
+
 def test_rays_that_clear_their_cell_are_not_scanned():
     """On a regular mesh the scan kernels do not scan rays that provably clear BOTH halves of their cell's triangles — most rock
     rays — and drop bins without a live ray (on an irregular mesh the eager kernel scans everything: test_culled_raycast_changes_no_bit_on_
