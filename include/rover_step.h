@@ -154,6 +154,15 @@ ROVER_API int rover_is_done(rover_ctx *ctx, const rover_step_in *in, const rover
  * ctx (heading, euler of the last rover_get_observations) is left untouched. */
 ROVER_API int rover_get_depths(rover_ctx *ctx, const float *positions, const float *rotations_euler, float *distances,
                                float *points, float *sources, void *stream);
+/* Rock_Detection.get_collisions(positions, rotations, joint_states) rock_detect.py:52-149 as its own call (the task holds
+ * self.Rock_detector and calls it at rover.py:291): positions [E,3], rotations [E,3] EULER angles (self.rover_rotation), joints [E,13]
+ * (RoverView.get_joint_positions; NULL = all zero) -> wheel_dist [E,24], body_dist [E,2] (each optional), the reference's
+ * (output_distances[:, 0:24], output_distances[:, 24:]).  Same ray pipeline and options as the step.
+ * rover_get_depths and rover_get_collisions overwrite the ctx's ray workspace (ray records, sorted list, distances, cull counters:
+ * what rover_replay_raycast / rover_get_cull_info / the profile describe afterwards is THIS call's rays); they leave the observation
+ * state (euler, heading) alone and do not stand in for rover_get_observations: rover_calculate_metrics still requires that one. */
+ROVER_API int rover_get_collisions(rover_ctx *ctx, const float *positions, const float *rotations_euler, const float *joints,
+                                   float *wheel_dist, float *body_dist, void *stream);
 /* reset_buf.nonzero() rover.py:356 without the host sync: ids ascending (+env_offset), count to n_reset[0] */
 ROVER_API int rover_compact_resets(rover_ctx *ctx, const int64_t *reset, int64_t *reset_ids, int32_t *n_reset, void *stream);
 /* tensor_quat_to_eul tasks/utils/math/tensor_quat_to_euler.py:6-31 */

@@ -101,6 +101,7 @@ SYMBOLS = {
     "rover_is_done": (C.c_int, [_P, C.POINTER(StepIn), C.POINTER(StepOut), _P]),
     "rover_compact_resets": (C.c_int, [_P, _P, _P, _P, _P]),
     "rover_get_depths": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rover_get_collisions": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "rover_quat_to_euler": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "rover_clearance": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rover_shift_spawns": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
@@ -371,6 +372,20 @@ class Engine:
         self._check(self.lib.rover_get_depths(self._h, _ptr(positions), _ptr(rotations), _ptr(dist), _ptr(pts), _ptr(src), _stream()),
                     "rover_get_depths")
         return dist, pts, src
+
+    def get_collisions(self, positions, rotations, joints=None):
+        """Rock_Detection.get_collisions (rock_detect.py:52-149): positions [E,3], rotations [E,3] euler angles, joints [E,13] (None =
+        zero) -> (wheel_dist [E,24], body_dist [E,2])."""
+        e, f = self.num_envs, torch.float32
+        self._chk(positions, (e, 3), f, "positions")
+        self._chk(rotations, (e, 3), f, "rotations")
+        if joints is not None:
+            self._chk(joints, (e, 13), f, "joints")
+        wheel = torch.empty(e, 24, device=positions.device)
+        body = torch.empty(e, 2, device=positions.device)
+        self._check(self.lib.rover_get_collisions(self._h, _ptr(positions), _ptr(rotations), _ptr(joints), _ptr(wheel), _ptr(body),
+                                                  _stream()), "rover_get_collisions")
+        return wheel, body
 
     def compact_resets(self, reset, reset_ids, n_reset):
         self._chk(reset, (self.num_envs,), torch.int64, "reset")

@@ -90,7 +90,8 @@ struct rover_ctx {
     size_t mlp_scratch_floats = 0;
     uint64_t workspace_bytes = 0;
     bool ws_ok = false, bins_ok = false;   // false after a failed (re)allocation: the step entry points refuse to run
-    bool rays_valid = false;
+    bool rays_valid = false;            // the ray workspace holds a finished ray cast (rover_replay_raycast)
+    bool obs_valid = false;             // ... and euler / heading hold the state of a rover_get_observations (rover_calculate_metrics reads them)
     // in-situ ray-cast timing (rover_set_profiling)
     bool profiling = false;
     int32_t prof_every = 1;             // time every prof_every-th ray-cast launch (an event pair costs ~12 us of stream time)
@@ -287,6 +288,7 @@ static int alloc_workspace(rover_ctx* c) {
     HIP_TRY(c, hipMemset(c->d_heading, 0, E * sizeof(float)));
     c->workspace_bytes = n * (sizeof(RayRec) + sizeof(float) + 2 * sizeof(uint32_t) + sizeof(uint2)) + E * (4 * sizeof(float) + sizeof(int64_t));
     c->rays_valid = false;
+    c->obs_valid = false;
     c->ws_ok = true;
     return alloc_bins(c);
 }
@@ -752,7 +754,8 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     if (variant >= 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
                                    c->d_block_sums, c->d_sorted, hist_fused, s));
-    c->bkt_table_dirty = false;
+    // fused histogram: bucket_sort_kernel has cleared the table again; otherwise the table (if the sort ran) holds this step's offsets
+    if (variant >= 2) c->bkt_table_dirty = !hist_fused;        // (variant 1 does not touch the table)
     const bool timed = c->profiling && (c->prof_seen++ % c->prof_every) == 0;
     if (timed) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
@@ -785,6 +788,7 @@ static int do_observations(rover_ctx* c, const rover_step_in* in, const rover_st
     const int64_t stride = out->obs_stride ? out->obs_stride : (int64_t)W;
     if (stride < (int64_t)W) return fail(c, ROVER_E_INVALID, "obs_stride %lld < row width %u", (long long)stride, W);
     if (int r = cast_rays(c, in->pos, in->quat, in->joints, in->target, nullptr, s)) return r;
+    c->obs_valid = true;
     ObsArgs o{};
     o.E = E; o.W = W; o.R8 = c->R8; o.obs_stride = stride;
     o.pos = in->pos; o.target = in->target; o.heading = c->d_heading; o.lin_hist = in->lin_hist; o.ang_hist = in->ang_hist;
@@ -856,7 +860,7 @@ int rover_calculate_metrics(rover_ctx* c, const rover_step_in* in, const rover_s
     if (!c) return ROVER_E_INVALID;
     if (!in || !out) return fail(c, ROVER_E_INVALID, "calculate_metrics: null struct");
     if (int r = check_ready(c)) return r;
-    if (!c->rays_valid) return fail(c, ROVER_E_STATE, "calculate_metrics: call rover_get_observations first (rover.py:479 reads self.heading_diff)");
+    if (!c->obs_valid) return fail(c, ROVER_E_STATE, "calculate_metrics: call rover_get_observations first (rover.py:479 reads self.heading_diff)");
     USE_DEVICE(c);
     return do_metrics(c, in, out, 0, 0, 1, 0, (hipStream_t)stream);
 }
@@ -880,6 +884,20 @@ int rover_get_depths(rover_ctx* c, const float* positions, const float* rotation
     if (distances || points || sources)
         HIP_TRY(c, launch_export_dist(c->d_dist_out, c->d_rays, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, c->precision, distances,
                                       nullptr, nullptr, sources, points, s));
+    return ROVER_OK;
+}
+
+int rover_get_collisions(rover_ctx* c, const float* positions, const float* rotations_euler, const float* joints, float* wheel_dist,
+                         float* body_dist, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!positions || !rotations_euler) return fail(c, ROVER_E_INVALID, "get_collisions: positions and rotations are required");
+    if (int r = check_ready(c)) return r;
+    USE_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if (int r = cast_rays(c, positions, nullptr, joints, nullptr, rotations_euler, s)) return r;
+    if (wheel_dist || body_dist)
+        HIP_TRY(c, launch_export_dist(c->d_dist_out, c->d_rays, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, c->precision, nullptr,
+                                      wheel_dist, body_dist, nullptr, nullptr, s));
     return ROVER_OK;
 }
 

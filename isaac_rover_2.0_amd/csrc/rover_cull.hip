@@ -486,7 +486,11 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
         const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
         const RawTri* rt = map ? rtab1 : rtab0;
         const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
+#ifdef ROVER_SEQ_RAYS
+        const uint32_t g = gid + pos;                                   // (gid: the run's first sorted position, wave-uniform)
+#else
         const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
+#endif
         const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
         if (base + 64u < n) en_next = entry(min(base + 64u + lane, n - 1u));
@@ -586,7 +590,13 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 // LAZY: the far pairs of a bin (slot 1) are gathered and unpacked only if one of its rays tests them — a second, dependent round of
 // gathers in the bins that do, half the set-up in the bins that do not (most of them when a bin holds few rays).
 template <int H, int LAZY, int SKIPT>
-__global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS) {
+#ifndef ROVER_CULL_WAVES
+#define ROVER_CULL_WAVES 6
+#endif
+#ifndef ROVER_CULL_LCAP_LAZY
+#define ROVER_CULL_LCAP_LAZY 512u
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float k_ca = H ? c_a_h : CullK<0>::c_a, k_tau2 = H ? tau2_h : CullK<0>::tau2;      // (f32 proof: compile-time constants)
     // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
     // exposed memory latency per run instead of one per bin); s_bk: the run's 64 running minima as ordered-u32 keys.
@@ -596,10 +606,16 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // them back without a round trip through memory, and phase 1 does not wait for the acknowledgement of 8-byte stores scattered over
     // 120 MB.  What does not fit goes to the wave's global region as before.  (Sized so that the LDS never caps the waves the registers
     // allow: 6 per SIMD x 4.25 + 4 KB, 7 x 4.25 + 3 KB.)
-    constexpr uint32_t LCAP = LAZY ? 512u : 384u;
+    constexpr uint32_t LCAP = LAZY ? ROVER_CULL_LCAP_LAZY : 384u;
     static_assert(CULL_QCAP - LCAP <= CULL_QGLOBAL, "the global region holds what the LDS part does not");
     __shared__ uint2 s_lq[CULL_WPB][LCAP];
-    const uint32_t x = blockIdx.x & 7u, tw = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = blockIdx.x & 7u, tw =
+#ifdef ROVER_DIAG_TW_OLD
+        threadIdx.x >> 6,
+#else
+        CULL_WPB == 1 ? 0u : threadIdx.x >> 6,
+#endif
+        lane = threadIdx.x & 63u;      // (one wave per workgroup: tw is a constant, and what derives from it — the queue region's address — is wave-uniform for the compiler too)
     // this wave: wave w (0..3) of block slot jslot of XCD x
     const uint32_t qx = blockIdx.x >> 3, w = (qx % (4u / CULL_WPB)) * CULL_WPB + tw, jslot = qx / (4u / CULL_WPB);
     uint32_t* const bk = s_bk[tw];
@@ -653,7 +669,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // id rows ahead.
     // (through an opaque copy of the ray id: everything below is invariant across segments, and hoisted out of this loop by the
     //  compiler it would stay in registers through the scan AND the exact phase — 76 VGPRs instead of 62)
+#ifdef ROVER_SEQ_RAYS
+    uint32_t gid_s = i0 + (lane < n_run ? lane : n_run - 1u);
+#else
     uint32_t gid_s = gid;
+#endif
     asm volatile("" : "+v"(gid_s));
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid_s)[0], rsb = reinterpret_cast<const float4*>(rays + gid_s)[1];
     const uint32_t rflags = __float_as_uint(rsb.w);
@@ -718,7 +738,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
             const uint64_t above = live & (~1ull << lane);                 // (per lane)
             nxt = above ? (uint32_t)__builtin_ctzll(above) : lane;
         }
+#ifdef ROVER_SEQ_RAYS
+        const uint32_t gnx = i0 + nxt;
+#else
         const uint32_t gnx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)gid);
+#endif
         nxw = (gnx & 0x3fffffffu) | ((uint32_t)((conemask >> lane) & 1ull) << 31) | ((uint32_t)((farskip >> lane) & 1ull) << 30);
     }
     const uint64_t hm_all = (heads | (1ull << r_next)) & (~0ull << r_next);
@@ -749,12 +773,19 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
         if (pf_heads) prefetch_row();
     uint32_t cused = 0;
     auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
+#ifdef ROVER_SEQ_RAYS
+        const float4* rp = reinterpret_cast<const float4*>(rays + (i0 + r));
+#else
         const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
+#endif
         a4 = rp[0]; b4 = rp[1];
     };
     float4 nxa, nxb;
     load_ray(live ? (uint32_t)__builtin_ctzll(live) : r_next, nxa, nxb);       // the segment's first live ray
     bool full = false;
+#ifdef ROVER_DIAG_NOSCAN
+    hm = 0;
+#endif
     while (hm && !full) {                      // one (map, cell) bin of the run: rays [i, i_end)
         const uint32_t i = (uint32_t)__builtin_ctzll(hm);
         hm &= hm - 1ull;
@@ -885,11 +916,19 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
     // The wait also retires id-row loads of bins this segment did not reach (the ring restarts with the next segment).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
+#ifdef ROVER_SEQ_RAYS
+    cull_exact<H>(rays, rtab0, rtab1, lq, LCAP, qw, cused, i0, lane, bk);
+#else
     cull_exact<H>(rays, rtab0, rtab1, lq, LCAP, qw, cused, gid, lane, bk);
+#endif
     ctot += cused;
     }
     wave_lds_sync();
+#ifdef ROVER_DIAG_SEQ_OUT
+    if (lane < n_run) out[i0 + lane] = funkey(bk[lane]) + __uint_as_float(gid & 1u);
+#else
     if (lane < n_run) out[gid] = funkey(bk[lane]);
+#endif
     // per-wave counters of THIS launch (plain stores, 16 B per wave; summed on the host by rover_get_cull_info)
     if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins);
     }
@@ -981,8 +1020,25 @@ static uint32_t cull_slots_per_launch(uint64_t entries) {
     return (uint32_t)(s < 1 ? 1 : (s > 0x7fffffffull ? 0x7fffffffull : s));
 }
 
+#ifdef ROVER_SEQ_RAYS
+__global__ void __launch_bounds__(256) diag_gather_rays_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted, uint32_t n,
+                                                               RayRec* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4* rp = reinterpret_cast<const float4*>(rays + sorted[i]);
+    const float4 a = rp[0], b = rp[1];
+    float4* o = reinterpret_cast<float4*>(out + i);
+    o[0] = a; o[1] = b;
+}
+#endif
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const CullGrid g = cull_grid(a.n_sorted, a.n_terrain, a.run);
+#ifdef ROVER_SEQ_RAYS
+    static RayRec* d_seq = nullptr; static uint32_t seq_n = 0;
+    if (seq_n < a.n_sorted) { if (d_seq) (void)hipFree(d_seq); (void)hipMalloc((void**)&d_seq, (size_t)a.n_sorted * sizeof(RayRec)); seq_n = a.n_sorted; }
+    hipLaunchKernelGGL(diag_gather_rays_kernel, dim3(blocks_for(a.n_sorted, 256)), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted, d_seq);
+    a.rays = d_seq;
+#endif
     const uint32_t slots = g.t8 + g.r8;                              // block slots per XCD
     const uint32_t per = cull_slots_per_launch(a.queue_entries);
     // one launch, unless the queue regions of all slots exceed the budget the queue was sized for (huge batches): then slices

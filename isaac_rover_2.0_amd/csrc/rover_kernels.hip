@@ -113,6 +113,23 @@ __device__ __forceinline__ uint32_t cell_coord(float v, float shift, float cell,
     return (uint32_t)s;
 }
 
+// The ray's normal-cone bound for the culled ray cast (rover_cull.hip), a 16-bit fraction rounded up, 0xffff = none; (dx, dy, dz) = the
+// ray record's direction.  f32 proof: a cell whose triangles all have |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole.
+// As-shipped fp16 arithmetic (precision 2): (B)'s threshold is per triangle, the cell stores the largest angle from the vertical a ray
+// may have (as a fraction of pi / 2) and the ray its angle beta (d is normalised in fp16 there: re-normalised here).
+__device__ __forceinline__ uint32_t ray_cone_bound(float dx, float dy, float dz, int precision) {
+    uint32_t qq = 0xffffu;
+    if (precision == 2) {
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        const float beta = acosf(fminf(1.0f, fabsf(dz) * inv)) * 0.63661977f + 4.0e-5f;      // / (pi / 2), rounded up
+        if (beta < 0.9999f) qq = (uint32_t)ceilf(beta * 65535.0f);                            // NaN -> 0xffff
+    } else {
+        const float qm = 3.5e-3f * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
+        if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                // NaN -> 0xffff
+    }
+    return qq;
+}
+
 // -(F.normalize(dir)), ray_casting.py:31
 __device__ __forceinline__ void neg_normalize(float dx, float dy, float dz, float& ox, float& oy, float& oz) {
     float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -288,19 +305,7 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
         } else {
             neg_normalize(ux, uy, uz, dx, dy, dz);
         }
-        // the ray's normal-cone bound for the culled ray cast (rover_cull.hip), a 16-bit fraction rounded up, 0xffff = none.
-        // f32 proof: a cell whose triangles all have |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole.
-        // As-shipped fp16 arithmetic: (B)'s threshold is per triangle, the cell stores the largest angle from the vertical a ray
-        // may have (as a fraction of pi / 2) and the ray its angle beta (d is normalised in fp16 there: re-normalised here).
-        uint32_t qq = 0xffffu;
-        if (a.precision == 2) {
-            const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-            const float beta = acosf(fminf(1.0f, fabsf(dz) * inv)) * 0.63661977f + 4.0e-5f;      // / (pi / 2), rounded up
-            if (beta < 0.9999f) qq = (uint32_t)ceilf(beta * 65535.0f);                            // NaN -> 0xffff
-        } else {
-            const float qm = 3.5e-3f * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
-            if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                // NaN -> 0xffff
-        }
+        const uint32_t qq = ray_cone_bound(dx, dy, dz, a.precision);
         s_dir[w][lane] = make_float4(dx, dy, dz, __uint_as_float(fl | (qq << 16)));
     }
     // The group's 64 x 8 records and bin keys, env-major through LDS (rows of 17 float4 / 9 dwords: a wave's 64 rows spread over the banks):
@@ -532,6 +537,49 @@ __global__ void __launch_bounds__(256) export_dist_kernel(const float* __restric
             }
         }
     }
+}
+
+// The ray records of the last cast in slot order (24 wheel, 2 body, P heightmap rays per env): origin, the record's direction
+// (-normalize(direction), ray_casting.py:31), cell id, distance — what a test feeds to the oracle's per-ray arithmetic.
+__global__ void __launch_bounds__(256) export_rays_kernel(const RayRec* __restrict__ rays, const float* __restrict__ dist, uint32_t E, uint32_t R8,
+                                                          uint32_t n_real, float* __restrict__ src, float* __restrict__ dir,
+                                                          int32_t* __restrict__ cell, float* __restrict__ out_dist) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)E * n_real) return;
+    const uint32_t e = (uint32_t)(i / n_real), sl = (uint32_t)(i % n_real);
+    const RayRec r = rays[(uint64_t)e * R8 + sl];
+    if (src) { src[3 * i] = r.sx; src[3 * i + 1] = r.sy; src[3 * i + 2] = r.sz; }
+    if (dir) { dir[3 * i] = r.dx; dir[3 * i + 1] = r.dy; dir[3 * i + 2] = r.dz; }
+    if (cell) cell[i] = (int32_t)r.cell;
+    if (out_dist) out_dist[i] = dist[(uint64_t)e * R8 + sl];
+}
+
+// Caller-supplied rays into the step's workspace (rover_cast_rays): origin and record direction as given, cell id, map flag, cone bound
+// and bin key as prep_rays_kernel derives them from an origin / a direction (camera.py:233-264 for the cell).
+__global__ void __launch_bounds__(256) import_rays_kernel(const float* __restrict__ src, const float* __restrict__ dir, uint32_t E, uint32_t R8,
+                                                          uint32_t n_real, KnnDev terrain, KnnDev rocks, uint32_t rocks_bin_offset,
+                                                          int precision, int cell_rcp, RayRec* __restrict__ rays, uint32_t* __restrict__ bin_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)E * R8) return;
+    const uint32_t e = (uint32_t)(i / R8), sl = (uint32_t)(i % R8);
+    RayRec rec;
+    rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
+    uint32_t bin = 0xffffffffu;
+    if (sl < n_real) {
+        const uint64_t o = 3ull * ((uint64_t)e * n_real + sl);
+        const bool rk = sl < 26u;
+        const KnnDev& m = rk ? rocks : terrain;
+        rec.sx = src[o]; rec.sy = src[o + 1]; rec.sz = src[o + 2];
+        rec.dx = dir[o]; rec.dy = dir[o + 1]; rec.dz = dir[o + 2];
+        const uint32_t ix = cell_coord(rec.sx, m.shift_x, m.cell, m.inv_cell, cell_rcp, m.X);
+        uint32_t iy = cell_coord(rec.sy, m.shift_y, m.cell, m.inv_cell, cell_rcp, m.X);
+        if (iy > (uint32_t)(m.Y - 1)) iy = (uint32_t)(m.Y - 1);
+        rec.cell = ix * (uint32_t)m.Y + iy;
+        rec.flags = (rk ? 3u : 2u) | (ray_cone_bound(rec.dx, rec.dy, rec.dz, precision) << 16);
+        bin = (rk ? rocks_bin_offset : 0u) + rec.cell;
+    }
+    rays[i] = rec;
+    if (bin_out) bin_out[i] = bin;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1769,6 +1817,20 @@ hipError_t launch_export_dist(const float* dist, const RayRec* rays, uint32_t E,
                               float* wheel, float* body, float* ray_src, float* hit_pt, hipStream_t s) {
     hipLaunchKernelGGL(export_dist_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, dist, rays, E, R8, P, precision,
                        ray_dist, wheel, body, ray_src, hit_pt);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_rays(const RayRec* rays, const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* src, float* dir, int32_t* cell,
+                              float* out_dist, hipStream_t s) {
+    hipLaunchKernelGGL(export_rays_kernel, dim3(blocks_for((uint64_t)E * (26u + P), 256)), dim3(256), 0, s, rays, dist, E, R8, 26u + P, src, dir,
+                       cell, out_dist);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_rays(const float* src, const float* dir, uint32_t E, uint32_t R8, uint32_t P, const KnnDev& terrain, const KnnDev& rocks,
+                              uint32_t rocks_bin_offset, int precision, int cell_rcp, RayRec* rays, uint32_t* bin_out, hipStream_t s) {
+    hipLaunchKernelGGL(import_rays_kernel, dim3(blocks_for((uint64_t)E * R8, 256)), dim3(256), 0, s, src, dir, E, R8, 26u + P, terrain, rocks,
+                       rocks_bin_offset, precision, cell_rcp, rays, bin_out);
     return hipGetLastError();
 }
 

@@ -70,6 +70,21 @@ class _Camera:
         return self._engine.get_depths(positions.float().contiguous(), rotations.float().contiguous())
 
 
+class _RockDetector:
+    """What the task reads from ``self.Rock_detector`` (``rover.py:94,291``): ``get_collisions`` on caller-supplied poses."""
+
+    def __init__(self):
+        self._engine = None
+
+    def get_collisions(self, positions, rotations, joint_states):
+        """rock_detect.py:52-149: rover positions [E,3], euler rotations [E,3], joint positions [E,13] -> (wheel distances [E,24],
+        body distances [E,2]) through ``rover_get_collisions`` (the step path casts these rays inside ``rover_step``)."""
+        if self._engine is None:
+            raise _lib.RoverError("Rock_detector.get_collisions: the detector is not bound to a task yet")
+        return self._engine.get_collisions(positions.float().contiguous(), rotations.float().contiguous(),
+                                           joint_states.float().contiguous())
+
+
 class RoverTask(RLTask):
     def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
                  device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0, stone_mask_margin=None,
@@ -99,6 +114,7 @@ class RoverTask(RLTask):
         self.shift = torch.tensor(list(scene.shift), device=self._device, dtype=torch.float32)   # :91
         hm = Heightmap(self._device) if distribution is None else Heightmap(self._device, *distribution)
         self.Camera = _Camera(hm)
+        self.Rock_detector = _RockDetector()                                              # :94
         self.num_exteroceptive = self.Camera.get_num_exteroceptive()
         self.global_step = 0
         # run seed (cfg/config.yaml `seed`): mixed into every library RNG draw, so that seed sweeps re-randomise the resets
@@ -138,6 +154,7 @@ class RoverTask(RLTask):
         self._engine.set_option("ray_precision", {"fp32": 0, "fp16_sources": 1, "fp16_as_shipped": 2}[ray_precision])
         self._engine.set_option("cell_index_mode", {"cpu_div": 0, "cuda_rcp": 1}[cell_index_mode])
         self.Camera._engine = self._engine
+        self.Rock_detector._engine = self._engine
         self._env_offset = int(env_offset)
 
         # persistent side-state the three methods hand to each other (:274-283, :343, :667)

@@ -86,6 +86,33 @@ def test_get_depths_argument_checks():
     eng.close()
 
 
+def test_get_collisions_argument_checks_and_state():
+    """rover_get_collisions: null poses / a bare ctx / wrong shapes are refused; NULL joints mean zero joints; and neither it nor
+    rover_get_depths stands in for rover_get_observations: rover_calculate_metrics on a ctx that only ran them is refused."""
+    from isaac_rover_amd import _lib
+    eng, scene = _engine(16)
+    lib, dev = eng.lib, eng.device
+    assert lib.rover_get_collisions(eng._h, None, None, None, None, None, None) == -1
+    assert b"positions and rotations" in lib.rover_last_error(eng._h)
+    with pytest.raises(_lib.RoverError, match="joints"):
+        eng.get_collisions(torch.zeros(16, 3, device=dev), torch.zeros(16, 3, device=dev), torch.zeros(16, 12, device=dev))
+    bare = _lib.Engine(16, device=0)
+    with pytest.raises(_lib.RoverError, match="maps must be set"):
+        bare.get_collisions(torch.zeros(16, 3, device=dev), torch.zeros(16, 3, device=dev))
+    bare.close()
+    pos = torch.zeros(16, 3, device=dev) + 1.5
+    w0, b0 = eng.get_collisions(pos, torch.zeros(16, 3, device=dev))
+    w1, b1 = eng.get_collisions(pos, torch.zeros(16, 3, device=dev), torch.zeros(16, 13, device=dev))
+    torch.cuda.synchronize()
+    assert torch.equal(w0, w1) and torch.equal(b0, b1) and w0.shape == (16, 24) and b0.shape == (16, 2)
+    # no observation yet on this ctx: the metrics must refuse (their heading state would be the memset's zeros)
+    eng.get_depths(pos, torch.zeros(16, 3, device=dev))
+    sin, sout = _lib.StepIn(), _lib.StepOut()
+    assert lib.rover_calculate_metrics(eng._h, C.byref(sin), C.byref(sout), None) == -2
+    assert b"rover_get_observations first" in lib.rover_last_error(eng._h)
+    eng.close()
+
+
 def test_c_level_argument_checks():
     from isaac_rover_amd import _lib
     eng, _ = _engine(16)

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import STEP_FIXTURES_AS_SHIPPED, STEP_FIXTURES_FP32, assert_step_close, load_golden, scene_for, states_of
+from conftest import (RAY_FLIP_BUDGET, STEP_FIXTURES_AS_SHIPPED, STEP_FIXTURES_FP32, TOL_RAY, assert_step_close, load_golden, scene_for,
+                      states_of)
 
 pytestmark = pytest.mark.gpu
 
@@ -941,6 +942,37 @@ def test_get_depths_returns_the_reference_triple(precision, tag):
                 np.testing.assert_allclose(gp[close], want_pt[close], rtol=0, atol=2.5e-3, err_msg=f"{label} points v{variant}")
         eng.close()
     assert (want_d < 11.0).mean() > 0.5 and (want_d == 11.0).any()          # hits and misses (k = 11: the point 11 m along the ray)
+
+
+@pytest.mark.parametrize("precision,name", [(0, "step_e64_p37_fp32"), (2, "step_e64_p37_fp16_as_shipped"),
+                                            (0, "step_irregular_p37_fp32"), (2, "step_irregular_p37_fp16_as_shipped")])
+def test_get_collisions_matches_the_reference(precision, name):
+    """Rock_Detection.get_collisions (rock_detect.py:52-149) as its own C-ABI call: `rover_get_collisions` on the reference's
+    (positions, euler rotations, joint positions) against the reference's own wheel / body distances of the same fixture (the
+    values its get_observations handed to check_collision, rover.py:291).  As shipped (fp16 tensors): bit for bit."""
+    from hip_helpers import make_engine
+    fx = load_golden(name)
+    scene = scene_for(fx)
+    distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
+    e = fx["in_pos"].shape[0]
+    for variant in (3, 2, 1) if precision == 0 else (3, 2):
+        eng = make_engine(scene, distn, e, variant=variant)
+        eng.set_option("ray_precision", precision)
+        dev = eng.device
+        wheel, body = eng.get_collisions(torch.from_numpy(fx["in_pos"]).to(dev), torch.from_numpy(fx["out_euler"]).to(dev),
+                                         torch.from_numpy(fx["in_joints"]).to(dev))
+        torch.cuda.synchronize()
+        wheel, body = wheel.cpu().numpy(), body.cpu().numpy()
+        assert wheel.shape == (e, 24) and body.shape == (e, 2)
+        if precision == 2:
+            np.testing.assert_array_equal(wheel, fx["out_wheel_dist"], err_msg=f"wheel v{variant}")
+            np.testing.assert_array_equal(body, fx["out_body_dist"], err_msg=f"body v{variant}")
+        else:
+            for got, want in ((wheel, fx["out_wheel_dist"]), (body, fx["out_body_dist"])):
+                d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+                assert float((d > TOL_RAY).mean()) <= RAY_FLIP_BUDGET, f"v{variant}: {(d > TOL_RAY).mean():.4%} of rays differ"
+        eng.close()
+    assert (fx["out_wheel_dist"] < 11.0).any()
 
 
 def test_quat_to_euler_and_ackermann():

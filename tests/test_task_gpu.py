@@ -72,6 +72,24 @@ def test_camera_get_depths_on_the_task():
     env.close()
 
 
+def test_rock_detector_get_collisions_on_the_task():
+    """The drop-in task's `self.Rock_detector.get_collisions(positions, rotations, joints)` (rock_detect.py:52, held at rover.py:94,
+    called at rover.py:291): the reference's (wheel_dist, body_dist) on the reference's own inputs; `check_collision` on them gives the
+    fixture's collision mask."""
+    fx = load_golden("step_e64_p37_fp32")
+    task, env = _make_task(fx, True)
+    dev = task.device
+    wheel, body = task.Rock_detector.get_collisions(torch.from_numpy(fx["in_pos"]).to(dev), torch.from_numpy(fx["out_euler"]).to(dev),
+                                                    torch.from_numpy(fx["in_joints"]).to(dev))
+    torch.cuda.synchronize()
+    for got, want in ((wheel, fx["out_wheel_dist"]), (body, fx["out_body_dist"])):
+        d = np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64))
+        assert float((d > 2e-3).mean()) <= 1e-3
+    task.check_collision(wheel, body)                                                           # rover.py:663-668
+    np.testing.assert_array_equal(task.rock_collison.cpu().numpy(), fx["out_rock_collision"])
+    env.close()
+
+
 def test_native_observation_layout():
     """1634 rays -> 1750-float observation = [4 | 634 sparse | 1112 dense] (learning/model.py:186-192)."""
     fx = load_golden("step_e8_native_fp32")
