@@ -371,7 +371,7 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     else:
         head = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": valu_obj["unit"], "frac": frac}
-    head.update({"kernel": {3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
+    head.update({"kernel": {4: "lane_scan_kernel", 3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "launches_timed_every": int(getattr(args, "event_every", 1)), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
                  "reuse_factor": (algo / traffic) if traffic else None,
@@ -457,7 +457,7 @@ def measure_also(args, device, local_rank, **override):
            "workload": f"{E} envs x ({a.rays} + 26) rays, K={a.k}, {a.cells}x{a.cells} cells, mesh={a.mesh}, ray_precision={a.ray_precision}, "
                        f"cell_index_mode={a.cell_index_mode}",
            "roofline": roofline(a, E, n_rays, prof, info, _lib_version())}
-    if info.raycast_variant == 3:
+    if info.raycast_variant >= 3:
         ci = eng.cull_info()
         out["cull"] = {"candidate_pairs_per_ray": ci["pairs_per_ray"], "rays_with_both_tests": ci["rays_both_tests"] / max(ci["rays"], 1),
                        "rays_far_skipped": ci["rays_far_skipped"] / max(ci["rays"], 1), "triangles": ci["triangles"]}
@@ -692,7 +692,7 @@ def run_rank(args):
             "lib": _lib_version(),
             "lib_built_from_tree": _lib_matches_tree(),      # false: the .so was built from other sources than the ones next to it
         }
-        if info.raycast_variant == 3:
+        if info.raycast_variant >= 3:
             ci = eng.cull_info()
             line["cull"] = {"candidate_pairs_per_ray": ci["pairs_per_ray"], "rays_with_both_tests": ci["rays_both_tests"] / max(ci["rays"], 1),
                             "rays_per_bin": ci["rays"] / max(ci["bins"], 1), "max_pairs_per_run": ci["max_pairs_per_run"],
@@ -701,6 +701,9 @@ def run_rank(args):
                             "always_candidate_triangles": ci["always_candidate_triangles"], "cells_without_cone": ci["cells_without_cone"],
                             "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"],
                             "cells_with_far_bound": ci["cells_with_far_bound"], "far_records_on_demand": bool(ci["far_records_on_demand"])}
+            if info.raycast_variant == 4:
+                line["cull"].update({"lane_items_per_ray": ci["lane_items"] / max(ci["rays"], 1), "lane_passes": ci["lane_passes"],
+                                     "lane_flushes": ci["lane_flushes"]})
         if world > 1:
             line["gather_check"] = ok
             line["per_rank"] = per_rank          # [rank]: ms per step of that rank; ms per step its compute stream waited for a transfer (rank 0 = the root's receive time that was not hidden)

@@ -163,6 +163,16 @@ ROVER_API int rover_get_depths(rover_ctx *ctx, const float *positions, const flo
  * state (euler, heading) alone and do not stand in for rover_get_observations: rover_calculate_metrics still requires that one. */
 ROVER_API int rover_get_collisions(rover_ctx *ctx, const float *positions, const float *rotations_euler, const float *joints,
                                    float *wheel_dist, float *body_dist, void *stream);
+/* The ray phase on its own, for parity tests that must not depend on the pose trigonometry (ray_casting.py:3-66 + the cell lookup
+ * camera.py:233-264 + min over K, camera.py:116-117):
+ *  rover_export_rays: the rays of the last cast on this ctx in slot order — per env 24 wheel, 2 body, P heightmap rays: origins
+ *    src [E,26+P,3], the ray records' directions dir [E,26+P,3] (= -normalize(direction), ray_casting.py:31, as the kernels use it),
+ *    cell ids cell [E,26+P] int32, distances dist [E,26+P] (each optional).
+ *  rover_cast_rays: casts caller-supplied rays in the same layout (origins + record directions; slots 0..25 against the rocks map,
+ *    the rest against the terrain map) through the step's sort + ray-cast kernels (variant / precision / cell index mode as set) and
+ *    returns their distances dist [E,26+P].  Overwrites the ray workspace like rover_get_depths. */
+ROVER_API int rover_export_rays(rover_ctx *ctx, float *src, float *dir, int32_t *cell, float *dist, void *stream);
+ROVER_API int rover_cast_rays(rover_ctx *ctx, const float *src, const float *dir, float *dist, void *stream);
 /* reset_buf.nonzero() rover.py:356 without the host sync: ids ascending (+env_offset), count to n_reset[0] */
 ROVER_API int rover_compact_resets(rover_ctx *ctx, const int64_t *reset, int64_t *reset_ids, int32_t *n_reset, void *stream);
 /* tensor_quat_to_eul tasks/utils/math/tensor_quat_to_euler.py:6-31 */
@@ -350,6 +360,7 @@ typedef struct {
     int64_t cells_with_far_bound[2];  /* per map: cells whose far bound is wide enough to hold for a usual ray (f32 proof tables) */
     uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them, and does not scan rays that clear their whole cell (rays_not_scanned) */
     uint64_t rays_not_scanned;        /* rays that cleared BOTH halves of their cell's triangles as groups (no candidate: the distance is the miss value) */
+    uint64_t lane_items, lane_passes, lane_flushes;   /* staged ray cast (variant 4): (ray, chunk of 16 pairs) items tested, staging passes, exact-phase rounds of runs */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -62,7 +62,8 @@ class CullInfo(C.Structure):
     _fields_ = [("triangles", C.c_int64 * 2), ("always_candidate_triangles", C.c_int64 * 2), ("cells_without_cone", C.c_int64 * 2),
                 ("rays", C.c_uint64), ("candidate_pairs", C.c_uint64), ("rays_both_tests", C.c_uint64), ("bins", C.c_uint64),
                 ("max_pairs_per_run", C.c_uint64), ("queue_bytes", C.c_uint64), ("launches_per_step", C.c_uint64), ("rays_far_skipped", C.c_uint64),
-                ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64), ("rays_not_scanned", C.c_uint64)]
+                ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64), ("rays_not_scanned", C.c_uint64),
+                ("lane_items", C.c_uint64), ("lane_passes", C.c_uint64), ("lane_flushes", C.c_uint64)]
 
 
 class ChainDesc(C.Structure):
@@ -102,6 +103,8 @@ SYMBOLS = {
     "rover_compact_resets": (C.c_int, [_P, _P, _P, _P, _P]),
     "rover_get_depths": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "rover_get_collisions": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rover_export_rays": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "rover_cast_rays": (C.c_int, [_P, _P, _P, _P, _P]),
     "rover_quat_to_euler": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "rover_clearance": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rover_shift_spawns": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
@@ -386,6 +389,26 @@ class Engine:
         self._check(self.lib.rover_get_collisions(self._h, _ptr(positions), _ptr(rotations), _ptr(joints), _ptr(wheel), _ptr(body),
                                                   _stream()), "rover_get_collisions")
         return wheel, body
+
+    def export_rays(self):
+        """The rays of the last cast in slot order (24 wheel, 2 body, P heightmap rays per env): (src [E,R,3], dir [E,R,3] — the ray
+        record's direction -normalize(direction) —, cell [E,R] int32, dist [E,R]), R = 26 + P."""
+        e, r = self.num_envs, 26 + self.P
+        src = torch.empty(e, r, 3, device=self.device)
+        dirs = torch.empty(e, r, 3, device=self.device)
+        cell = torch.empty(e, r, dtype=torch.int32, device=self.device)
+        dist = torch.empty(e, r, device=self.device)
+        self._check(self.lib.rover_export_rays(self._h, _ptr(src), _ptr(dirs), _ptr(cell), _ptr(dist), _stream()), "rover_export_rays")
+        return src, dirs, cell, dist
+
+    def cast_rays(self, src, dirs):
+        """Casts caller-supplied rays (layout of export_rays: origins, record directions) through the sort + ray-cast kernels."""
+        e, r, f = self.num_envs, 26 + self.P, torch.float32
+        self._chk(src, (e, r, 3), f, "src")
+        self._chk(dirs, (e, r, 3), f, "dir")
+        dist = torch.empty(e, r, device=self.device)
+        self._check(self.lib.rover_cast_rays(self._h, _ptr(src), _ptr(dirs), _ptr(dist), _stream()), "rover_cast_rays")
+        return dist
 
     def compact_resets(self, reset, reset_ids, n_reset):
         self._chk(reset, (self.num_envs,), torch.int64, "reset")

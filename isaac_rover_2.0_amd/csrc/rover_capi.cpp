@@ -33,6 +33,11 @@ struct rover_ctx {
     uint16_t* cull_rtab[2]{nullptr, nullptr};
     uint32_t* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
+    // tables of the staged ray cast (variant 4; f32 proof): per cell the pair records in group-bound order, their ids, the suffix bounds
+    float4* lane_lvl[2]{nullptr, nullptr};
+    uint4* lane_rec[2]{nullptr, nullptr};
+    uint2* lane_id[2]{nullptr, nullptr};
+    uint32_t lane_pp[2]{0, 0};
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
     uint4* d_cull_stats = nullptr;      // per-wave counters of the last culled launch (rover_get_cull_info)
@@ -179,6 +184,8 @@ static int effective_variant(const rover_ctx* c) {
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
+    // variant 4 (staged): the terrain part of the sorted list through lane_scan_kernel, the rocks part through the culled kernel; f32 proof only
+    if (c->variant == 4 && c->lane_rec[0] && c->precision != 2) return 4;
     return 3;
 }
 
@@ -199,7 +206,7 @@ static uint32_t effective_run(const rover_ctx* c) {
     //  8 192: 39.0 / 39.7 / 37.8 / 36.7; 16 384: 49.1 / 53.0 / 52.7 / 51.3; 32 768: 58.8 / 66.0 / 68.2 / 67.2; 65 536: 66.0 / 77.7 / 82.4 / 81.8;
     //  fp16 at 8 192 envs: 36.3 / 36.0 / 34.8 / 34.1): they keep the older table.  The native ray set on the regular mesh: 512 envs run 16 / 32 /
     //  64 -> 2.56 / 2.61 / 2.46, 1 024 envs 3.10 / 3.33 / 3.32.)
-    if (effective_variant(c) == 3) {
+    if (effective_variant(c) >= 3) {
         const bool quick_rays = c->precision != 2 && 2 * c->cull_farok[0] >= c->cull_cells[0];      // regular mesh (most cells have a far bound), f32 arithmetic
         if (quick_rays) return r < 3 ? 8u : (r < 6 ? 16u : (r < 20 ? 32u : 64u));                   // powers of two: 63 instead of 64 cost 6 %
         return r < 12 ? 8u : (r < 24 ? 16u : (r < 48 ? 32u : 64u));
@@ -245,7 +252,7 @@ static int alloc_bins(rover_ctx* c) {
 
 // candidate queue of the culled ray cast (one bounded region per resident wave) + its per-wave counters, for the options in force
 static int alloc_cull_queue(rover_ctx* c) {
-    if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) != 3) return ROVER_OK;
+    if (!c->ws_ok || !c->have_dist || !c->have_map[0] || !c->have_map[1] || effective_variant(c) < 3) return ROVER_OK;
     const uint32_t run = effective_run(c);
     const uint64_t entries = cull_queue_entries(valid_rays(c), (uint32_t)c->cfg.num_envs * (uint32_t)c->P, run, c->cull_budget, &c->cull_launches);
     // (the per-wave counters are sized by the RAY count, the queue — once capped by the budget — is not: a second
@@ -410,7 +417,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
-    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 3) ? x : 0; }
+    if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 4) ? x : 0; }
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
@@ -429,7 +436,8 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
 void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
-    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); dfree(c->cull_far[w]); dfree(c->cull_far_h[w]); }
+    for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); dfree(c->cull_far[w]); dfree(c->cull_far_h[w]);
+                                  dfree(c->lane_lvl[w]); dfree(c->lane_rec[w]); dfree(c->lane_id[w]); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -482,6 +490,8 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint32_t *d_qrow = nullptr, *d_qrow_h = nullptr;
     float4 *d_far = nullptr, *d_far_h = nullptr;
     float* d_nz = nullptr;
+    float4* d_llvl = nullptr; uint4* d_lrec = nullptr; uint2* d_lid = nullptr;
+    const uint32_t lane_pp = lane_pairs_per_row(K8);
     uint32_t* d_cnt = nullptr;
     uint32_t h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t cull_bytes = 0;
@@ -490,7 +500,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t);
         uint32_t T_int = 0;
         auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_far); dfree(d_far_h); dfree(d_nz); dfree(d_cnt);
-                            dfree(d_order); dfree(d_newid); dfree(d_table); };
+                            dfree(d_order); dfree(d_newid); dfree(d_table); dfree(d_llvl); dfree(d_lrec); dfree(d_lid); };
         // internal triangle numbering (spatial partners get ids 2p, 2p + 1, pairs ordered along a Morton curve): cull_numbering()
         std::vector<uint32_t> order, newid((size_t)T);
         {
@@ -508,7 +518,10 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u;
+        const uint64_t b_lane = n_cells * (9ull * sizeof(float4) + (uint64_t)lane_pp * (sizeof(uint4) + sizeof(uint2)));
+        // (the staged kernel addresses a cell's record row by a 32-bit byte offset)
+        const bool lane_fits = n_cells * (uint64_t)lane_pp * sizeof(uint4) < 0xffffffffull;
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u + (lane_fits ? b_lane : 0);
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
@@ -523,6 +536,11 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
                                    d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
                                    shift_x, shift_y, nullptr)) != hipSuccess ||
+            (lane_fits && ((e = hipMalloc((void**)&d_llvl, n_cells * 9ull * sizeof(float4))) != hipSuccess ||
+                           (e = hipMalloc((void**)&d_lrec, n_cells * (uint64_t)lane_pp * sizeof(uint4))) != hipSuccess ||
+                           (e = hipMalloc((void**)&d_lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess ||
+                           (e = launch_lane_build(d_cidx, d_ctab, n_cells, K8, (uint32_t)Y, cell, shift_x, shift_y, d_qrow, d_llvl, d_lrec, d_lid,
+                                                  nullptr)) != hipSuccess)) ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
             drop();
@@ -538,6 +556,8 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
     dfree(c->cull_ctab_h[which]); dfree(c->cull_qrow_h[which]); dfree(c->cull_far[which]); dfree(c->cull_far_h[which]);
+    dfree(c->lane_lvl[which]); dfree(c->lane_rec[which]); dfree(c->lane_id[which]);
+    c->lane_lvl[which] = d_llvl; c->lane_rec[which] = d_lrec; c->lane_id[which] = d_lid; c->lane_pp[which] = lane_pp;
     c->cull_far[which] = d_far; c->cull_far_h[which] = d_far_h;
     c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_qrow[which] = d_qrow; c->cull_bytes[which] = cull_bytes;
     c->cull_ctab_h[which] = d_ctab_h; c->cull_qrow_h[which] = d_qrow_h;
@@ -722,11 +742,36 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     return a;
 }
 
+// the ray-cast launch(es) of a step for the variant in force, on the ray records / sorted list in the workspace
+static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
+    const uint32_t E = (uint32_t)c->cfg.num_envs;
+    if (variant == 4) {
+        // the terrain rays (the first E x P of the sorted list: terrain bins sort first) through the staged kernel, the rock rays through the culled one
+        CullArgs a = cull_args(c, n_valid);
+        LaneArgs l{};
+        l.rays = c->d_rays; l.sorted = c->d_sorted; l.n_sorted = a.n_terrain < n_valid ? a.n_terrain : n_valid;
+        l.lvl = c->lane_lvl[0]; l.lrec = c->lane_rec[0]; l.lid = c->lane_id[0]; l.rtab = c->cull_rtab[0]; l.pp = c->lane_pp[0];
+        l.run = 64u; l.out = c->d_dist_out; l.stats = c->d_cull_stats;
+        HIP_TRY(c, launch_raycast_lane(l, s));
+        a.sorted += l.n_sorted; a.n_sorted -= l.n_sorted; a.n_terrain = 0;
+        a.stats += lane_waves(l.n_sorted, l.run);
+        if (a.n_sorted) HIP_TRY(c, launch_raycast_culled(a, s));
+    } else if (variant == 3)
+        HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
+    else if (variant == 2)
+        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
+                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
+    else
+        HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
+                                  (uint32_t)c->map[1].K8, c->d_dist_out, s));
+    return ROVER_OK;
+}
+
 // The ray pipeline of a step: env records + ray records, the bucket sort by (map, cell), the ray cast -> d_dist_out [E][R8].
 // euler_in != NULL (rover_get_depths): the poses come as euler angles, quat / joints / target may be NULL, and the ctx's euler / heading
 // state of the last observation is left alone.
 static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const float* joints, const float* target, const float* euler_in,
-                     hipStream_t s) {
+                     hipStream_t s, const float* import_src = nullptr, const float* import_dir = nullptr) {
     const uint32_t E = (uint32_t)c->cfg.num_envs;
     PrepArgs p{};
     p.E = E; p.P = (uint32_t)c->P; p.R8 = c->R8;
@@ -735,7 +780,7 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     p.rays = c->d_rays; p.euler = euler_in ? nullptr : c->d_euler; p.heading = euler_in ? nullptr : c->d_heading;
     const int variant = effective_variant(c);
     // (the queue is sized by every call that changes its size — never here: no hipMalloc inside a step / a stream capture)
-    if (variant == 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
+    if (variant >= 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
         return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
@@ -744,13 +789,19 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     p.cell_rcp = c->cell_rcp;
     // the sort's first pass (keys per coarse bucket and tile) inside prep_rays_kernel where a 64-env block's keys lie in one tile: the
     // table is zero between steps (allocation, then the sort's last kernel) — unless a step failed half way
-    const bool hist_fused = variant >= 2 && bin_hist_fused(E * c->R8, c->R8, c->n_bins, c->low_bits, &p.hist_blocks_per_tile);
+    // (caller-supplied rays, rover_cast_rays: import_rays_kernel writes the records and keys, the sort counts its keys itself)
+    const bool hist_fused = !import_src && variant >= 2 && bin_hist_fused(E * c->R8, c->R8, c->n_bins, c->low_bits, &p.hist_blocks_per_tile);
     if (hist_fused) {
         if (c->bkt_table_dirty) HIP_TRY(c, hipMemsetAsync(c->d_bkt_table, 0, c->bkt_table_bytes, s));
         c->bkt_table_dirty = true;
         p.hist = c->d_bkt_table; p.hist_low_bits = c->low_bits; p.hist_buckets = bucket_count(c);
     }
-    HIP_TRY(c, launch_prep(p, s));
+    if (import_src) {
+        HIP_TRY(c, launch_import_rays(import_src, import_dir, E, c->R8, (uint32_t)c->P, c->map[0], c->map[1], p.rocks_bin_offset, c->precision,
+                                      c->cell_rcp, c->d_rays, variant >= 2 ? c->d_bins : nullptr, s));
+    } else {
+        HIP_TRY(c, launch_prep(p, s));
+    }
     if (variant >= 2)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
                                    c->d_block_sums, c->d_sorted, hist_fused, s));
@@ -761,14 +812,7 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
         HIP_TRY(c, hipEventRecord(c->ev0[c->prof_pending], s));
     }
-    if (variant == 3)
-        HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
-    else if (variant == 2)
-        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table,
-                                         (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
-    else
-        HIP_TRY(c, launch_raycast(c->d_rays, E * c->R8, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
-                                  (uint32_t)c->map[1].K8, c->d_dist_out, s));
+    if (int r = run_raycast(c, variant, n_valid, s)) return r;
     if (timed) {
         HIP_TRY(c, hipEventRecord(c->ev1[c->prof_pending], s));
         ++c->prof_pending;
@@ -898,6 +942,27 @@ int rover_get_collisions(rover_ctx* c, const float* positions, const float* rota
     if (wheel_dist || body_dist)
         HIP_TRY(c, launch_export_dist(c->d_dist_out, c->d_rays, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, c->precision, nullptr,
                                       wheel_dist, body_dist, nullptr, nullptr, s));
+    return ROVER_OK;
+}
+
+int rover_export_rays(rover_ctx* c, float* src, float* dir, int32_t* cell, float* dist, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (int r = check_ready(c)) return r;
+    if (!c->rays_valid) return fail(c, ROVER_E_STATE, "export_rays: no ray records yet (run a step first)");
+    USE_DEVICE(c);
+    HIP_TRY(c, launch_export_rays(c->d_rays, c->d_dist_out, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, src, dir, cell, dist,
+                                  (hipStream_t)stream));
+    return ROVER_OK;
+}
+
+int rover_cast_rays(rover_ctx* c, const float* src, const float* dir, float* dist, void* stream) {
+    if (!c) return ROVER_E_INVALID;
+    if (!src || !dir || !dist) return fail(c, ROVER_E_INVALID, "cast_rays: src, dir and dist are required");
+    if (int r = check_ready(c)) return r;
+    USE_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if (int r = cast_rays(c, nullptr, nullptr, nullptr, nullptr, nullptr, s, src, dir)) return r;
+    HIP_TRY(c, launch_export_rays(c->d_rays, c->d_dist_out, (uint32_t)c->cfg.num_envs, c->R8, (uint32_t)c->P, nullptr, nullptr, nullptr, dist, s));
     return ROVER_OK;
 }
 
@@ -1068,13 +1133,14 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
     out->far_records_on_demand = (c->have_dist && c->have_map[0]) ? (uint64_t)cull_args(c, 0).lazy_far : 0;
     out->queue_bytes = c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0;
     out->launches_per_step = c->d_cull_queue ? c->cull_launches : 0;
-    if (!c->d_cull_stats || c->last_variant != 3) return ROVER_OK;
+    if (!c->d_cull_stats || c->last_variant < 3) return ROVER_OK;
     USE_DEVICE(c);
     HIP_TRY(c, hipDeviceSynchronize());
     std::vector<uint4> h(c->cull_stat_slots);
     HIP_TRY(c, hipMemcpy(h.data(), c->d_cull_stats, h.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (const uint4& v : h) {
-        out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z & 0xffu; out->rays_not_scanned += v.z >> 8; out->bins += v.w;
+        out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z & 0xffu; out->rays_not_scanned += v.z >> 8; out->bins += v.w & 0xffu;
+        out->lane_items += (v.w >> 8) & 0xfffu; out->lane_passes += (v.w >> 20) & 0x3fu; out->lane_flushes += v.w >> 26;
         out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
     }
     return ROVER_OK;
@@ -1305,7 +1371,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return ROVER_E_INVALID;
     USE_DEVICE(c);                                 // some options (re)allocate device workspace
     if (!strcmp(name, "raycast_variant")) {
-        if (value < 0 || value > 3) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned) or 3 (culled)");
+        if (value < 0 || value > 4) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned), 3 (culled) or 4 (staged)");
         c->variant = (int)value;
         return alloc_cull_queue(c);
     }
@@ -1390,16 +1456,9 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (v >= 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
-    if (v == 3) {
-        if (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c))
-            return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
-        HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
-    } else if (v == 2)
-        HIP_TRY(c, launch_raycast_binned(c->d_rays, c->d_sorted, n_valid, c->map[0].table, c->map[1].table, (uint32_t)c->map[0].K8,
-                                         (uint32_t)c->map[1].K8, effective_run(c), c->precision == 2, c->early_out, c->d_dist_out, s));
-    else
-        HIP_TRY(c, launch_raycast(c->d_rays, (uint32_t)c->cfg.num_envs * c->R8, c->map[0].table, c->map[1].table,
-                                  (uint32_t)c->map[0].K8, (uint32_t)c->map[1].K8, c->d_dist_out, s));
+    if (v >= 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))
+        return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
+    if (int r = run_raycast(c, v, n_valid, s)) return r;
     return ROVER_OK;
 }
 

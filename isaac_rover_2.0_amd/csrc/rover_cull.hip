@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 #include "rover_internal.h"
 #include "rover_raymath.h"
 
@@ -935,6 +937,465 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The STAGED ray cast (raycast variant 4): the culled ray cast with lanes and rays exchanged in phase 1.
+//
+// cull_scan_kernel gives a bin's triangles to the lanes and walks the bin's rays one by one: per ray ~25 wave instructions that test
+// nothing (ray parameters, ballots, queue bookkeeping), per bin a gather round trip (id row -> records) and an unpacking of 200 records
+// of which a steep ray can meet a few dozen.  Here a wave still takes a run of 64 sorted rays, but
+//   * the records a bin's rays can need arrive as ONE contiguous piece per 16 pairs: per cell the pairs' sphere records are stored
+//     ready to test (16 B per pair: centre relative to the cell's own centre and r2, fp16) in the order of the group-bound key G
+//     (far_build_kernel's), with a bound per SUFFIX of the list every 16 pairs ("levels"): a ray that clears the suffix behind 16 j pairs
+//     — the far skip's inequality, from one split to eight — needs the first j chunks only; a bin stages the chunks its rays need
+//     HBM -> LDS (global_load_lds, no registers, no dependent gather);
+//   * the tests are dealt as ITEMS = (ray, chunk) to the lanes, 64 items per round whatever ray or bin they belong to: a lane runs test
+//     (A) for its ray against the chunk's 16 pairs straight from LDS — 24 plain f32 / integer instructions per pair, the fp16 record
+//     read by v_fma_mix_f32 without a conversion — and leaves a 16-bit candidate mask: no per-ray overhead, no bin set-up, and a wave's
+//     work is the sum of its rays' needs, not 64 times the largest;
+//   * candidates become 2-byte queue entries (ray position, pair position) in LDS; the exact phase (the same arithmetic as every other
+//     ray-cast kernel, one lane per entry) fetches the pair's triangle ids through the cell's id row.
+// Rays off the cone path (test (B) is not implied by their cell's normal cone: body rays, steep ground) are not tested at all: every
+// pair of their cell is a candidate.  The kernel serves ONE map; the host runs it on the terrain part of the sorted list.
+//
+// Test (A) on these records.  A pair record holds, per triangle, m' = fp16(m - C) (m: ctab's sphere centre, C = (cell centre, z_c) in
+// f32) and r2' (fp16, rounded up) >= 1.19 (rho~ + e + 1e-3)^2 with rho~ >= the radius of the padded triangle about m (from ctab's own r2)
+// and e = |C + m' - m| the encoding's displacement, computed in double from the decoded values: the sphere about M = C + m' of radius
+// rho' = rho~ + e contains the padded triangle.  A lane computes s' = fl(s - C), h^ = fl(s' - m') (each component within 2.4e-7 |h| +
+// 5e-7 of the true h = s - M: two roundings of magnitudes <= |h| + |m'|, |m'| <= 4 m enforced by the builder), q = |h^|^2, t = h^ . d,
+// u = fl(fl(0.995 q - r2') - t^2) and culls iff u >= +0.  Rounding of q, t, u moves the inequality by < 3e-6 |h^|^2 + 3e-7 r2', so
+// u >= 0 gives W^ ^2 >= 0.004997 |h^|^2 + 1.19 (1 - 3e-7) (rho' + 1e-3)^2 for the distance W^ from M to the line through M + h^; by
+// Cauchy-Schwarz W^ >= 0.02126 |h^| + 1.0404 (rho' + 1e-3), and the true line is within |h - h^| <= 4.2e-7 |h| + 8.7e-7 of that one:
+// W >= 0.0212 |h| + 1.0404 rho' + 1.03e-3 > rho' + 0.02 (|h| + 2 rho'), which is all the rejection proof at the top of this file uses
+// of test (A).  The millimetre in r2' is what pays for the relative coordinates (a per cent of a 0.1 m triangle's radius).
+// Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are treated like rays off the cone path.
+// ---------------------------------------------------------------------------------------------------
+#define LN_CH 16u                    // pairs per chunk (one 256-byte piece of a cell's record row; one 16-bit candidate mask)
+#define LN_MAXCH 8u                  // chunks per row at most (K8 <= 256: 128 pairs)
+#define LN_LVL 9u                    // float4 per cell of the level table: header {Cx, Cy, z_c, q16} + 8 levels {G, z0, z1, rho_out}
+#define LN_SLOTS 16u                 // chunk slots of a wave's staging area (4 KB)
+#define LN_WIN 8u                    // a staging pass takes the bins whose first chunk index lies in a window of 8: 8 + 8 <= 16 slots
+#define LN_QCAP 1024u                // 2-byte queue entries per wave
+
+__device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v >= 0, finite or +inf)
+    _Float16 h = (_Float16)v;
+    uint16_t b = __builtin_bit_cast(uint16_t, h);
+    if ((float)h < v) b = (uint16_t)(b + 1u);                    // next fp16 above (0x7bff + 1 = +inf)
+    return b;
+}
+
+// one workgroup of 128 threads per cell, thread = source pair (idx4's (lane, slot)); see the header comment for the record
+__global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict__ idx4, const uint4* __restrict__ ctab, uint32_t K8, uint32_t pp,
+                                                         uint32_t Y, float cell_size, float shift_x, float shift_y, float k1, float tau2,
+                                                         double c_rho, const uint32_t* __restrict__ qrow, float4* __restrict__ lvl,
+                                                         uint4* __restrict__ lrec, uint2* __restrict__ lid) {
+    __shared__ float s_z0[128], s_z1[128], s_g[128], s_ro[128];
+    __shared__ uint32_t s_key[128];
+    __shared__ uint8_t s_src[128];
+    __shared__ uint4 s_rec[128];
+    __shared__ uint2 s_id[128];
+    const uint32_t cell = blockIdx.x, p = threadIdx.x, L = K8 >> 2, n_src = K8 >> 1;
+    const float ccx = (float)(cell / Y) * cell_size + shift_x, ccy = (float)(cell % Y) * cell_size + shift_y;
+    int32_t id[2] = {-1, -1};
+    uint4 rec[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (p < n_src) {
+        const int4 r4 = idx4[(uint64_t)cell * L + (p % L)];
+        const uint32_t slot = p / L;
+        id[0] = slot ? r4.z : r4.x; id[1] = slot ? r4.w : r4.y;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) if (id[e] >= 0) rec[e] = ctab[id[e]];
+    }
+    // z reference of the cell: the middle of its centres' z range
+    float zlo = __builtin_inff(), zhi = -__builtin_inff();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (id[e] < 0) continue;
+        const float mz = cvt2(rec[e].z).x;
+        if (mz == mz && fabsf(mz) < 6.0e4f) { zlo = fminf(zlo, mz); zhi = fmaxf(zhi, mz); }
+    }
+    s_z0[p] = zlo; s_z1[p] = zhi;
+    __syncthreads();
+    for (uint32_t sdt = 64u; sdt > 0; sdt >>= 1) {
+        if (p < sdt) { s_z0[p] = fminf(s_z0[p], s_z0[p + sdt]); s_z1[p] = fmaxf(s_z1[p], s_z1[p + sdt]); }
+        __syncthreads();
+    }
+    const float zc = s_z0[0] <= s_z1[0] ? 0.5f * (s_z0[0] + s_z1[0]) : 0.0f;
+    __syncthreads();
+    // the pair's record
+    uint16_t hb[2][4];
+    float G = __builtin_inff(), pz0 = __builtin_inff(), pz1 = -__builtin_inff(), pro = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        hb[e][0] = hb[e][1] = hb[e][2] = 0; hb[e][3] = 0xfc00u;              // empty slot: r2 = -inf, never a candidate
+        if (id[e] < 0) continue;
+        const f2 zn = cvt2(rec[e].z), w = cvt2(rec[e].w);
+        const float mx = __uint_as_float(rec[e].x), my = __uint_as_float(rec[e].y), mz = zn.x;
+        const float r2c = cull_r2(zn.y, w.x, w.y, tau2);                      // as cull_scan_kernel derives it
+        const float fx = (float)((double)mx - (double)ccx), fy = (float)((double)my - (double)ccy), fz = (float)((double)mz - (double)zc);
+        bool ok = r2c == r2c && r2c < 3.0e38f && r2c >= 0.0f && fabsf(fx) <= 4.0f && fabsf(fy) <= 4.0f && fabsf(fz) <= 4.0f;    // (NaN compares false)
+        const _Float16 hx = (_Float16)fx, hy = (_Float16)fy, hz = (_Float16)fz;
+        float g = -__builtin_inff(), r2h = __builtin_inff();
+        uint16_t r2b = 0x7c00u;                                                // +inf: always a candidate
+        if (ok) {
+            const double ex = (double)ccx + (double)(float)hx - (double)mx, ey = (double)ccy + (double)(float)hy - (double)my,
+                         ez = (double)zc + (double)(float)hz - (double)mz;
+            const double enc = sqrt(ex * ex + ey * ey + ez * ez);
+            const double rho = sqrt((double)r2c / c_rho);                     // >= rho + 1e-4 of the ctab record (its r2 >= c_rho (rho + 1e-4)^2)
+            const double need = c_rho * (rho + enc + 1.0e-3) * (rho + enc + 1.0e-3) * 1.000001;
+            if (need < 6.0e4) {
+                r2b = half_bits_up((float)(need * 1.0000001));
+                if (r2b < 0x0400u) r2b = 0x0400u;                              // no fp16 denormals
+                r2h = (float)__builtin_bit_cast(_Float16, r2b);
+            }
+        }
+        if (r2b != 0x7c00u) {
+            const float dxy = sqrtf((float)hx * (float)hx + (float)hy * (float)hy);
+            g = (dxy - k1 * sqrtf(r2h) * 1.00001f) * 0.99999f - 1.0e-6f;
+            pro = fmaxf(pro, dxy * 1.00001f);
+            pz0 = fminf(pz0, (float)hz); pz1 = fmaxf(pz1, (float)hz);
+            hb[e][0] = __builtin_bit_cast(uint16_t, hx); hb[e][1] = __builtin_bit_cast(uint16_t, hy); hb[e][2] = __builtin_bit_cast(uint16_t, hz);
+        }
+        hb[e][3] = r2b;
+        G = fminf(G, g);
+    }
+    // order the pairs by G (ascending; -inf = a pair that is always a candidate first, +inf = an empty pair last)
+    const uint32_t gb = __float_as_uint(G);
+    s_key[p] = (gb & 0x80000000u) ? ~gb : (gb | 0x80000000u);
+    s_src[p] = (uint8_t)p;
+    s_rec[p] = make_uint4((uint32_t)hb[0][0] | ((uint32_t)hb[0][1] << 16), (uint32_t)hb[0][2] | ((uint32_t)hb[0][3] << 16),
+                          (uint32_t)hb[1][0] | ((uint32_t)hb[1][1] << 16), (uint32_t)hb[1][2] | ((uint32_t)hb[1][3] << 16));
+    s_id[p] = make_uint2(id[0] >= 0 ? (uint32_t)id[0] : CULL_NOID, id[1] >= 0 ? (uint32_t)id[1] : CULL_NOID);
+    s_g[p] = G; s_z0[p] = pz0; s_z1[p] = pz1; s_ro[p] = pro;
+    __syncthreads();
+    for (uint32_t len = 2; len <= 128u; len <<= 1) {
+        for (uint32_t stride = len >> 1; stride > 0; stride >>= 1) {
+            if (p < 64u) {
+                const uint32_t lo = ((p / stride) * stride << 1) + (p % stride), hi = lo + stride;
+                const bool up = (lo & len) == 0;
+                const uint32_t a = s_key[lo], b = s_key[hi];
+                const uint8_t sa = s_src[lo], sb = s_src[hi];
+                if ((a > b || (a == b && sa > sb)) == up) { s_key[lo] = b; s_key[hi] = a; s_src[lo] = sb; s_src[hi] = sa; }
+            }
+            __syncthreads();
+        }
+    }
+    if (p < pp) {
+        const uint32_t src = s_src[p];
+        lrec[(uint64_t)cell * pp + p] = s_rec[src];
+        lid[(uint64_t)cell * pp + p] = s_id[src];
+    }
+    // levels: the bound of the suffix behind the first 16 j pairs
+    if (p < LN_MAXCH) {
+        float g = __builtin_inff(), z0 = __builtin_inff(), z1 = -__builtin_inff(), ro = 0.0f;
+        for (uint32_t q = p * LN_CH; q < 128u; ++q) {
+            const uint32_t src = s_src[q];
+            g = fminf(g, s_g[src]); z0 = fminf(z0, s_z0[src]); z1 = fmaxf(z1, s_z1[src]); ro = fmaxf(ro, s_ro[src]);
+        }
+        if (!(z0 <= z1)) { z0 = 0.0f; z1 = 0.0f; }
+        lvl[(uint64_t)cell * LN_LVL + 1u + p] = make_float4(g, z0, z1, ro);
+    }
+    if (p == 0) lvl[(uint64_t)cell * LN_LVL] = make_float4(ccx, ccy, zc, __uint_as_float(qrow[cell]));
+}
+
+// s - (fp16 half `HI` of `packed`), and a * b - (fp16 half of packed), in one v_fma_mix_f32 each
+template <int HI> __device__ __forceinline__ float mix_rsub(uint32_t packed, float s) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(s));
+    else    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(s));
+    return r;
+}
+__device__ __forceinline__ float mix_fms_hi(float a, float b, uint32_t packed) {       // a * b - (high half of packed)
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(packed));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= (uint32_t)off) v += o;
+    }
+    return v;
+}
+
+// the exact phase on 2-byte entries {ray position | pair position << 6}: ids through the cell's id row, then as cull_exact
+template <int H>
+__device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rt, const uint2* __restrict__ lid, uint32_t pp,
+                                           const uint16_t* q, uint32_t n, uint32_t gid, uint32_t cell, uint32_t lane, uint32_t* bk) {
+    if (n == 0u) return;
+    auto ids_of = [&](uint32_t i, uint32_t& pos) {
+        const uint32_t e = q[min(i, n - 1u)];
+        pos = e & 63u;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)cell);
+        return lid[(uint64_t)c * pp + (e >> 6)];
+    };
+    uint32_t pos_next;
+    uint2 id_next = ids_of(lane, pos_next);
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const bool live = base + lane < n;
+        const uint2 idp = id_next;
+        const uint32_t pos = pos_next;
+        const uint32_t id0 = idp.x, id1 = idp.y;
+        const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
+        const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
+        const float4* rp = reinterpret_cast<const float4*>(rays + g);
+        const float4 ra = rp[0], rb = rp[1];
+        if (base + 64u < n) id_next = ids_of(base + 64u + lane, pos_next);
+        float best;
+        if (H) {
+            h2 v[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const half2v x0 = __builtin_bit_cast(half2v, r0.d[k >> 1]), x1 = __builtin_bit_cast(half2v, r1.d[k >> 1]);
+                v[k] = (k & 1) ? h2{x0.y, x1.y} : h2{x0.x, x1.x};
+            }
+            const _Float16 hnan = (_Float16)__builtin_nanf("");
+            v[6] = h2{id0 == CULL_NOID ? hnan : v[6].x, id1 == CULL_NOID ? hnan : v[6].y};
+            CellRegsH<1> t;
+            set_pair_h(t, 0, v);
+            const uint64_t none[1][2] = {{0, 0}};
+            const _Float16 hsx = (_Float16)ra.x, hsy = (_Float16)ra.y, hsz = (_Float16)ra.z;
+            const _Float16 hdx = (_Float16)rb.x, hdy = (_Float16)rb.y, hdz = (_Float16)rb.z;
+            best = cast_pairs_h<1>(t, h2{hsx, hsx}, h2{hsy, hsy}, h2{hsz, hsz}, h2{hdx, hdx}, h2{hdy, hdy}, h2{hdz, hdz}, none, 0u);
+        } else {
+            const float qnan = __builtin_nanf("");
+            f2 v[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const f2 x0 = cvt2(r0.d[k >> 1]), x1 = cvt2(r1.d[k >> 1]);
+                v[k] = (k & 1) ? f2{x0.y, x1.y} : f2{x0.x, x1.x};
+            }
+            v[6] = f2{id0 == CULL_NOID ? qnan : v[6].x, id1 == CULL_NOID ? qnan : v[6].y};
+            CellRegs<1> t;
+            set_pair(t, 0, v);
+            const uint64_t none[1][2] = {{0, 0}};
+            best = cast_pairs<1>(t, f2{ra.x, ra.x}, f2{ra.y, ra.y}, f2{ra.z, ra.z}, f2{rb.x, rb.x}, f2{rb.y, rb.y}, f2{rb.z, rb.z}, none, 0u);
+        }
+        const uint32_t k = fkey(best);
+        if (live && k < fkey(RAY_MISS)) atomicMin(bk + pos, k);
+    }
+}
+
+#define LANE_SCAN_ARGS                                                                                                                        \
+    const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const float4 *__restrict__ lvl,                  \
+        const uint4 *__restrict__ lrec, const uint2 *__restrict__ lid, const RawTri *__restrict__ rtab, uint32_t pp, uint32_t run,            \
+        uint32_t n_blocks, uint32_t t8, uint32_t chs, float *__restrict__ out, uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
+
+template <int H>
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
+    __shared__ uint4 s_stage[LN_SLOTS * LN_CH];           // staged chunks: 16 slots x 16 pair records
+    __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, slot base, -}
+    __shared__ uint16_t s_items[64 * LN_MAXCH];           // ray | chunk << 6
+    __shared__ uint16_t s_cand[64 * LN_MAXCH];            // candidate mask of (ray, chunk): bit 15 - i = pair i of the chunk
+    __shared__ uint16_t s_q[LN_QCAP];                     // ray | pair position << 6
+    __shared__ uint32_t s_bk[64];
+    __shared__ uint32_t s_csrc[LN_SLOTS];                 // byte offset in lrec of the chunk staged in each slot
+    const uint32_t lane = threadIdx.x, x = blockIdx.x & 7u, qx = blockIdx.x >> 3, w = qx & 3u, j = qx >> 2;
+    const uint32_t lb = chs == 31u ? x * t8 + j : ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u));
+    if (j >= t8 || lb >= n_blocks) return;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
+    const uint32_t i0 = wave * run;
+    if (i0 >= n_sorted) return;
+    const uint32_t n_run = min(run, n_sorted - i0), nch = pp / LN_CH;
+    const bool act = lane < n_run;
+    const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    const uint32_t gid = sorted[i0 + (act ? lane : n_run - 1u)];
+    const float4 rsa = reinterpret_cast<const float4*>(rays + gid)[0], rsb = reinterpret_cast<const float4*>(rays + gid)[1];
+    const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w);
+    const float4* lp = lvl + (uint64_t)cell * LN_LVL;
+    const float4 hdr = lp[0];
+    float4 lv[LN_MAXCH];
+#pragma unroll
+    for (int k = 0; k < (int)LN_MAXCH; ++k) lv[k] = lp[1 + k];
+    s_bk[lane] = fkey(RAY_MISS);
+    // the ray relative to its cell; its level = the first suffix it clears
+    const float sx = rsa.x - hdr.x, sy = rsa.y - hdr.y, sz = rsa.z - hdr.z;
+    const bool tame = fabsf(sx) < 1.0e4f && fabsf(sy) < 1.0e4f && fabsf(sz) < 1.0e4f && fabsf(rsb.x) <= 2.0f && fabsf(rsb.y) <= 2.0f && fabsf(rsb.z) <= 2.0f;
+    const bool cone = __float_as_uint(hdr.w) >= (rflags >> 16);
+    uint32_t L = nch;
+    {
+        const float o = __builtin_amdgcn_sqrtf(sx * sx + sy * sy);
+        const float dxy2 = rsb.x * rsb.x + rsb.y * rsb.y, adz = fabsf(rsb.z), sq = __builtin_amdgcn_sqrtf(dxy2);
+        const bool steep = adz * adz >= 0.81f * (dxy2 + adz * adz) * 1.0001f;
+        const float dxy1 = sq * 1.0001f;
+#pragma unroll
+        for (int k = (int)LN_MAXCH - 1; k >= 0; --k) {
+            const float dzm = fmaxf(fabsf(sz - lv[k].y), fabsf(sz - lv[k].z));
+            const float e_adz = o * adz + dzm * sq * 1.0001f;
+            const float amax = (dzm * adz + (o + lv[k].w) * dxy1) * 1.0001f;
+            const bool clears = steep && (lv[k].x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * amax * adz) * 1.0001f;
+            if ((uint32_t)k < nch && clears) L = (uint32_t)k;
+        }
+    }
+    const bool allc = act && !(cone && tame);                 // every pair of the cell is a candidate, nothing is tested
+    if (allc) L = nch;
+    if (!act) L = 0u;
+    const uint32_t n_items = allc ? 0u : L;
+    // (diagnostic build of the library's own: ROVER_LANE_DIAG=1 prints where a wave's time goes — launch_raycast_lane)
+    uint64_t tq = 0;
+    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) { if (diag) { const uint64_t n = __builtin_amdgcn_s_memtime(); dg[k] += (uint32_t)(n - tq); tq = n; } };
+    if (diag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tq = __builtin_amdgcn_s_memtime();
+        dg[5] = (uint32_t)(tq - t_start);
+        for (uint32_t v = 0; v < 10u; ++v) {                                                  // histogram of the rays' levels behind the per-wave rows
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && (allc ? 9u : L) == v));
+            if (lane == 0u && cnt) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + v, cnt);
+        }
+    }
+    // bins of the run, the chunks each stages (the largest need of its rays), staging passes
+    const uint32_t prevc = (uint32_t)__shfl_up((int)cell, 1, 64);
+    const bool head = act && (lane == 0u || cell != prevc);
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
+    const uint64_t le = (2ull << lane) - 1ull;                                // bits 0..lane
+    const uint64_t below = heads & le, above = heads & ~le;
+    const uint32_t lo = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u, hi = above ? (uint32_t)__builtin_ctzll(above) : n_run;
+    const uint64_t binmask = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+    uint32_t need = 0;
+#pragma unroll
+    for (uint32_t v = 1; v <= LN_MAXCH; ++v) need += (__builtin_amdgcn_ballot_w64(n_items >= v) & binmask) ? 1u : 0u;     // (rays that test nothing stage nothing)
+    if (!act) need = 0u;
+    const uint32_t hc = head ? need : 0u;
+    const uint32_t cb_incl = wave_incl_scan(hc, lane);
+    const uint32_t cb = (uint32_t)__shfl((int)(cb_incl - hc), (int)lo, 64);   // first chunk index of this lane's bin
+    const uint32_t pl = cb / LN_WIN, sb = cb - pl * LN_WIN;                    // staging pass and slot base of the bin
+    const uint32_t last_pass = (uint32_t)__builtin_amdgcn_readlane((int)pl, (int)(n_run - 1u));
+    const uint32_t it_incl = wave_incl_scan(n_items, lane), it_pre = it_incl - n_items;
+    wave_lds_sync();
+    s_ray[2u * lane] = make_float4(sx, sy, sz, rsb.x);
+    s_ray[2u * lane + 1u] = make_float4(rsb.y, rsb.z, __uint_as_float(sb), 0.0f);
+#pragma unroll
+    for (uint32_t k = 0; k < LN_MAXCH; ++k)
+        if (k < n_items) s_items[it_pre + k] = (uint16_t)(lane | (k << 6));
+    uint32_t cused = 0, ctot = 0, n_flush = 0, n_passes = 0;
+    lap(0);
+    const uint32_t rowb = cell * pp * 16u;                                    // byte offset of the cell's record row (tables stay below 4 GB)
+    auto flush = [&]() {
+        wave_lds_sync();
+        lap(3);
+        lane_exact<H>(rays, rtab, lid, pp, s_q, cused, gid, cell, lane, s_bk);
+        ctot += cused;
+        cused = 0;
+        ++n_flush;
+        wave_lds_sync();
+        lap(4);
+    };
+    for (uint32_t p = 0; p <= last_pass; ++p) {
+        const bool mine = act && pl == p;
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(mine);
+        if (!pm) continue;
+        const uint32_t f = (uint32_t)__builtin_ctzll(pm), l_end = 64u - (uint32_t)__builtin_clzll(pm);      // the pass's rays [f, l_end)
+        ++n_passes;
+        // stage the pass's chunks
+        if (head && mine) {
+#pragma unroll
+            for (uint32_t k = 0; k < LN_MAXCH; ++k)
+                if (k < need) s_csrc[sb + k] = rowb + k * (LN_CH * 16u);
+        }
+        const uint32_t nslots = (uint32_t)__builtin_amdgcn_readlane((int)(sb + need), (int)(l_end - 1u));
+        const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)sb, (int)f);                       // (the slots below belong to the pass before)
+        wave_lds_sync();
+#pragma unroll
+        for (uint32_t i = 0; i < LN_SLOTS / 4u; ++i) {
+            const uint32_t c = 4u * i + (lane >> 4);
+            if (c >= slot0 && c < nslots) {
+                const char* src = reinterpret_cast<const char*>(lrec) + s_csrc[c] + ((lane & 15u) << 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)&s_stage[i * 64u], 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        lap(1);
+        // the pass's items, 64 per round
+        const uint32_t it0 = (uint32_t)__builtin_amdgcn_readlane((int)it_pre, (int)f);
+        const uint32_t it1 = (uint32_t)__builtin_amdgcn_readlane((int)it_incl, (int)(l_end - 1u));
+        for (uint32_t base = it0; base < it1; base += 64u) {
+            const bool ok = base + lane < it1;
+            const uint32_t it = s_items[ok ? base + lane : it0];
+            const uint32_t rl = it & 63u, ch = it >> 6;
+            const float4 ra = s_ray[2u * rl], rb = s_ray[2u * rl + 1u];
+            const uint4* cp = &s_stage[(__float_as_uint(rb.z) + ch) * LN_CH];
+            uint32_t mask = 0;
+#pragma unroll 4
+            for (uint32_t i = 0; i < LN_CH; ++i) {
+                const uint4 r = cp[i];
+                uint32_t sg;
+                {
+                    const float hx = mix_rsub<0>(r.x, ra.x), hy = mix_rsub<1>(r.x, ra.y), hz = mix_rsub<0>(r.y, ra.z);
+                    float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
+                    float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
+                    float u = mix_fms_hi(qq, c_a, r.y);
+                    u = __builtin_fmaf(-t, t, u);
+                    sg = __float_as_uint(u);
+                }
+                {
+                    const float hx = mix_rsub<0>(r.z, ra.x), hy = mix_rsub<1>(r.z, ra.y), hz = mix_rsub<0>(r.w, ra.z);
+                    float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
+                    float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
+                    float u = mix_fms_hi(qq, c_a, r.w);
+                    u = __builtin_fmaf(-t, t, u);
+                    sg |= __float_as_uint(u);
+                }
+                mask = __builtin_amdgcn_alignbit(mask, sg, 31);       // (mask << 1) | sign: a pair is a candidate unless both u >= +0
+            }
+            if (ok) s_cand[rl * LN_MAXCH + ch] = (uint16_t)mask;
+        }
+        wave_lds_sync();
+        lap(2);
+        // candidates -> queue entries, for the pass's rays
+        uint32_t cm[LN_MAXCH], cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < LN_MAXCH; ++k) {
+            uint32_t m = 0;
+            if (mine && k < L) m = allc ? 0xffffu : (uint32_t)s_cand[lane * LN_MAXCH + k];
+            cm[k] = m; cnt += (uint32_t)__builtin_popcount(m);
+        }
+        const uint32_t e_incl = wave_incl_scan(cnt, lane), e_pre = e_incl - cnt;
+        uint32_t r_lo = f;
+        for (;;) {
+            const uint32_t base_e = (uint32_t)__builtin_amdgcn_readlane((int)e_pre, (int)r_lo);
+            const uint64_t fm = __builtin_amdgcn_ballot_w64(mine && lane >= r_lo && e_incl - base_e <= LN_QCAP - cused);
+            if (!fm) { flush(); continue; }                    // (an empty queue takes any one ray: <= 128 entries)
+            const uint32_t r_hi = 64u - (uint32_t)__builtin_clzll(fm);
+            if (mine && lane >= r_lo && lane < r_hi) {
+                uint32_t at = cused + (e_pre - base_e);
+#pragma unroll
+                for (uint32_t k = 0; k < LN_MAXCH; ++k) {
+                    uint32_t m = cm[k];
+                    while (m) {
+                        const uint32_t b = 31u - (uint32_t)__builtin_clz(m);           // bit 15 - i = pair i
+                        m &= ~(1u << b);
+                        s_q[at++] = (uint16_t)(lane | ((k * LN_CH + (15u - b)) << 6));
+                    }
+                }
+            }
+            cused += (uint32_t)__builtin_amdgcn_readlane((int)e_incl, (int)(r_hi - 1u)) - base_e;
+            if (r_hi >= l_end) break;
+            r_lo = r_hi;
+            flush();
+        }
+    }
+    lap(3);
+    if (cused) flush();
+    wave_lds_sync();
+    if (act) out[gid] = funkey(s_bk[lane]);
+    {
+        const uint64_t am = n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull);
+        const uint32_t n_both = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(allc) & am);
+        const uint32_t n_askip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u) & am);
+        const uint32_t n_fskip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !allc && 2u * L <= nch) & am);
+        const uint32_t n_bins = (uint32_t)__builtin_popcountll(heads);
+        const uint32_t it_tot = (uint32_t)__builtin_amdgcn_readlane((int)it_incl, 63);
+        if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins | (it_tot << 8) | (n_passes << 20) | (n_flush << 26));
+        if (diag && lane == 0u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) diag[(size_t)wave * 8u + k] = dg[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint64_t n, uint32_t bs) { return (uint32_t)((n + bs - 1) / bs); }
@@ -1060,7 +1521,7 @@ uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run) {
     if (run > CULL_RUNMAX) run = CULL_RUNMAX;
     if (run == 0) run = 1;
     const uint32_t rr = run >= 32u ? run / 2u : run;                // the rocks part walks shorter runs (cull_grid)
-    return (uint32_t)(4u * ((n_rays / rr + 4u) / 4u + 3u));
+    return (uint32_t)(4u * ((n_rays / rr + 4u) / 4u + 5u));        // (+ the rounding of a second part: the staged ray cast counts its terrain waves in front)
 }
 
 // Entries of the candidate queue: one region of CULL_QGLOBAL entries per wave of a launch, capped by `budget_bytes` (a launch then
@@ -1072,6 +1533,51 @@ uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, u
     if (per > slots) per = slots ? slots : 1u;
     if (n_launches) *n_launches = slots ? (slots + per - 1u) / per : 1u;
     return (uint64_t)per * 8u * 4u * CULL_QGLOBAL;
+}
+
+// ---- the staged ray cast (variant 4) ----
+uint32_t lane_pairs_per_row(uint32_t K8) { return ((K8 / 2u + LN_CH - 1u) / LN_CH) * LN_CH; }
+
+hipError_t launch_lane_build(const int32_t* idx4, const uint4* ctab, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell_size, float shift_x,
+                             float shift_y, const uint32_t* qrow, float4* lvl, uint4* lrec, uint2* lid, hipStream_t s) {
+    float k1, k2;
+    cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    hipLaunchKernelGGL(lane_build_kernel, dim3((uint32_t)n_cells), dim3(128), 0, s, reinterpret_cast<const int4*>(idx4), ctab, K8, lane_pairs_per_row(K8),
+                       Y, cell_size, shift_x, shift_y, k1, CullK<0>::tau2, CullK<0>::c_rho, qrow, lvl, lrec, lid);
+    return hipGetLastError();
+}
+
+uint32_t lane_waves(uint32_t n_rays, uint32_t run) {
+    const CullGrid g = cull_grid(n_rays, n_rays, run);
+    return g.n_blocks * 4u;
+}
+
+hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
+    if (a.n_sorted == 0u) return hipSuccess;
+    const CullGrid g = cull_grid(a.n_sorted, a.n_sorted, a.run);           // every block is a "terrain" block: runs of g.run
+    float k1, k2;
+    cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    static const bool want_diag = getenv("ROVER_LANE_DIAG") != nullptr;
+    static uint32_t* d_diag = nullptr; static uint32_t diag_waves = 0; static int diag_left = 3;
+    const uint32_t waves = g.n_blocks * 4u;
+    if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 16u) * sizeof(uint32_t)); diag_waves = waves; }
+    if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 16u) * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(lane_scan_kernel<0>, dim3(g.t8 * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted, a.n_sorted, a.lvl, a.lrec, a.lid,
+                       reinterpret_cast<const RawTri*>(a.rtab), a.pp, g.run, g.n_blocks, g.t8, g.chs, a.out, a.stats, k2, CullK<0>::c_a,
+                       want_diag ? d_diag : nullptr);
+    if (want_diag && d_diag && diag_left > 0) {      // where a wave's time goes: mean shader-clock cycles per wave and phase (synchronises: a diagnostic)
+        --diag_left;
+        std::vector<uint32_t> h((size_t)waves * 8u + 16u);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), d_diag, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < (size_t)waves * 8u; ++i) sum[i & 7u] += h[i];
+            const uint32_t* hg = h.data() + (size_t)waves * 8u;
+            fprintf(stderr, "lane_scan_kernel, %u waves, mean cycles per wave: prologue loads %.0f | bins/scans %.0f | staging wait %.0f | items %.0f | entries %.0f | exact %.0f"
+                    " ; rays by level 0..8: %u %u %u %u %u %u %u %u %u, untested (all pairs candidates): %u\n", waves,
+                    sum[5] / waves, sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves, hg[0], hg[1], hg[2], hg[3], hg[4], hg[5], hg[6], hg[7], hg[8], hg[9]);
+        }
+    }
+    return hipGetLastError();
 }
 
 }  // namespace rover

@@ -82,6 +82,24 @@ struct CullArgs {
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
+// the staged ray cast (raycast variant 4, rover_cull.hip): lane = (ray, chunk of 16 pairs) over per-cell record rows staged in LDS; one map per launch
+struct LaneArgs {
+    const RayRec* rays;
+    const uint32_t* sorted;      // the part of the sorted list that belongs to the map
+    uint32_t n_sorted;
+    const float4* lvl;           // [cell][9]: header + 8 suffix bounds
+    const uint4* lrec;           // [cell][pp]: pair records in G order
+    const uint2* lid;            // [cell][pp]: the pairs' triangle ids
+    const uint16_t* rtab;
+    uint32_t pp, run;
+    float* out;
+    uint4* stats;
+};
+uint32_t lane_pairs_per_row(uint32_t K8);
+uint32_t lane_waves(uint32_t n_rays, uint32_t run);
+hipError_t launch_lane_build(const int32_t* idx4, const uint4* ctab, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell_size, float shift_x,
+                             float shift_y, const uint32_t* qrow, float4* lvl, uint4* lrec, uint2* lid, hipStream_t s);
+hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s);
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches);
 
 // n / d for every 32-bit n with a multiply-high and two shifts (Granlund & Montgomery's round-up method): the compiler's own

@@ -154,6 +154,16 @@ def raycast(m: KnnMap, src, dirs):
     return out
 
 
+def raycast_unit(m: KnnMap, src, dneg, half=False):
+    """Rays given as the HIP path's ray records hold them: origin and d = -normalize(direction).  ``half``: the as-shipped fp16
+    arithmetic (src / dneg then hold fp16 values)."""
+    s = _np(src, np.float32).reshape(-1, 3)
+    d = _np(dneg, np.float32).reshape(-1, 3)
+    out = np.zeros(s.shape[0], np.float32)
+    lib().oracle_raycast_unit(C.byref(m.c), s.shape[0], _p(s), _p(d), 1 if half else 0, _p(out))
+    return out
+
+
 def clearance(info7, xy):
     info = _np(info7, np.float32)
     q = _np(xy, np.float32).reshape(-1, 2)

@@ -189,11 +189,16 @@ static inline int64_t cell_index(float v, float shift, float cell, int32_t dim0)
 
 /* ray_casting.py:3-66 for one ray against the K triangles of its cell, then min over K
  * (camera.py:116-117).  d_in is the un-normalised direction. */
+static float ray_min_core(const oracle_knn_map *m, const float *s, const float *d);
 static float ray_min_distance(const oracle_knn_map *m, const float *s, const float *d_in) {
     /* F.normalize (ray_casting.py:31): x / max(||x||_2, 1e-12), then negated */
     float nrm = sqrtf(d_in[0] * d_in[0] + d_in[1] * d_in[1] + d_in[2] * d_in[2]);
     if (nrm < 1e-12f) nrm = 1e-12f;
     float d[3] = {-(d_in[0] / nrm), -(d_in[1] / nrm), -(d_in[2] / nrm)};
+    return ray_min_core(m, s, d);
+}
+/* ray_casting.py:34-59 + the min over K for a ray whose d = -normalize(direction) is given */
+static float ray_min_core(const oracle_knn_map *m, const float *s, const float *d) {
     int64_t ix = cell_index(s[0], m->shift_x, m->cell, m->X);
     int64_t iy = cell_index(s[1], m->shift_y, m->cell, m->X);
     if (iy > m->Y - 1) iy = m->Y - 1;                          /* memory safety only (reference indexes out of range) */
@@ -236,9 +241,13 @@ static void cross_h(const float *u, const float *v, float *o) {
 }
 static float dot_h(const float *u, const float *v) { return RH(RH(RH(u[0]*v[0]) + RH(u[1]*v[1])) + RH(u[2]*v[2])); }
 
+static float ray_min_core_h(const oracle_knn_map *m, const float *s, const float *d);
 static float ray_min_distance_h(const oracle_knn_map *m, const float *s, const float *d_in) {
     float nrm = RH(sqrtf(d_in[0] * d_in[0] + d_in[1] * d_in[1] + d_in[2] * d_in[2]));     /* eps 1e-12 is 0 in fp16 */
     float d[3] = {-RH(d_in[0] / nrm), -RH(d_in[1] / nrm), -RH(d_in[2] / nrm)};
+    return ray_min_core_h(m, s, d);
+}
+static float ray_min_core_h(const oracle_knn_map *m, const float *s, const float *d) {
     int64_t ix = cell_index(s[0], m->shift_x, m->cell, m->X);
     int64_t iy = cell_index(s[1], m->shift_y, m->cell, m->X);
     if (iy > m->Y - 1) iy = m->Y - 1;
@@ -491,6 +500,13 @@ ORACLE_API void oracle_ackermann(int n, const float *lin_in, const float *ang_in
             steer[6*i + w] = sa;
         }
     }
+}
+
+/* the same for rays whose d = -normalize(direction) is given (what a ray record of the HIP path holds): the per-ray arithmetic
+ * without the normalisation, in either arithmetic (half: the as-shipped fp16 sequence on fp16-valued s, d) */
+ORACLE_API void oracle_raycast_unit(const oracle_knn_map *m, int n, const float *src3, const float *dneg3, int half, float *out) {
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < n; ++i) out[i] = half ? ray_min_core_h(m, src3 + 3*i, dneg3 + 3*i) : ray_min_core(m, src3 + 3*i, dneg3 + 3*i);
 }
 
 /* standalone ray cast of arbitrary rays (used to pin the kernel's inner loop in isolation) */

@@ -209,41 +209,84 @@ def _oracle_maps(scene):
             orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices))
 
 
-def _all_envs_vs_oracle(scene, distn, st, label):
-    """fp32 mode: the kernel the library picks for a full batch against the oracle on every env (tolerances of conftest.py: scalars
-    1e-5, ray distances 2e-3 on >= 99.9 % of the rays, integer outputs exact away from their thresholds).
-    fp16_as_shipped: the culled kernel (fp16 proof tables, fp16 exact phase) == the every-triangle kernel bit for bit on every
-    output, and against the oracle's fp16 mode everything but the rays whose fp16 rounding a sin / cos / atan2 ulp moved."""
+def _rays_vs_oracle(eng, maps, half, label):
+    """The ray phase on its own, free of the pose trigonometry: the device's OWN rays of the last step (origins and ray-record
+    directions as prep_rays_kernel made them, `rover_export_rays`) through the oracle's per-ray arithmetic (ray_casting.py:34-59 + the
+    cell lookup + min over K, `oracle.raycast_unit`) must give the device's distances bit for bit — every ray, both maps."""
+    from oracle import oracle as orc
+    src, dirs, cell, dist = (x.cpu().numpy() for x in eng.export_rays())
+    t, r = maps
+    want_rock = orc.raycast_unit(r, src[:, :26], dirs[:, :26], half=half).reshape(dist[:, :26].shape)
+    want_terr = orc.raycast_unit(t, src[:, 26:], dirs[:, 26:], half=half).reshape(dist[:, 26:].shape)
+    n_bad = int((dist[:, :26].view(np.uint32) != want_rock.view(np.uint32)).sum()) + \
+        int((dist[:, 26:].view(np.uint32) != want_terr.view(np.uint32)).sum())
+    print(f"[{label}] ray phase on the device's own rays vs the oracle: {n_bad} of {dist.size} distances differ")
+    want_all = np.concatenate((want_rock, want_terr), axis=1)
+    for e, sl in list(zip(*np.nonzero(dist.view(np.uint32) != want_all.view(np.uint32))))[:8]:
+        print(f"   env {e} slot {sl}: src {src[e, sl].tolist()} ({src[e, sl].view(np.uint32).tolist()}) dir {dirs[e, sl].tolist()} "
+              f"({dirs[e, sl].view(np.uint32).tolist()}) cell {cell[e, sl]}: device {dist[e, sl]!r} oracle {want_all[e, sl]!r}")
+    assert n_bad == 0, f"{label}: {n_bad} of {dist.size} ray distances differ from the oracle on IDENTICAL rays"
+    return src, cell
+
+
+def _all_envs_vs_oracle(scene, distn, st, label, budget=None):
+    """Two comparisons per arithmetic (fp32 parity mode, the reference's as-shipped fp16 arithmetic), each on every env:
+      (a) the ray phase on identical rays (`_rays_vs_oracle`): ZERO differing distances;
+      (b) the whole step against the oracle's own step.  What may differ there is what the pose trigonometry moves: the device's
+          sin / cos / atan2 differ from the host libm's by an ulp on some poses, which moves a ray origin by an ulp (a fp16 rounding
+          in the as-shipped mode), and with it — rarely — a cell index or an eps-edge decision.  The numbers of rays whose origin /
+          cell differ are measured and printed; the distance / flag budgets are twice what was measured on MI355X (`budget`)."""
+    from hip_helpers import hip_step, make_engine
     from oracle import oracle as orc
     n = st["pos"].shape[0]
-    t, r = _oracle_maps(scene)
-    got = _run(scene, distn, st, variant=None)                       # the library's own choice of ray-cast kernel
+    maps = _oracle_maps(scene)
+    t, r = maps
+    b = dict(flips32=2e-4, flags32=1e-4, rays16=2e-3, flags16=2e-3)
+    b.update(budget or {})
+    eng = make_engine(scene, distn, n, variant=None)                 # the library's own choice of ray-cast kernel
+    got = hip_step(eng, st)
+    src, cell = _rays_vs_oracle(eng, maps, False, f"{label} fp32")
+    eng.close()
     want = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp32")
     g = dict(got)
     np.testing.assert_array_equal(g.pop("reset_ids"), np.nonzero(got["reset_buf"])[0])      # compaction of the flags the step itself set
     assert_step_close(g, {"out_" + k: v for k, v in want.items()}, f"{label} fp32, all {n} envs")
-    # stricter than the budget of assert_step_close, and reported: how many rays / flags differ at all
+    # what the trigonometry moved: terrain ray origins that differ at all (an ulp), and how many of them land in another cell
+    ws = want["ray_sources"].reshape(src[:, 26:].shape)
+    moved = (src[:, 26:].view(np.uint32) != ws.view(np.uint32)).any(axis=2)
+    cx = np.rint(np.clip((ws[..., 0] - scene.shift[0]) / np.float32(0.1), 0, scene.terrain.map_indices.shape[0] - 1))
+    cy = np.rint(np.clip((ws[..., 1] - scene.shift[1]) / np.float32(0.1), 0, scene.terrain.map_indices.shape[0] - 1))
+    cy = np.minimum(cy, scene.terrain.map_indices.shape[1] - 1)
+    other_cell = (cell[:, 26:] != (cx * scene.terrain.map_indices.shape[1] + cy).astype(np.int64))
     flips = float(((got["ray_dist"] < 11.0) != (want["ray_dist"] < 11.0)).mean())
-    assert flips < 2e-4, f"{label}: {flips:.5%} of the terrain rays flip hit <-> miss against the oracle"
-    assert float((got["reset_buf"] != want["reset_buf"]).mean()) < 1e-4
-    assert float((got["rock_collision"] != want["rock_collision"]).mean()) < 1e-4
+    f_reset = float((got["reset_buf"] != want["reset_buf"]).mean())
+    f_coll = float((got["rock_collision"] != want["rock_collision"]).mean())
+    print(f"[{label} fp32] whole step vs the oracle: {moved.mean():.4%} of the terrain ray origins differ by an ulp, "
+          f"{other_cell.mean():.5%} land in another cell; hit<->miss flips {flips:.5%}, reset flags {f_reset:.5%}, collision flags {f_coll:.5%}")
+    assert flips <= b["flips32"], f"{label}: {flips:.5%} of the terrain rays flip hit <-> miss against the oracle"
+    assert f_reset <= b["flags32"] and f_coll <= b["flags32"]
 
     outs = {}
     for variant in (3, 2):
-        from hip_helpers import hip_step, make_engine
         eng = make_engine(scene, distn, n, variant=variant)
         eng.set_option("ray_precision", 2)
         assert eng.info().raycast_variant == variant
         outs[variant] = hip_step(eng, st)
+        if variant == 3:
+            src16, _ = _rays_vs_oracle(eng, maps, True, f"{label} as shipped")
         eng.close()
     for k in outs[3]:
         np.testing.assert_array_equal(outs[3][k], outs[2][k], err_msg=f"{label} as shipped: {k}, culled vs every-triangle kernel")
     want16 = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp16_as_shipped")
-    for k in ("ray_dist", "wheel_dist", "body_dist"):
-        bad = float((outs[3][k] != want16[k]).mean())
-        assert bad < 2e-3, f"{label} as shipped: {k}: {bad:.4%} of the rays differ from the oracle's fp16 mode"
-    assert float((outs[3]["reset_buf"] != want16["reset_buf"]).mean()) < 2e-3
-    assert float((outs[3]["rock_collision"] != want16["rock_collision"]).mean()) < 2e-3
+    moved16 = (src16[:, 26:].view(np.uint32) != want16["ray_sources"].reshape(src16[:, 26:].shape).view(np.uint32)).any(axis=2)
+    bad = {k: float((outs[3][k] != want16[k]).mean()) for k in ("ray_dist", "wheel_dist", "body_dist")}
+    f_reset = float((outs[3]["reset_buf"] != want16["reset_buf"]).mean())
+    f_coll = float((outs[3]["rock_collision"] != want16["rock_collision"]).mean())
+    print(f"[{label} as shipped] whole step vs the oracle: {moved16.mean():.4%} of the terrain ray origins round to another fp16 value; "
+          f"distances that differ: {bad}; reset flags {f_reset:.5%}, collision flags {f_coll:.5%}")
+    for k, v in bad.items():
+        assert v <= b["rays16"], f"{label} as shipped: {k}: {v:.4%} of the rays differ from the oracle's fp16 mode"
+    assert f_reset <= b["flags16"] and f_coll <= b["flags16"]
     np.testing.assert_array_equal(outs[3]["progress_buf"], want16["progress_buf"])
     return got
 

@@ -287,6 +287,74 @@ def test_culled_raycast_changes_no_bit(k, cells):
         assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
+@pytest.mark.parametrize("k,cells,rays", [(200, 96, "120"), (200, 96, "37"), (40, 96, "120"), (255, 48, "37"), (8, 64, "9")])
+def test_staged_raycast_changes_no_bit(k, cells, rays):
+    """The staged kernel (variant 4: lane = (ray, chunk of 16 pairs) over LDS-staged per-cell record rows, fp16 records relative to the
+    cell, suffix bounds every 16 pairs) against the binned kernel with its early out off — every triangle evaluated — on the batch of
+    test_culled_raycast_changes_no_bit: steep tilts, arbitrary orientations, rays in facet planes, poses far outside the map, NaN."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import synth
+    n = 3000
+    scene = synth.make_scene(n_cells=cells, k=k, n_stones=40)
+    distn = synth.ray_distribution(rays)
+    st = synth.make_states(n, cells * 0.1, seed=78)
+    g = torch.Generator().manual_seed(5)
+    st["quat"] = synth.quat_from_euler(0.5 * torch.randn(n, generator=g), 0.5 * torch.randn(n, generator=g), 3.0 * torch.randn(n, generator=g))
+    st["quat"][0:600] = synth.quat_from_euler(0.08 * torch.randn(600, generator=g), 0.08 * torch.randn(600, generator=g), 3.0 * torch.randn(600, generator=g))
+    q = torch.randn(1000, 4, generator=g)
+    st["quat"][1000:2000] = q / q.norm(dim=1, keepdim=True)
+    axis = torch.tensor([[1.0, 0, 0, 0], [0.70710678, 0.70710678, 0, 0], [0.70710678, 0, 0.70710678, 0], [0, 1.0, 0, 0]])
+    st["quat"][2000:2900] = axis[torch.randint(0, 4, (900,), generator=g)]
+    st["pos"][2000:2900, 0:2] = torch.round(st["pos"][2000:2900, 0:2] * 20) / 20
+    st["pos"][2900:2950] *= 1.0e4
+    st["pos"][2950:2960] = float("nan")
+    st["pos"][2960:2970, 2] += 500.0
+    eng = make_engine(scene, distn, n, variant=2)
+    eng.set_option("raycast_early_out", 0)
+    ref = hip_step(eng, st)
+    eng.close()
+    eng = make_engine(scene, distn, n, variant=4)
+    assert eng.info().raycast_variant == 4
+    got = hip_step(eng, st)
+    got2 = hip_step(eng, st)
+    ci = eng.cull_info()
+    eng.close()
+    for key in ref:
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+        np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} (second step)")
+    assert ci["rays"] == n * (distn[0].shape[0] + 26)
+    assert (ref["ray_dist"] < 11.0).mean() > 0.3
+
+
+@pytest.mark.parametrize("seed,k,coarse,fine", [(1, 200, 1.2, 0.0375), (2, 64, 3.0, 0.05)])
+def test_staged_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine):
+    """The same on irregular meshes (needles, flanks, always-candidate triangles, cells without a cone: rays off the cone path take
+    every pair of their cell as a candidate)."""
+    from hip_helpers import hip_step, make_engine
+    from isaac_rover_amd import _lib, assets, synth
+    n = 3000
+    spec = synth.IrregularSpec(extent_x=12.0, extent_y=12.0, n_rocks=24, seed=seed, coarse=coarse, fine=fine)
+    tool = _lib.Engine(8, device=0)
+    scene, zf = assets.build_irregular_scene(tool, spec, k)
+    tool.close()
+    distn = synth.ray_distribution("120" if seed != 2 else "37")
+    st = synth.make_states(n, 12.0, seed=80 + seed, heightfn=zf, margin_m=1.0)
+    g = torch.Generator().manual_seed(seed)
+    st["quat"][1000:2000] = synth.quat_from_euler(0.5 * torch.randn(1000, generator=g), 0.5 * torch.randn(1000, generator=g), 3.0 * torch.randn(1000, generator=g))
+    st["pos"][2900:2950] *= 1.0e4
+    st["pos"][2950:2960] = float("nan")
+    eng = make_engine(scene, distn, n, variant=2)
+    eng.set_option("raycast_early_out", 0)
+    ref = hip_step(eng, st)
+    eng.close()
+    eng = make_engine(scene, distn, n, variant=4)
+    assert eng.info().raycast_variant == 4
+    got = hip_step(eng, st)
+    eng.close()
+    for key in ref:
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+
+
 @pytest.mark.parametrize("name,precision", [("step_irregular_p37_fp32", 0), ("step_irregular_native_fp32", 0),
                                             ("step_e32_p37_k200_fp32", 0), ("step_irregular_p37_fp16_as_shipped", 2),
                                             ("step_e32_p37_k200_fp16_as_shipped", 2)])
@@ -973,6 +1041,51 @@ def test_get_collisions_matches_the_reference(precision, name):
                 assert float((d > TOL_RAY).mean()) <= RAY_FLIP_BUDGET, f"v{variant}: {(d > TOL_RAY).mean():.4%} of rays differ"
         eng.close()
     assert (fx["out_wheel_dist"] < 11.0).any()
+
+
+@pytest.mark.parametrize("precision,name", [(0, "step_e64_p37_fp32"), (2, "step_e64_p37_fp16_as_shipped"),
+                                            (0, "step_irregular_p37_fp32"), (2, "step_irregular_p37_fp16_as_shipped"),
+                                            (0, "step_e32_p37_k200_fp32"), (0, "step_lattice_fp32")])
+def test_ray_phase_on_exported_and_supplied_rays(precision, name):
+    """`rover_export_rays` / `rover_cast_rays`: the device's own rays of a step through the oracle's per-ray arithmetic
+    (ray_casting.py:34-59, cell lookup camera.py:233-264, min over K) give the device's distances BIT FOR BIT in every ray-cast kernel
+    and either arithmetic — the comparison that does not depend on the pose trigonometry; and the same rays handed back through
+    `rover_cast_rays` reproduce them."""
+    from hip_helpers import hip_step, make_engine
+    from oracle import oracle as orc
+    fx = load_golden(name)
+    scene = scene_for(fx)
+    distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
+    st = states_of(fx)
+    e = st["pos"].shape[0]
+    t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
+    r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
+    for variant in (3, 2, 1) if precision == 0 else (3, 2):
+        eng = make_engine(scene, distn, e, variant=variant)
+        eng.set_option("ray_precision", precision)
+        got = hip_step(eng, st)
+        src, dirs, cell, dist = eng.export_rays()
+        torch.cuda.synchronize()
+        s_, d_, dist_ = src.cpu().numpy(), dirs.cpu().numpy(), dist.cpu().numpy()
+        np.testing.assert_array_equal(dist_[:, 26:], got["ray_dist"])
+        np.testing.assert_array_equal(dist_[:, :24], got["wheel_dist"])
+        want = np.concatenate((orc.raycast_unit(r, s_[:, :26], d_[:, :26], half=precision == 2).reshape(e, 26),
+                               orc.raycast_unit(t, s_[:, 26:], d_[:, 26:], half=precision == 2).reshape(e, -1)), axis=1)
+        np.testing.assert_array_equal(dist_.view(np.uint32), want.view(np.uint32), err_msg=f"{name} v{variant}")
+        again = eng.cast_rays(src, dirs)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(again.cpu().numpy().view(np.uint32), dist_.view(np.uint32), err_msg=f"{name} v{variant} cast_rays")
+        # supplied rays that are not a step's: every ray of env 0 given to every env, shifted by the env's index in x
+        s2 = src[0:1].repeat(e, 1, 1).clone(); d2 = dirs[0:1].repeat(e, 1, 1).clone()
+        s2[:, :, 0] += (torch.arange(e, device=src.device, dtype=torch.float32) * 0.0371)[:, None]
+        if precision == 2:
+            s2 = s2.half().float()
+        got2 = eng.cast_rays(s2.contiguous(), d2.contiguous()).cpu().numpy()
+        s2n, d2n = s2.cpu().numpy(), d2.cpu().numpy()
+        want2 = np.concatenate((orc.raycast_unit(r, s2n[:, :26], d2n[:, :26], half=precision == 2).reshape(e, 26),
+                                orc.raycast_unit(t, s2n[:, 26:], d2n[:, 26:], half=precision == 2).reshape(e, -1)), axis=1)
+        np.testing.assert_array_equal(got2.view(np.uint32), want2.view(np.uint32), err_msg=f"{name} v{variant} supplied rays")
+        eng.close()
 
 
 def test_quat_to_euler_and_ackermann():

@@ -48,6 +48,23 @@ KERNEL(k_v_fma_f32, VDECL, REP8(V8("v_fma_f32")), VSINK)
                              OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8"                        \
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
 KERNEL(k_v_add_f32, VDECL, REP8(V8M("v_add_f32")), VSINK)
+// v_fma_mix_f32 with an fp16 first source (low half), f32 second / third: what a lane-per-ray sphere test on fp16 records issues
+#define V8X asm volatile("v_fma_mix_f32 %0, %8, -1.0, %0 op_sel_hi:[1,0,0]\nv_fma_mix_f32 %1, %8, -1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"   \
+                         "v_fma_mix_f32 %2, %8, -1.0, %2 op_sel_hi:[1,0,0]\nv_fma_mix_f32 %3, %8, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"   \
+                         "v_fma_mix_f32 %4, %8, -1.0, %4 op_sel_hi:[1,0,0]\nv_fma_mix_f32 %5, %8, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"   \
+                         "v_fma_mix_f32 %6, %8, -1.0, %6 op_sel_hi:[1,0,0]\nv_fma_mix_f32 %7, %8, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"     \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+KERNEL(k_v_fma_mix_f32, VDECL, REP8(V8X), VSINK)
+// v_addc_co_u32 x, vcc, x, x, vcc: shift a compare result into a per-lane bit mask
+#define V8C asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc\nv_addc_co_u32 %1, vcc, %1, %1, vcc\nv_addc_co_u32 %2, vcc, %2, %2, vcc\nv_addc_co_u32 %3, vcc, %3, %3, vcc\n" \
+                         "v_addc_co_u32 %4, vcc, %4, %4, vcc\nv_addc_co_u32 %5, vcc, %5, %5, vcc\nv_addc_co_u32 %6, vcc, %6, %6, vcc\nv_addc_co_u32 %7, vcc, %7, %7, vcc"   \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");
+KERNEL(k_v_addc, VDECL, REP8(V8C), VSINK)
+// a compare writing VCC followed by the addc that consumes it (the pair as the mask build issues it)
+#define V8CC asm volatile("v_cmp_gt_f32 vcc, %0, %8\nv_addc_co_u32 %1, vcc, %1, %1, vcc\nv_cmp_gt_f32 vcc, %2, %8\nv_addc_co_u32 %3, vcc, %3, %3, vcc\n"     \
+                          "v_cmp_gt_f32 vcc, %4, %8\nv_addc_co_u32 %5, vcc, %5, %5, vcc\nv_cmp_gt_f32 vcc, %6, %8\nv_addc_co_u32 %7, vcc, %7, %7, vcc"       \
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");
+KERNEL(k_cmp_addc, VDECL, REP8(V8CC), VSINK)
 KERNEL(k_v_mul_f32, VDECL, REP8(V8M("v_mul_f32")), VSINK)
 KERNEL(k_v_min_f32, VDECL, REP8(V8M("v_min_f32")), VSINK)
 KERNEL(k_v_and_b32, VDECL, REP8(V8M("v_and_b32")), VSINK)
@@ -114,6 +131,9 @@ int main(int argc, char** argv) {
     const Case cases[] = {
         {"v_fma_f32", k_v_fma_f32, 64, "wave64 f32 FMA"},
         {"v_add_f32", k_v_add_f32, 64, "wave64 f32 add"},
+        {"v_fma_mix_f32", k_v_fma_mix_f32, 64, "mixed-precision FMA, fp16 first source"},
+        {"v_addc_co_u32", k_v_addc, 64, "add with carry in / out through VCC"},
+        {"cmp_addc", k_cmp_addc, 64, "v_cmp_gt_f32 vcc + v_addc_co_u32 pairs, counted as 2"},
         {"v_mul_f32", k_v_mul_f32, 64, "wave64 f32 multiply"},
         {"v_min_f32", k_v_min_f32, 64, "wave64 f32 min"},
         {"v_and_b32", k_v_and_b32, 64, "wave64 32-bit integer / logic"},
