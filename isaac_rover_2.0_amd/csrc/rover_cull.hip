@@ -971,8 +971,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
 #define LN_CH 16u                    // pairs per chunk (one 256-byte piece of a cell's record row; one 16-bit candidate mask)
 #define LN_MAXCH 8u                  // chunks per row at most (K8 <= 256: 128 pairs)
 #define LN_LVL 9u                    // float4 per cell of the level table: header {Cx, Cy, z_c, q16} + 8 levels {G, z0, z1, rho_out}
-#define LN_SLOTS 16u                 // chunk slots of a wave's staging area (4 KB)
-#define LN_WIN 8u                    // a staging pass takes the bins whose first chunk index lies in a window of 8: 8 + 8 <= 16 slots
 #define LN_QCAP 1024u                // 2-byte queue entries per wave
 
 __device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v >= 0, finite or +inf)
@@ -1180,15 +1178,13 @@ __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, cons
         const uint4 *__restrict__ lrec, const uint2 *__restrict__ lid, const RawTri *__restrict__ rtab, uint32_t pp, uint32_t run,            \
         uint32_t n_blocks, uint32_t t8, uint32_t chs, float *__restrict__ out, uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
 
-template <int H>
+template <int H, int DIAG>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
-    __shared__ uint4 s_stage[LN_SLOTS * LN_CH];           // staged chunks: 16 slots x 16 pair records
-    __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, slot base, -}
+    __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, byte offset of the cell's record row, -}
     __shared__ uint16_t s_items[64 * LN_MAXCH];           // ray | chunk << 6
     __shared__ uint16_t s_cand[64 * LN_MAXCH];            // candidate mask of (ray, chunk): bit 15 - i = pair i of the chunk
     __shared__ uint16_t s_q[LN_QCAP];                     // ray | pair position << 6
     __shared__ uint32_t s_bk[64];
-    __shared__ uint32_t s_csrc[LN_SLOTS];                 // byte offset in lrec of the chunk staged in each slot
     const uint32_t lane = threadIdx.x, x = blockIdx.x & 7u, qx = blockIdx.x >> 3, w = qx & 3u, j = qx >> 2;
     const uint32_t lb = chs == 31u ? x * t8 + j : ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u));
     if (j >= t8 || lb >= n_blocks) return;
@@ -1197,7 +1193,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     if (i0 >= n_sorted) return;
     const uint32_t n_run = min(run, n_sorted - i0), nch = pp / LN_CH;
     const bool act = lane < n_run;
-    const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    const uint64_t t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t gid = sorted[i0 + (act ? lane : n_run - 1u)];
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid)[0], rsb = reinterpret_cast<const float4*>(rays + gid)[1];
     const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w);
@@ -1230,11 +1226,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     if (allc) L = nch;
     if (!act) L = 0u;
     const uint32_t n_items = allc ? 0u : L;
-    // (diagnostic build of the library's own: ROVER_LANE_DIAG=1 prints where a wave's time goes — launch_raycast_lane)
+    // (diagnostic of the library's own: ROVER_LANE_DIAG=1 prints where a wave's time goes — launch_raycast_lane)
     uint64_t tq = 0;
     uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto lap = [&](int k) { if (diag) { const uint64_t n = __builtin_amdgcn_s_memtime(); dg[k] += (uint32_t)(n - tq); tq = n; } };
-    if (diag) {
+    auto lap = [&](int k) { if (DIAG) { const uint64_t n = __builtin_amdgcn_s_memtime(); dg[k] += (uint32_t)(n - tq); tq = n; } };
+    if (DIAG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
         dg[5] = (uint32_t)(tq - t_start);
@@ -1242,34 +1238,78 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
             const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && (allc ? 9u : L) == v));
             if (lane == 0u && cnt) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + v, cnt);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tq = __builtin_amdgcn_s_memtime();
     }
-    // bins of the run, the chunks each stages (the largest need of its rays), staging passes
+    // The items, in the order bin by bin, chunk by chunk, the bin's rays that test the chunk: lanes that read the same 256 bytes of a
+    // record row sit next to each other.  Position of item (ray, k) = items of the bins before + items of the bin's chunks before k + the
+    // ray's rank among the bin's rays with more than k items.
     const uint32_t prevc = (uint32_t)__shfl_up((int)cell, 1, 64);
     const bool head = act && (lane == 0u || cell != prevc);
     const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
-    const uint64_t le = (2ull << lane) - 1ull;                                // bits 0..lane
+    const uint64_t lt = (1ull << lane) - 1ull, le = (lt << 1) | 1ull;         // bits below / up to this lane
     const uint64_t below = heads & le, above = heads & ~le;
     const uint32_t lo = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u, hi = above ? (uint32_t)__builtin_ctzll(above) : n_run;
     const uint64_t binmask = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-    uint32_t need = 0;
-#pragma unroll
-    for (uint32_t v = 1; v <= LN_MAXCH; ++v) need += (__builtin_amdgcn_ballot_w64(n_items >= v) & binmask) ? 1u : 0u;     // (rays that test nothing stage nothing)
-    if (!act) need = 0u;
-    const uint32_t hc = head ? need : 0u;
-    const uint32_t cb_incl = wave_incl_scan(hc, lane);
-    const uint32_t cb = (uint32_t)__shfl((int)(cb_incl - hc), (int)lo, 64);   // first chunk index of this lane's bin
-    const uint32_t pl = cb / LN_WIN, sb = cb - pl * LN_WIN;                    // staging pass and slot base of the bin
-    const uint32_t last_pass = (uint32_t)__builtin_amdgcn_readlane((int)pl, (int)(n_run - 1u));
-    const uint32_t it_incl = wave_incl_scan(n_items, lane), it_pre = it_incl - n_items;
+    const uint32_t it_incl = wave_incl_scan(n_items, lane);
+    const uint32_t it_tot = (uint32_t)__builtin_amdgcn_readlane((int)it_incl, 63);
+    const uint32_t bin_base = (uint32_t)__shfl((int)(it_incl - n_items), (int)lo, 64);
     wave_lds_sync();
     s_ray[2u * lane] = make_float4(sx, sy, sz, rsb.x);
-    s_ray[2u * lane + 1u] = make_float4(rsb.y, rsb.z, __uint_as_float(sb), 0.0f);
+    s_ray[2u * lane + 1u] = make_float4(rsb.y, rsb.z, __uint_as_float(cell * pp * 16u), 0.0f);      // (tables stay below 4 GB: rover_set_knn_map checks)
+    {
+        uint32_t off = bin_base;
 #pragma unroll
-    for (uint32_t k = 0; k < LN_MAXCH; ++k)
-        if (k < n_items) s_items[it_pre + k] = (uint16_t)(lane | (k << 6));
-    uint32_t cused = 0, ctot = 0, n_flush = 0, n_passes = 0;
+        for (uint32_t k = 0; k < LN_MAXCH; ++k) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64(n_items > k) & binmask;
+            if (k < n_items) s_items[off + (uint32_t)__builtin_popcountll(m & lt)] = (uint16_t)(lane | (k << 6));
+            off += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    uint32_t cused = 0, ctot = 0, n_flush = 0;
+    wave_lds_sync();
     lap(0);
-    const uint32_t rowb = cell * pp * 16u;                                    // byte offset of the cell's record row (tables stay below 4 GB)
+    // the tests: 64 items per round, the records straight from the cell's row (L1 / L2: a chunk is read by the bin's rays side by side)
+    for (uint32_t base = 0; base < it_tot; base += 64u) {
+        const bool ok = base + lane < it_tot;
+        const uint32_t it = s_items[ok ? base + lane : 0u];
+        const uint32_t rl = it & 63u, ch = it >> 6;
+        const float4 ra = s_ray[2u * rl], rb = s_ray[2u * rl + 1u];
+        const uint4* cp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lrec) + __float_as_uint(rb.z)) + ch * LN_CH;
+        uint32_t mask = 0;
+#pragma unroll 1                                                // (unrolled, the compiler keeps all sixteen in flight: 128 VGPRs and spills)
+        for (uint32_t hf = 0; hf < 2u; ++hf) {                  // eight records in flight, twice
+        uint4 rec[LN_CH / 2u];
+#pragma unroll
+        for (uint32_t i = 0; i < LN_CH / 2u; ++i) rec[i] = cp[hf * (LN_CH / 2u) + i];
+#pragma unroll
+        for (uint32_t i = 0; i < LN_CH / 2u; ++i) {
+            const uint4 r = rec[i];
+            uint32_t sg;
+            {
+                const float hx = mix_rsub<0>(r.x, ra.x), hy = mix_rsub<1>(r.x, ra.y), hz = mix_rsub<0>(r.y, ra.z);
+                float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
+                float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
+                float u = mix_fms_hi(qq, c_a, r.y);
+                u = __builtin_fmaf(-t, t, u);
+                sg = __float_as_uint(u);
+            }
+            {
+                const float hx = mix_rsub<0>(r.z, ra.x), hy = mix_rsub<1>(r.z, ra.y), hz = mix_rsub<0>(r.w, ra.z);
+                float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
+                float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
+                float u = mix_fms_hi(qq, c_a, r.w);
+                u = __builtin_fmaf(-t, t, u);
+                sg |= __float_as_uint(u);
+            }
+            mask = __builtin_amdgcn_alignbit(mask, sg, 31);       // (mask << 1) | sign: a pair is a candidate unless both u >= +0
+        }
+        }
+        if (ok) s_cand[rl * LN_MAXCH + ch] = (uint16_t)mask;
+    }
+    wave_lds_sync();
+    lap(2);
+    // candidates -> queue entries; the exact phase whenever the queue could not take the next ray's entries (rare) and at the end
     auto flush = [&]() {
         wave_lds_sync();
         lap(3);
@@ -1280,85 +1320,22 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         wave_lds_sync();
         lap(4);
     };
-    for (uint32_t p = 0; p <= last_pass; ++p) {
-        const bool mine = act && pl == p;
-        const uint64_t pm = __builtin_amdgcn_ballot_w64(mine);
-        if (!pm) continue;
-        const uint32_t f = (uint32_t)__builtin_ctzll(pm), l_end = 64u - (uint32_t)__builtin_clzll(pm);      // the pass's rays [f, l_end)
-        ++n_passes;
-        // stage the pass's chunks
-        if (head && mine) {
-#pragma unroll
-            for (uint32_t k = 0; k < LN_MAXCH; ++k)
-                if (k < need) s_csrc[sb + k] = rowb + k * (LN_CH * 16u);
-        }
-        const uint32_t nslots = (uint32_t)__builtin_amdgcn_readlane((int)(sb + need), (int)(l_end - 1u));
-        const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)sb, (int)f);                       // (the slots below belong to the pass before)
-        wave_lds_sync();
-#pragma unroll
-        for (uint32_t i = 0; i < LN_SLOTS / 4u; ++i) {
-            const uint32_t c = 4u * i + (lane >> 4);
-            if (c >= slot0 && c < nslots) {
-                const char* src = reinterpret_cast<const char*>(lrec) + s_csrc[c] + ((lane & 15u) << 4);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)&s_stage[i * 64u], 16, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_sync();
-        lap(1);
-        // the pass's items, 64 per round
-        const uint32_t it0 = (uint32_t)__builtin_amdgcn_readlane((int)it_pre, (int)f);
-        const uint32_t it1 = (uint32_t)__builtin_amdgcn_readlane((int)it_incl, (int)(l_end - 1u));
-        for (uint32_t base = it0; base < it1; base += 64u) {
-            const bool ok = base + lane < it1;
-            const uint32_t it = s_items[ok ? base + lane : it0];
-            const uint32_t rl = it & 63u, ch = it >> 6;
-            const float4 ra = s_ray[2u * rl], rb = s_ray[2u * rl + 1u];
-            const uint4* cp = &s_stage[(__float_as_uint(rb.z) + ch) * LN_CH];
-            uint32_t mask = 0;
-#pragma unroll 4
-            for (uint32_t i = 0; i < LN_CH; ++i) {
-                const uint4 r = cp[i];
-                uint32_t sg;
-                {
-                    const float hx = mix_rsub<0>(r.x, ra.x), hy = mix_rsub<1>(r.x, ra.y), hz = mix_rsub<0>(r.y, ra.z);
-                    float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
-                    float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
-                    float u = mix_fms_hi(qq, c_a, r.y);
-                    u = __builtin_fmaf(-t, t, u);
-                    sg = __float_as_uint(u);
-                }
-                {
-                    const float hx = mix_rsub<0>(r.z, ra.x), hy = mix_rsub<1>(r.z, ra.y), hz = mix_rsub<0>(r.w, ra.z);
-                    float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
-                    float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
-                    float u = mix_fms_hi(qq, c_a, r.w);
-                    u = __builtin_fmaf(-t, t, u);
-                    sg |= __float_as_uint(u);
-                }
-                mask = __builtin_amdgcn_alignbit(mask, sg, 31);       // (mask << 1) | sign: a pair is a candidate unless both u >= +0
-            }
-            if (ok) s_cand[rl * LN_MAXCH + ch] = (uint16_t)mask;
-        }
-        wave_lds_sync();
-        lap(2);
-        // candidates -> queue entries, for the pass's rays
+    {
         uint32_t cm[LN_MAXCH], cnt = 0;
 #pragma unroll
         for (uint32_t k = 0; k < LN_MAXCH; ++k) {
             uint32_t m = 0;
-            if (mine && k < L) m = allc ? 0xffffu : (uint32_t)s_cand[lane * LN_MAXCH + k];
+            if (act && k < L) m = allc ? 0xffffu : (uint32_t)s_cand[lane * LN_MAXCH + k];
             cm[k] = m; cnt += (uint32_t)__builtin_popcount(m);
         }
         const uint32_t e_incl = wave_incl_scan(cnt, lane), e_pre = e_incl - cnt;
-        uint32_t r_lo = f;
+        uint32_t r_lo = 0;
         for (;;) {
             const uint32_t base_e = (uint32_t)__builtin_amdgcn_readlane((int)e_pre, (int)r_lo);
-            const uint64_t fm = __builtin_amdgcn_ballot_w64(mine && lane >= r_lo && e_incl - base_e <= LN_QCAP - cused);
+            const uint64_t fm = __builtin_amdgcn_ballot_w64(act && lane >= r_lo && e_incl - base_e <= LN_QCAP - cused);
             if (!fm) { flush(); continue; }                    // (an empty queue takes any one ray: <= 128 entries)
             const uint32_t r_hi = 64u - (uint32_t)__builtin_clzll(fm);
-            if (mine && lane >= r_lo && lane < r_hi) {
+            if (act && lane >= r_lo && lane < r_hi) {
                 uint32_t at = cused + (e_pre - base_e);
 #pragma unroll
                 for (uint32_t k = 0; k < LN_MAXCH; ++k) {
@@ -1371,7 +1348,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
                 }
             }
             cused += (uint32_t)__builtin_amdgcn_readlane((int)e_incl, (int)(r_hi - 1u)) - base_e;
-            if (r_hi >= l_end) break;
+            if (r_hi >= n_run) break;
             r_lo = r_hi;
             flush();
         }
@@ -1386,9 +1363,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         const uint32_t n_askip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u) & am);
         const uint32_t n_fskip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !allc && 2u * L <= nch) & am);
         const uint32_t n_bins = (uint32_t)__builtin_popcountll(heads);
-        const uint32_t it_tot = (uint32_t)__builtin_amdgcn_readlane((int)it_incl, 63);
-        if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins | (it_tot << 8) | (n_passes << 20) | (n_flush << 26));
-        if (diag && lane == 0u) {
+        if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins | (it_tot << 8) | (n_flush << 26));
+        if (DIAG && lane == 0u) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) diag[(size_t)wave * 8u + k] = dg[k];
         }
@@ -1562,9 +1538,9 @@ hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
     const uint32_t waves = g.n_blocks * 4u;
     if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 16u) * sizeof(uint32_t)); diag_waves = waves; }
     if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 16u) * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(lane_scan_kernel<0>, dim3(g.t8 * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted, a.n_sorted, a.lvl, a.lrec, a.lid,
-                       reinterpret_cast<const RawTri*>(a.rtab), a.pp, g.run, g.n_blocks, g.t8, g.chs, a.out, a.stats, k2, CullK<0>::c_a,
-                       want_diag ? d_diag : nullptr);
+    hipLaunchKernelGGL((want_diag && d_diag ? lane_scan_kernel<0, 1> : lane_scan_kernel<0, 0>), dim3(g.t8 * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted,
+                       a.n_sorted, a.lvl, a.lrec, a.lid, reinterpret_cast<const RawTri*>(a.rtab), a.pp, g.run, g.n_blocks, g.t8, g.chs, a.out, a.stats, k2,
+                       CullK<0>::c_a, want_diag ? d_diag : nullptr);
     if (want_diag && d_diag && diag_left > 0) {      // where a wave's time goes: mean shader-clock cycles per wave and phase (synchronises: a diagnostic)
         --diag_left;
         std::vector<uint32_t> h((size_t)waves * 8u + 16u);
@@ -1572,7 +1548,7 @@ hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t i = 0; i < (size_t)waves * 8u; ++i) sum[i & 7u] += h[i];
             const uint32_t* hg = h.data() + (size_t)waves * 8u;
-            fprintf(stderr, "lane_scan_kernel, %u waves, mean cycles per wave: prologue loads %.0f | bins/scans %.0f | staging wait %.0f | items %.0f | entries %.0f | exact %.0f"
+            fprintf(stderr, "lane_scan_kernel, %u waves, mean cycles per wave: prologue loads %.0f | bins/scans %.0f | (unused) %.0f | items %.0f | entries %.0f | exact %.0f"
                     " ; rays by level 0..8: %u %u %u %u %u %u %u %u %u, untested (all pairs candidates): %u\n", waves,
                     sum[5] / waves, sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves, hg[0], hg[1], hg[2], hg[3], hg[4], hg[5], hg[6], hg[7], hg[8], hg[9]);
         }
