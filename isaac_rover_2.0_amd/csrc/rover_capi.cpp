@@ -34,10 +34,9 @@ struct rover_ctx {
     uint32_t* cull_qrow[2]{nullptr, nullptr};
     uint64_t cull_bytes[2]{0, 0};
     // tables of the staged ray cast (variant 4; f32 proof): per cell the pair records in group-bound order, their ids, the suffix bounds
-    float4* lane_lvl[2]{nullptr, nullptr};
-    uint4* lane_rec[2]{nullptr, nullptr};
-    uint2* lane_id[2]{nullptr, nullptr};
+    LaneTables lane[2]{}, lane_h[2]{};  // per map: f32 proof / as-shipped fp16 proof
     uint32_t lane_pp[2]{0, 0};
+    int lane_rocks = -1;                // variant 4: the rocks part of the sorted list through the staged kernel too: -1 auto, 0 / 1 (option "lane_rocks", ROVER_LANE_ROCKS)
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
     uint4* d_cull_stats = nullptr;      // per-wave counters of the last culled launch (rover_get_cull_info)
@@ -176,6 +175,7 @@ static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_env
 // measurement, when the ray cast behind the sort was the every-triangle kernel.)
 #define ROVER_AUTO_CULL_RAYS_F32 49152u
 #define ROVER_AUTO_CULL_RAYS_F16 24576u
+#define ROVER_AUTO_LANE_RAYS 393216u
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
@@ -184,8 +184,13 @@ static int effective_variant(const rover_ctx* c) {
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
-    // variant 4 (staged): the terrain part of the sorted list through lane_scan_kernel, the rocks part through the culled kernel; f32 proof only
-    if (c->variant == 4 && c->lane_rec[0] && c->precision != 2) return 4;
+    // variant 4 (staged, rover_cull.hip: lane = (ray, chunk of 16 pairs) over per-cell record rows): either arithmetic, each with its
+    // proof's tables.  Auto (measured on MI355X, 37 + 26 rays, K = 200, one call per size, whole step in M env-steps/s, culled / staged):
+    // f32 65 536 envs 121 / 132, 32 768: 98 / 110, 16 384: 72 / 78, 8 192: 55 / 58, 4 096: 40 / 40, 2 048: 27 / 25; 120 + 26 rays 56.5 / 68.2;
+    // the native 1 634 + 26 rays at 4 096 envs 4.63 / 5.47, at 512 envs 2.64 / 2.36; irregular mesh 81 / 100.  As shipped (fp16 proof: a
+    // third of the rays lie off their cell's narrow cone and test every pair both ways) 89.8 / 81.4: stays on the culled kernel.
+    const bool v4_ok = c->lane[0].lrec && c->lane[1].lrec && c->lane_h[0].lrec && c->lane_h[1].lrec;
+    if (v4_ok && (c->variant == 4 || (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) >= ROVER_AUTO_LANE_RAYS))) return 4;
     return 3;
 }
 
@@ -417,6 +422,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
+    if (const char* v = getenv("ROVER_LANE_ROCKS")) c->lane_rocks = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 4) ? x : 0; }
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
@@ -437,7 +443,7 @@ void rover_destroy(rover_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->cfg.device);
     for (int w = 0; w < 2; ++w) { uint16_t* t = const_cast<uint16_t*>(c->map[w].table); dfree(t); dfree(c->cull_idx[w]); dfree(c->cull_ctab[w]); dfree(c->cull_rtab[w]); dfree(c->cull_qrow[w]); dfree(c->cull_ctab_h[w]); dfree(c->cull_qrow_h[w]); dfree(c->cull_far[w]); dfree(c->cull_far_h[w]);
-                                  dfree(c->lane_lvl[w]); dfree(c->lane_rec[w]); dfree(c->lane_id[w]); }
+                                  dfree(c->lane[w].lvl); dfree(c->lane[w].lrec); dfree(c->lane[w].lid); dfree(c->lane_h[w].lvl); dfree(c->lane_h[w].lrec); dfree(c->lane_h[w].lid); }
     dfree(c->d_dist); dfree(c->d_obs_idx);
     { float* h = const_cast<float*>(c->hf.hm); dfree(h); }
     dfree(c->d_stones);
@@ -490,7 +496,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     uint32_t *d_qrow = nullptr, *d_qrow_h = nullptr;
     float4 *d_far = nullptr, *d_far_h = nullptr;
     float* d_nz = nullptr;
-    float4* d_llvl = nullptr; uint4* d_lrec = nullptr; uint2* d_lid = nullptr;
+    LaneTables lt{}, lth{};
     const uint32_t lane_pp = lane_pairs_per_row(K8);
     uint32_t* d_cnt = nullptr;
     uint32_t h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -500,7 +506,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         const uint64_t b_idx = n_cells * K8 * sizeof(int32_t);
         uint32_t T_int = 0;
         auto drop = [&]() { cleanup(); dfree(d_cidx); dfree(d_ctab); dfree(d_ctab_h); dfree(d_rtab); dfree(d_qrow); dfree(d_qrow_h); dfree(d_far); dfree(d_far_h); dfree(d_nz); dfree(d_cnt);
-                            dfree(d_order); dfree(d_newid); dfree(d_table); dfree(d_llvl); dfree(d_lrec); dfree(d_lid); };
+                            dfree(d_order); dfree(d_newid); dfree(d_table); dfree(lt.lvl); dfree(lt.lrec); dfree(lt.lid); dfree(lth.lvl); dfree(lth.lrec); dfree(lth.lid); };
         // internal triangle numbering (spatial partners get ids 2p, 2p + 1, pairs ordered along a Morton curve): cull_numbering()
         std::vector<uint32_t> order, newid((size_t)T);
         {
@@ -518,10 +524,9 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         T_int = (uint32_t)order.size();
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
-        const uint64_t b_lane = n_cells * (9ull * sizeof(float4) + (uint64_t)lane_pp * (sizeof(uint4) + sizeof(uint2)));
-        // (the staged kernel addresses a cell's record row by a 32-bit byte offset)
-        const bool lane_fits = n_cells * (uint64_t)lane_pp * sizeof(uint4) < 0xffffffffull;
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u + (lane_fits ? b_lane : 0);
+        const uint64_t b_lane = n_cells * ((uint64_t)lane_lvl_stride() * sizeof(float4) + (uint64_t)lane_pp * (2 * sizeof(uint4) + sizeof(uint2)));
+        const bool lane_fits = true;
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u + (lane_fits ? 2 * b_lane : 0);
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
@@ -533,14 +538,15 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = hipMemcpy(d_order, order.data(), (uint64_t)T_int * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemset(d_cnt, 0, 8 * sizeof(uint32_t))) != hipSuccess ||
+            (lane_fits && ((e = hipMalloc((void**)&lt.lvl, n_cells * (uint64_t)lane_lvl_stride() * sizeof(float4))) != hipSuccess ||
+                           (e = hipMalloc((void**)&lt.lrec, n_cells * 2ull * lane_pp * sizeof(uint4))) != hipSuccess ||
+                           (e = hipMalloc((void**)&lt.lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess ||
+                           (e = hipMalloc((void**)&lth.lvl, n_cells * (uint64_t)lane_lvl_stride() * sizeof(float4))) != hipSuccess ||
+                           (e = hipMalloc((void**)&lth.lrec, n_cells * 2ull * lane_pp * sizeof(uint4))) != hipSuccess ||
+                           (e = hipMalloc((void**)&lth.lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess)) ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
                                    d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
-                                   shift_x, shift_y, nullptr)) != hipSuccess ||
-            (lane_fits && ((e = hipMalloc((void**)&d_llvl, n_cells * 9ull * sizeof(float4))) != hipSuccess ||
-                           (e = hipMalloc((void**)&d_lrec, n_cells * (uint64_t)lane_pp * sizeof(uint4))) != hipSuccess ||
-                           (e = hipMalloc((void**)&d_lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess ||
-                           (e = launch_lane_build(d_cidx, d_ctab, n_cells, K8, (uint32_t)Y, cell, shift_x, shift_y, d_qrow, d_llvl, d_lrec, d_lid,
-                                                  nullptr)) != hipSuccess)) ||
+                                   shift_x, shift_y, lt, lth, nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
             drop();
@@ -556,8 +562,9 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
     dfree(old);
     dfree(c->cull_idx[which]); dfree(c->cull_ctab[which]); dfree(c->cull_rtab[which]); dfree(c->cull_qrow[which]);
     dfree(c->cull_ctab_h[which]); dfree(c->cull_qrow_h[which]); dfree(c->cull_far[which]); dfree(c->cull_far_h[which]);
-    dfree(c->lane_lvl[which]); dfree(c->lane_rec[which]); dfree(c->lane_id[which]);
-    c->lane_lvl[which] = d_llvl; c->lane_rec[which] = d_lrec; c->lane_id[which] = d_lid; c->lane_pp[which] = lane_pp;
+    dfree(c->lane[which].lvl); dfree(c->lane[which].lrec); dfree(c->lane[which].lid);
+    dfree(c->lane_h[which].lvl); dfree(c->lane_h[which].lrec); dfree(c->lane_h[which].lid);
+    c->lane[which] = lt; c->lane_h[which] = lth; c->lane_pp[which] = lane_pp;
     c->cull_far[which] = d_far; c->cull_far_h[which] = d_far_h;
     c->cull_idx[which] = d_cidx; c->cull_ctab[which] = d_ctab; c->cull_rtab[which] = d_rtab; c->cull_qrow[which] = d_qrow; c->cull_bytes[which] = cull_bytes;
     c->cull_ctab_h[which] = d_ctab_h; c->cull_qrow_h[which] = d_qrow_h;
@@ -746,16 +753,36 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
 static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
     const uint32_t E = (uint32_t)c->cfg.num_envs;
     if (variant == 4) {
-        // the terrain rays (the first E x P of the sorted list: terrain bins sort first) through the staged kernel, the rock rays through the culled one
-        CullArgs a = cull_args(c, n_valid);
         LaneArgs l{};
-        l.rays = c->d_rays; l.sorted = c->d_sorted; l.n_sorted = a.n_terrain < n_valid ? a.n_terrain : n_valid;
-        l.lvl = c->lane_lvl[0]; l.lrec = c->lane_rec[0]; l.lid = c->lane_id[0]; l.rtab = c->cull_rtab[0]; l.pp = c->lane_pp[0];
-        l.run = 64u; l.out = c->d_dist_out; l.stats = c->d_cull_stats;
-        HIP_TRY(c, launch_raycast_lane(l, s));
-        a.sorted += l.n_sorted; a.n_sorted -= l.n_sorted; a.n_terrain = 0;
-        a.stats += lane_waves(l.n_sorted, l.run);
-        if (a.n_sorted) HIP_TRY(c, launch_raycast_culled(a, s));
+        l.rays = c->d_rays; l.sorted = c->d_sorted; l.n_sorted = n_valid; l.n_terrain = E * (uint32_t)c->P;
+        const bool lh = c->precision == 2;
+        for (int w = 0; w < 2; ++w) {
+            const LaneTables& t = lh ? c->lane_h[w] : c->lane[w];
+            l.lvl[w] = t.lvl; l.lrec[w] = t.lrec; l.lid[w] = t.lid; l.rtab[w] = c->cull_rtab[w]; l.pp[w] = c->lane_pp[w];
+        }
+        {
+            const CullProofH ph = cull_proof_h(c->cull_eta_h);
+            l.half = lh ? 1 : 0; l.c_a_h = ph.c_a; l.k2_far = cull_far_k2(l.half, ph);
+        }
+        l.run = effective_run(c); l.out = c->d_dist_out; l.stats = c->d_cull_stats;
+        // The rocks part too?  On a regular rocks mesh no: its rays are few per bin and a tenth of them lie off every cone (the horizontal body
+        // rays, which test every pair of their cell both ways) — the staged kernel reads a cell's whole 3.5 KB row for one such ray where the
+        // culled kernel reads 800 bytes of ids (65 536 envs: 440 us in one launch against 259 + 137).  On an irregular rocks mesh — most cells
+        // without a usable far bound — yes (555 us against 327 + 270).
+        const bool rocks_too = c->lane_rocks < 0 ? 2 * c->cull_farok[1] < c->cull_cells[1] : c->lane_rocks != 0;
+        if (rocks_too) {
+            HIP_TRY(c, launch_raycast_lane(l, s));
+        } else {
+            // the terrain rays (the first E x P of the sorted list: terrain bins sort first) through the staged kernel, the rock rays — few per
+            // bin, a tenth of them off every cone (the horizontal body rays) — through the culled one, which reads 800 bytes of ids per bin
+            // where the staged kernel reads the 3.5 KB of a cell's whole row for one such ray
+            CullArgs a = cull_args(c, n_valid);
+            l.n_sorted = l.n_terrain < n_valid ? l.n_terrain : n_valid;
+            HIP_TRY(c, launch_raycast_lane(l, s));
+            a.sorted += l.n_sorted; a.n_sorted -= l.n_sorted; a.n_terrain = 0;
+            a.stats += lane_waves(l.n_sorted, l.run);
+            if (a.n_sorted) HIP_TRY(c, launch_raycast_culled(a, s));
+        }
     } else if (variant == 3)
         HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));
     else if (variant == 2)
@@ -1374,6 +1401,11 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 4) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned), 3 (culled) or 4 (staged)");
         c->variant = (int)value;
         return alloc_cull_queue(c);
+    }
+    if (!strcmp(name, "lane_rocks")) {
+        if (value < -1 || value > 1) return fail(c, ROVER_E_INVALID, "lane_rocks must be -1 (auto), 0 or 1");
+        c->lane_rocks = (int)value;
+        return ROVER_OK;
     }
     if (!strcmp(name, "ray_precision")) {
         if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "ray_precision must be 0 (fp32), 1 (fp16 sources) or 2 (as shipped)");

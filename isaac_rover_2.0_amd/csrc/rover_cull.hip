@@ -36,6 +36,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
+#include <type_traits>
 #include "rover_internal.h"
 #include "rover_raymath.h"
 
@@ -488,11 +489,7 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
         const uint32_t id0 = en.x & CULL_NOID, id1 = en.y & CULL_NOID;
         const RawTri* rt = map ? rtab1 : rtab0;
         const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
-#ifdef ROVER_SEQ_RAYS
-        const uint32_t g = gid + pos;                                   // (gid: the run's first sorted position, wave-uniform)
-#else
         const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
-#endif
         const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
         if (base + 64u < n) en_next = entry(min(base + 64u + lane, n - 1u));
@@ -592,13 +589,7 @@ template <int HI> __device__ __forceinline__ f2 pk_fma_s(f2 a, sgpr2 s, f2 c) { 
 // LAZY: the far pairs of a bin (slot 1) are gathered and unpacked only if one of its rays tests them — a second, dependent round of
 // gathers in the bins that do, half the set-up in the bins that do not (most of them when a bin holds few rays).
 template <int H, int LAZY, int SKIPT>
-#ifndef ROVER_CULL_WAVES
-#define ROVER_CULL_WAVES 6
-#endif
-#ifndef ROVER_CULL_LCAP_LAZY
-#define ROVER_CULL_LCAP_LAZY 512u
-#endif
-__global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS) {
+__global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS) {
     const float k_ca = H ? c_a_h : CullK<0>::c_a, k_tau2 = H ? tau2_h : CullK<0>::tau2;      // (f32 proof: compile-time constants)
     // The id rows of a run's bins travel HBM -> LDS CULL_RING bins ahead of their use (global_load_lds: no registers, one
     // exposed memory latency per run instead of one per bin); s_bk: the run's 64 running minima as ordered-u32 keys.
@@ -608,16 +599,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
     // them back without a round trip through memory, and phase 1 does not wait for the acknowledgement of 8-byte stores scattered over
     // 120 MB.  What does not fit goes to the wave's global region as before.  (Sized so that the LDS never caps the waves the registers
     // allow: 6 per SIMD x 4.25 + 4 KB, 7 x 4.25 + 3 KB.)
-    constexpr uint32_t LCAP = LAZY ? ROVER_CULL_LCAP_LAZY : 384u;
+    constexpr uint32_t LCAP = LAZY ? 512u : 384u;
     static_assert(CULL_QCAP - LCAP <= CULL_QGLOBAL, "the global region holds what the LDS part does not");
     __shared__ uint2 s_lq[CULL_WPB][LCAP];
-    const uint32_t x = blockIdx.x & 7u, tw =
-#ifdef ROVER_DIAG_TW_OLD
-        threadIdx.x >> 6,
-#else
-        CULL_WPB == 1 ? 0u : threadIdx.x >> 6,
-#endif
-        lane = threadIdx.x & 63u;      // (one wave per workgroup: tw is a constant, and what derives from it — the queue region's address — is wave-uniform for the compiler too)
+    const uint32_t x = blockIdx.x & 7u, tw = CULL_WPB == 1 ? 0u : threadIdx.x >> 6, lane = threadIdx.x & 63u;      // (one wave per workgroup: tw is a constant, and what derives from it — the queue region's address — is wave-uniform for the compiler too)
     // this wave: wave w (0..3) of block slot jslot of XCD x
     const uint32_t qx = blockIdx.x >> 3, w = (qx % (4u / CULL_WPB)) * CULL_WPB + tw, jslot = qx / (4u / CULL_WPB);
     uint32_t* const bk = s_bk[tw];
@@ -671,11 +656,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
     // id rows ahead.
     // (through an opaque copy of the ray id: everything below is invariant across segments, and hoisted out of this loop by the
     //  compiler it would stay in registers through the scan AND the exact phase — 76 VGPRs instead of 62)
-#ifdef ROVER_SEQ_RAYS
-    uint32_t gid_s = i0 + (lane < n_run ? lane : n_run - 1u);
-#else
     uint32_t gid_s = gid;
-#endif
     asm volatile("" : "+v"(gid_s));
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid_s)[0], rsb = reinterpret_cast<const float4*>(rays + gid_s)[1];
     const uint32_t rflags = __float_as_uint(rsb.w);
@@ -740,11 +721,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
             const uint64_t above = live & (~1ull << lane);                 // (per lane)
             nxt = above ? (uint32_t)__builtin_ctzll(above) : lane;
         }
-#ifdef ROVER_SEQ_RAYS
-        const uint32_t gnx = i0 + nxt;
-#else
         const uint32_t gnx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)gid);
-#endif
         nxw = (gnx & 0x3fffffffu) | ((uint32_t)((conemask >> lane) & 1ull) << 31) | ((uint32_t)((farskip >> lane) & 1ull) << 30);
     }
     const uint64_t hm_all = (heads | (1ull << r_next)) & (~0ull << r_next);
@@ -775,19 +752,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
         if (pf_heads) prefetch_row();
     uint32_t cused = 0;
     auto load_ray = [&](uint32_t r, float4& a4, float4& b4) {       // wave-uniform address -> scalar loads
-#ifdef ROVER_SEQ_RAYS
-        const float4* rp = reinterpret_cast<const float4*>(rays + (i0 + r));
-#else
         const float4* rp = reinterpret_cast<const float4*>(rays + (uint32_t)__builtin_amdgcn_readlane((int)gid, (int)r));
-#endif
         a4 = rp[0]; b4 = rp[1];
     };
     float4 nxa, nxb;
     load_ray(live ? (uint32_t)__builtin_ctzll(live) : r_next, nxa, nxb);       // the segment's first live ray
     bool full = false;
-#ifdef ROVER_DIAG_NOSCAN
-    hm = 0;
-#endif
     while (hm && !full) {                      // one (map, cell) bin of the run: rays [i, i_end)
         const uint32_t i = (uint32_t)__builtin_ctzll(hm);
         hm &= hm - 1ull;
@@ -918,19 +888,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
     // The wait also retires id-row loads of bins this segment did not reach (the ring restarts with the next segment).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
-#ifdef ROVER_SEQ_RAYS
-    cull_exact<H>(rays, rtab0, rtab1, lq, LCAP, qw, cused, i0, lane, bk);
-#else
     cull_exact<H>(rays, rtab0, rtab1, lq, LCAP, qw, cused, gid, lane, bk);
-#endif
     ctot += cused;
     }
     wave_lds_sync();
-#ifdef ROVER_DIAG_SEQ_OUT
-    if (lane < n_run) out[i0 + lane] = funkey(bk[lane]) + __uint_as_float(gid & 1u);
-#else
     if (lane < n_run) out[gid] = funkey(bk[lane]);
-#endif
     // per-wave counters of THIS launch (plain stores, 16 B per wave; summed on the host by rover_get_cull_info)
     if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins);
     }
@@ -970,8 +932,23 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROVER_CULL_WAVES, 8))) __laun
 // ---------------------------------------------------------------------------------------------------
 #define LN_CH 16u                    // pairs per chunk (one 256-byte piece of a cell's record row; one 16-bit candidate mask)
 #define LN_MAXCH 8u                  // chunks per row at most (K8 <= 256: 128 pairs)
-#define LN_LVL 9u                    // float4 per cell of the level table: header {Cx, Cy, z_c, q16} + 8 levels {G, z0, z1, rho_out}
+#define LN_LVL 10u                   // float4 per cell of the level table: header {Cx, Cy, z_c, q16}, 8 levels {G, z0, z1, rho_out}, the levels' 8 x 16-bit cones
+// A pair with a triangle whose cone value (f32 proof: |N_z| / |N|; fp16 proof: the largest ray angle it admits, over pi / 2) is below this
+// is ordered in FRONT of the others, so that the suffixes keep a cone rays lie in (0: off.  Grid mesh: 0 / 0.25 / 0.35 / 0.5 -> ray cast 440 /
+// 440 / 440 / 494 us — at 0.5 half of the pairs of a bumpy heightfield are "steep" and every ray's prefix grows —; irregular mesh 811 / 559 / 560 us)
+#ifndef LN_QGOOD
+#define LN_QGOOD 0.3f
+#endif
+#ifndef LN_QGOOD_H
+#define LN_QGOOD_H 0.2f
+#endif                // a triangle whose normal is farther than 60 degrees from the vertical is ordered in front of the others (so that the suffixes keep a cone)
 #define LN_QCAP 1024u                // 2-byte queue entries per wave
+#ifndef LN_AB
+#define LN_AB 8u                     // pair records an item keeps in flight (test (A) only / tests (A) and (B): two records per pair)
+#endif
+#ifndef LN_ABB
+#define LN_ABB 4u
+#endif
 
 __device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v >= 0, finite or +inf)
     _Float16 h = (_Float16)v;
@@ -983,9 +960,11 @@ __device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v
 // one workgroup of 128 threads per cell, thread = source pair (idx4's (lane, slot)); see the header comment for the record
 __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict__ idx4, const uint4* __restrict__ ctab, uint32_t K8, uint32_t pp,
                                                          uint32_t Y, float cell_size, float shift_x, float shift_y, float k1, float tau2,
-                                                         double c_rho, const uint32_t* __restrict__ qrow, float4* __restrict__ lvl,
-                                                         uint4* __restrict__ lrec, uint2* __restrict__ lid) {
-    __shared__ float s_z0[128], s_z1[128], s_g[128], s_ro[128];
+                                                         double c_rho, const uint32_t* __restrict__ qrow, const float* __restrict__ nz_abs,
+                                                         float4* __restrict__ lvl, uint4* __restrict__ lrec, uint2* __restrict__ lid, int half,
+                                                         float q_good) {
+    __shared__ float s_z0[128], s_z1[128], s_g[128], s_ro[128], s_qn[128];
+    __shared__ uint4 s_nrec[128];
     __shared__ uint32_t s_key[128];
     __shared__ uint8_t s_src[128];
     __shared__ uint4 s_rec[128];
@@ -1018,11 +997,12 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
     const float zc = s_z0[0] <= s_z1[0] ? 0.5f * (s_z0[0] + s_z1[0]) : 0.0f;
     __syncthreads();
     // the pair's record
-    uint16_t hb[2][4];
-    float G = __builtin_inff(), pz0 = __builtin_inff(), pz1 = -__builtin_inff(), pro = 0.0f;
+    uint16_t hb[2][4], nb[2][4];
+    float G = __builtin_inff(), pz0 = __builtin_inff(), pz1 = -__builtin_inff(), pro = 0.0f, pq = 2.0f;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         hb[e][0] = hb[e][1] = hb[e][2] = 0; hb[e][3] = 0xfc00u;              // empty slot: r2 = -inf, never a candidate
+        nb[e][0] = nb[e][1] = nb[e][2] = 0; nb[e][3] = 0xfc00u;              // (test (B): (n . d)^2 - r2B with r2B = -inf holds too)
         if (id[e] < 0) continue;
         const f2 zn = cvt2(rec[e].z), w = cvt2(rec[e].w);
         const float mx = __uint_as_float(rec[e].x), my = __uint_as_float(rec[e].y), mz = zn.x;
@@ -1044,6 +1024,15 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
                 r2h = (float)__builtin_bit_cast(_Float16, r2b);
             }
         }
+        // test (B)'s record: the stored normal as it is (fp16) and r2B >= tau^2 |n|^2, what cull_scan_kernel compares (n . d)^2 with, rounded up
+        nb[e][3] = 0x7c00u;                                                    // always a candidate: (B) never holds
+        if (r2b != 0x7c00u) {
+            nb[e][0] = (uint16_t)(rec[e].z >> 16); nb[e][1] = (uint16_t)(rec[e].w & 0xffffu); nb[e][2] = (uint16_t)(rec[e].w >> 16);
+            // (the fp16 proof's (B) threshold is per triangle: r2 F, F = 1 + code / 512 from the centre's low mantissa bits, as cull_scan_kernel decodes it)
+            const float Fb = half ? 1.0f + (float)((rec[e].x & 63u) | ((rec[e].y & 63u) << 6)) * (1.0f / 512.0f) : 1.0f;
+            nb[e][3] = half_bits_up(r2c * Fb * 1.000001f);
+            pq = fminf(pq, nz_abs[id[e]]);                                     // |N_z| / |N| (rounded down) of the exact normal
+        }
         if (r2b != 0x7c00u) {
             const float dxy = sqrtf((float)hx * (float)hx + (float)hy * (float)hy);
             g = (dxy - k1 * sqrtf(r2h) * 1.00001f) * 0.99999f - 1.0e-6f;
@@ -1054,14 +1043,18 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
         hb[e][3] = r2b;
         G = fminf(G, g);
     }
-    // order the pairs by G (ascending; -inf = a pair that is always a candidate first, +inf = an empty pair last)
-    const uint32_t gb = __float_as_uint(G);
+    // order the pairs by G (ascending; -inf = a pair that is always a candidate first, +inf = an empty pair last); pairs with a
+    // steep triangle in front of the rest (their G counts as it is in the bounds: only the ORDER is forced)
+    const float Gs = (pq < q_good && G > -3.0e38f && G < 3.0e38f) ? -1.0e30f + G : G;
+    const uint32_t gb = __float_as_uint(Gs);
     s_key[p] = (gb & 0x80000000u) ? ~gb : (gb | 0x80000000u);
     s_src[p] = (uint8_t)p;
     s_rec[p] = make_uint4((uint32_t)hb[0][0] | ((uint32_t)hb[0][1] << 16), (uint32_t)hb[0][2] | ((uint32_t)hb[0][3] << 16),
                           (uint32_t)hb[1][0] | ((uint32_t)hb[1][1] << 16), (uint32_t)hb[1][2] | ((uint32_t)hb[1][3] << 16));
+    s_nrec[p] = make_uint4((uint32_t)nb[0][0] | ((uint32_t)nb[0][1] << 16), (uint32_t)nb[0][2] | ((uint32_t)nb[0][3] << 16),
+                           (uint32_t)nb[1][0] | ((uint32_t)nb[1][1] << 16), (uint32_t)nb[1][2] | ((uint32_t)nb[1][3] << 16));
     s_id[p] = make_uint2(id[0] >= 0 ? (uint32_t)id[0] : CULL_NOID, id[1] >= 0 ? (uint32_t)id[1] : CULL_NOID);
-    s_g[p] = G; s_z0[p] = pz0; s_z1[p] = pz1; s_ro[p] = pro;
+    s_g[p] = G; s_z0[p] = pz0; s_z1[p] = pz1; s_ro[p] = pro; s_qn[p] = pq;
     __syncthreads();
     for (uint32_t len = 2; len <= 128u; len <<= 1) {
         for (uint32_t stride = len >> 1; stride > 0; stride >>= 1) {
@@ -1075,22 +1068,34 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
             __syncthreads();
         }
     }
-    if (p < pp) {
+    if (p < pp) {       // a cell's row: the pp records of test (A), then the pp records of test (B)
         const uint32_t src = s_src[p];
-        lrec[(uint64_t)cell * pp + p] = s_rec[src];
+        lrec[(uint64_t)cell * 2u * pp + p] = s_rec[src];
+        lrec[(uint64_t)cell * 2u * pp + pp + p] = s_nrec[src];
         lid[(uint64_t)cell * pp + p] = s_id[src];
     }
     // levels: the bound of the suffix behind the first 16 j pairs
+    __shared__ uint32_t s_q16[LN_MAXCH];
     if (p < LN_MAXCH) {
-        float g = __builtin_inff(), z0 = __builtin_inff(), z1 = -__builtin_inff(), ro = 0.0f;
+        float g = __builtin_inff(), z0 = __builtin_inff(), z1 = -__builtin_inff(), ro = 0.0f, qn = 2.0f;
         for (uint32_t q = p * LN_CH; q < 128u; ++q) {
             const uint32_t src = s_src[q];
-            g = fminf(g, s_g[src]); z0 = fminf(z0, s_z0[src]); z1 = fmaxf(z1, s_z1[src]); ro = fmaxf(ro, s_ro[src]);
+            g = fminf(g, s_g[src]); z0 = fminf(z0, s_z0[src]); z1 = fmaxf(z1, s_z1[src]); ro = fmaxf(ro, s_ro[src]); qn = fminf(qn, s_qn[src]);
         }
         if (!(z0 <= z1)) { z0 = 0.0f; z1 = 0.0f; }
         lvl[(uint64_t)cell * LN_LVL + 1u + p] = make_float4(g, z0, z1, ro);
+        // the suffix's normal cone, as idx4_build_kernel encodes a cell's (an empty suffix, or one of always-candidates only — whose G is -inf
+        // anyway —: the widest)
+        uint32_t q16 = 0xfffeu;
+        if (qn <= 1.0f) { q16 = qn > 0.0f ? (uint32_t)floorf(qn * 65535.0f) : 0u; q16 = q16 > 0xfffeu ? 0xfffeu : q16; }
+        s_q16[p] = q16;
     }
-    if (p == 0) lvl[(uint64_t)cell * LN_LVL] = make_float4(ccx, ccy, zc, __uint_as_float(qrow[cell]));
+    __syncthreads();
+    if (p == 0) {
+        lvl[(uint64_t)cell * LN_LVL] = make_float4(ccx, ccy, zc, __uint_as_float(qrow[cell]));
+        lvl[(uint64_t)cell * LN_LVL + 9u] = make_float4(__uint_as_float(s_q16[0] | (s_q16[1] << 16)), __uint_as_float(s_q16[2] | (s_q16[3] << 16)),
+                                                        __uint_as_float(s_q16[4] | (s_q16[5] << 16)), __uint_as_float(s_q16[6] | (s_q16[7] << 16)));
+    }
 }
 
 // s - (fp16 half `HI` of `packed`), and a * b - (fp16 half of packed), in one v_fma_mix_f32 each
@@ -1115,29 +1120,48 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
+// (n . d)^2-side helpers of test (B) on a fp16 record: a * b + c with a = fp16 half `HI` of `packed`
+template <int HI> __device__ __forceinline__ float mix_mul(uint32_t packed, float b) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b));
+    else    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b));
+    return r;
+}
+template <int HI> __device__ __forceinline__ float mix_fma(uint32_t packed, float b, float c) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b), "v"(c));
+    else    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b), "v"(c));
+    return r;
+}
+
 // the exact phase on 2-byte entries {ray position | pair position << 6}: ids through the cell's id row, then as cull_exact
+// (cellm: per lane, the cell of run position `lane` with its map in bit 31)
 template <int H>
-__device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rt, const uint2* __restrict__ lid, uint32_t pp,
-                                           const uint16_t* q, uint32_t n, uint32_t gid, uint32_t cell, uint32_t lane, uint32_t* bk) {
+__device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rt0, const RawTri* __restrict__ rt1,
+                                           const uint2* __restrict__ lid0, const uint2* __restrict__ lid1, uint32_t pp01, const uint16_t* q, uint32_t n,
+                                           uint32_t gid, uint32_t cellm, uint32_t lane, uint32_t* bk) {
     if (n == 0u) return;
-    auto ids_of = [&](uint32_t i, uint32_t& pos) {
+    auto ids_of = [&](uint32_t i, uint32_t& pos, uint32_t& map) {
         const uint32_t e = q[min(i, n - 1u)];
         pos = e & 63u;
-        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)cell);
-        return lid[(uint64_t)c * pp + (e >> 6)];
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)cellm);
+        map = c >> 31;
+        const uint32_t pp = map ? pp01 >> 16 : pp01 & 0xffffu;
+        return (map ? lid1 : lid0)[(uint64_t)(c & 0x7fffffffu) * pp + (e >> 6)];
     };
-    uint32_t pos_next;
-    uint2 id_next = ids_of(lane, pos_next);
+    uint32_t pos_next, map_next;
+    uint2 id_next = ids_of(lane, pos_next, map_next);
     for (uint32_t base = 0; base < n; base += 64u) {
         const bool live = base + lane < n;
         const uint2 idp = id_next;
         const uint32_t pos = pos_next;
+        const RawTri* rt = map_next ? rt1 : rt0;
         const uint32_t id0 = idp.x, id1 = idp.y;
         const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
         const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
         const float4* rp = reinterpret_cast<const float4*>(rays + g);
         const float4 ra = rp[0], rb = rp[1];
-        if (base + 64u < n) id_next = ids_of(base + 64u + lane, pos_next);
+        if (base + 64u < n) id_next = ids_of(base + 64u + lane, pos_next, map_next);
         float best;
         if (H) {
             h2 v[9];
@@ -1174,58 +1198,78 @@ __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, cons
 }
 
 #define LANE_SCAN_ARGS                                                                                                                        \
-    const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const float4 *__restrict__ lvl,                  \
-        const uint4 *__restrict__ lrec, const uint2 *__restrict__ lid, const RawTri *__restrict__ rtab, uint32_t pp, uint32_t run,            \
-        uint32_t n_blocks, uint32_t t8, uint32_t chs, float *__restrict__ out, uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
+    const RayRec *__restrict__ rays, const uint32_t *__restrict__ sorted, uint32_t n_sorted, const float4 *__restrict__ lvl0,                 \
+        const float4 *__restrict__ lvl1, const uint4 *__restrict__ lrec0, const uint4 *__restrict__ lrec1, const uint2 *__restrict__ lid0,    \
+        const uint2 *__restrict__ lid1, const RawTri *__restrict__ rtab0, const RawTri *__restrict__ rtab1, uint32_t pp01, uint32_t run,      \
+        uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr, uint32_t run_r, float *__restrict__ out,                  \
+        uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
 
 template <int H, int DIAG>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
-    __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, byte offset of the cell's record row, -}
-    __shared__ uint16_t s_items[64 * LN_MAXCH];           // ray | chunk << 6
+    __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, the cell's record row (64-bit address)}
+    __shared__ uint16_t s_items[64 * LN_MAXCH];           // ray | chunk << 6: the items that run test (A) only, behind them the ones that run (A) and (B)
     __shared__ uint16_t s_cand[64 * LN_MAXCH];            // candidate mask of (ray, chunk): bit 15 - i = pair i of the chunk
     __shared__ uint16_t s_q[LN_QCAP];                     // ray | pair position << 6
     __shared__ uint32_t s_bk[64];
-    const uint32_t lane = threadIdx.x, x = blockIdx.x & 7u, qx = blockIdx.x >> 3, w = qx & 3u, j = qx >> 2;
-    const uint32_t lb = chs == 31u ? x * t8 + j : ((((j >> chs) << 3) + x) << chs) + (j & ((1u << chs) - 1u));
-    if (j >= t8 || lb >= n_blocks) return;
+    const uint32_t lane = threadIdx.x, x = blockIdx.x & 7u, qx = blockIdx.x >> 3, w = qx & 3u, jslot = qx >> 2;
+    // blocks [0, split): runs of `run` rays of the terrain part of the sorted list, then runs of `run_r` rays of the rocks part, dealt
+    // to the XCDs like cull_scan_kernel's (chunks of blocks round robin: neighbouring bins share an L2)
+    uint32_t lb;
+    const uint32_t chs = chsr & 0xffu, chr = chsr >> 8;
+    if (jslot < t8) {
+        lb = chs == 31u ? x * t8 + jslot : ((((jslot >> chs) << 3) + x) << chs) + (jslot & ((1u << chs) - 1u));
+        if (lb >= split) return;
+    } else {
+        const uint32_t jr = jslot - t8;
+        lb = split + (chr == 31u ? x * r8 + jr : ((((jr >> chr) << 3) + x) << chr) + (jr & ((1u << chr) - 1u)));
+        if (lb >= n_blocks) return;
+    }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(lb * 4u + w);
-    const uint32_t i0 = wave * run;
+    const uint32_t my_run = lb < split ? run : run_r;
+    const uint32_t i0 = lb < split ? wave * run : split * 4u * run + (wave - split * 4u) * run_r;
     if (i0 >= n_sorted) return;
-    const uint32_t n_run = min(run, n_sorted - i0), nch = pp / LN_CH;
+    const uint32_t n_run = min(my_run, n_sorted - i0);
     const bool act = lane < n_run;
     const uint64_t t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t gid = sorted[i0 + (act ? lane : n_run - 1u)];
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid)[0], rsb = reinterpret_cast<const float4*>(rays + gid)[1];
-    const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w);
-    const float4* lp = lvl + (uint64_t)cell * LN_LVL;
+    const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w), map = rflags & 1u;
+    const uint32_t pp = map ? pp01 >> 16 : pp01 & 0xffffu, nch = pp / LN_CH;
+    const float4* lp = (map ? lvl1 : lvl0) + (uint64_t)cell * LN_LVL;
     const float4 hdr = lp[0];
     float4 lv[LN_MAXCH];
 #pragma unroll
     for (int k = 0; k < (int)LN_MAXCH; ++k) lv[k] = lp[1 + k];
+    const float4 lq = lp[9];                                  // the suffixes' cones, 16 bits each
     s_bk[lane] = fkey(RAY_MISS);
-    // the ray relative to its cell; its level = the first suffix it clears
+    // the ray relative to its cell; its level = the first suffix it clears as a group: by distance (far_build_kernel's inequality on the
+    // suffix's bound) and, for test (B), by lying inside the suffix's normal cone
     const float sx = rsa.x - hdr.x, sy = rsa.y - hdr.y, sz = rsa.z - hdr.z;
     const bool tame = fabsf(sx) < 1.0e4f && fabsf(sy) < 1.0e4f && fabsf(sz) < 1.0e4f && fabsf(rsb.x) <= 2.0f && fabsf(rsb.y) <= 2.0f && fabsf(rsb.z) <= 2.0f;
-    const bool cone = __float_as_uint(hdr.w) >= (rflags >> 16);
+    const uint32_t rq = rflags >> 16;                         // the ray's own cone bound (0xffff: none)
+    const bool cone = __float_as_uint(hdr.w) >= rq;           // the whole cell's cone covers the ray: test (A) alone decides
     uint32_t L = nch;
     {
         const float o = __builtin_amdgcn_sqrtf(sx * sx + sy * sy);
         const float dxy2 = rsb.x * rsb.x + rsb.y * rsb.y, adz = fabsf(rsb.z), sq = __builtin_amdgcn_sqrtf(dxy2);
         const bool steep = adz * adz >= 0.81f * (dxy2 + adz * adz) * 1.0001f;
         const float dxy1 = sq * 1.0001f;
+        const uint32_t qw[4] = {__float_as_uint(lq.x), __float_as_uint(lq.y), __float_as_uint(lq.z), __float_as_uint(lq.w)};
 #pragma unroll
         for (int k = (int)LN_MAXCH - 1; k >= 0; --k) {
             const float dzm = fmaxf(fabsf(sz - lv[k].y), fabsf(sz - lv[k].z));
             const float e_adz = o * adz + dzm * sq * 1.0001f;
             const float amax = (dzm * adz + (o + lv[k].w) * dxy1) * 1.0001f;
             const bool clears = steep && (lv[k].x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * amax * adz) * 1.0001f;
-            if ((uint32_t)k < nch && clears) L = (uint32_t)k;
+            const uint32_t q16 = (k & 1) ? qw[k >> 1] >> 16 : qw[k >> 1] & 0xffffu;
+            if ((uint32_t)k < nch && clears && q16 >= rq) L = (uint32_t)k;
         }
     }
-    const bool allc = act && !(cone && tame);                 // every pair of the cell is a candidate, nothing is tested
+    const bool allc = act && !tame;                           // a wild ray: every pair of the cell is a candidate, nothing is tested
+    const bool ab = act && tame && !cone;                     // off the cell's cone: the prefix runs tests (A) and (B)
     if (allc) L = nch;
     if (!act) L = 0u;
-    const uint32_t n_items = allc ? 0u : L;
+    const uint32_t n_a = (act && !allc && !ab) ? L : 0u, n_b = ab ? L : 0u;
     // (diagnostic of the library's own: ROVER_LANE_DIAG=1 prints where a wave's time goes — launch_raycast_lane)
     uint64_t tq = 0;
     uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1234,86 +1278,109 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
         dg[5] = (uint32_t)(tq - t_start);
-        for (uint32_t v = 0; v < 10u; ++v) {                                                  // histogram of the rays' levels behind the per-wave rows
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && (allc ? 9u : L) == v));
+        for (uint32_t v = 0; v < 11u; ++v) {                                                  // histogram of the rays' levels behind the per-wave rows
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !map && (allc ? 9u : (ab ? 10u : L)) == v));
+            const uint32_t cnt1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && map && (allc ? 9u : (ab ? 10u : L)) == v));
             if (lane == 0u && cnt) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + v, cnt);
+            if (lane == 0u && cnt1) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + 12u + v, cnt1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
     }
     // The items, in the order bin by bin, chunk by chunk, the bin's rays that test the chunk: lanes that read the same 256 bytes of a
     // record row sit next to each other.  Position of item (ray, k) = items of the bins before + items of the bin's chunks before k + the
-    // ray's rank among the bin's rays with more than k items.
-    const uint32_t prevc = (uint32_t)__shfl_up((int)cell, 1, 64);
-    const bool head = act && (lane == 0u || cell != prevc);
+    // ray's rank among the bin's rays with more than k items.  Two lists: the (A) items, behind them the (A) + (B) items.
+    const uint32_t key = cell | (map << 31);
+    const uint32_t prevk = (uint32_t)__shfl_up((int)key, 1, 64);
+    const bool head = act && (lane == 0u || key != prevk);
     const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
     const uint64_t lt = (1ull << lane) - 1ull, le = (lt << 1) | 1ull;         // bits below / up to this lane
     const uint64_t below = heads & le, above = heads & ~le;
     const uint32_t lo = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u, hi = above ? (uint32_t)__builtin_ctzll(above) : n_run;
     const uint64_t binmask = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-    const uint32_t it_incl = wave_incl_scan(n_items, lane);
-    const uint32_t it_tot = (uint32_t)__builtin_amdgcn_readlane((int)it_incl, 63);
-    const uint32_t bin_base = (uint32_t)__shfl((int)(it_incl - n_items), (int)lo, 64);
+    const uint32_t ia_incl = wave_incl_scan(n_a, lane), ib_incl = wave_incl_scan(n_b, lane);
+    const uint32_t ia_tot = (uint32_t)__builtin_amdgcn_readlane((int)ia_incl, 63), ib_tot = (uint32_t)__builtin_amdgcn_readlane((int)ib_incl, 63);
+    const uint32_t base_a = (uint32_t)__shfl((int)(ia_incl - n_a), (int)lo, 64), base_b = ia_tot + (uint32_t)__shfl((int)(ib_incl - n_b), (int)lo, 64);
     wave_lds_sync();
-    s_ray[2u * lane] = make_float4(sx, sy, sz, rsb.x);
-    s_ray[2u * lane + 1u] = make_float4(rsb.y, rsb.z, __uint_as_float(cell * pp * 16u), 0.0f);      // (tables stay below 4 GB: rover_set_knn_map checks)
     {
-        uint32_t off = bin_base;
+        const char* rowp = reinterpret_cast<const char*>(map ? lrec1 : lrec0) + (uint64_t)cell * (2u * 16u) * pp;
+        const uint64_t ra64 = (uint64_t)reinterpret_cast<uintptr_t>(rowp);
+        s_ray[2u * lane] = make_float4(sx, sy, sz, rsb.x);
+        s_ray[2u * lane + 1u] = make_float4(rsb.y, rsb.z, __uint_as_float((uint32_t)ra64), __uint_as_float((uint32_t)(ra64 >> 32)));
+        uint32_t off_a = base_a, off_b = base_b;
 #pragma unroll
         for (uint32_t k = 0; k < LN_MAXCH; ++k) {
-            const uint64_t m = __builtin_amdgcn_ballot_w64(n_items > k) & binmask;
-            if (k < n_items) s_items[off + (uint32_t)__builtin_popcountll(m & lt)] = (uint16_t)(lane | (k << 6));
-            off += (uint32_t)__builtin_popcountll(m);
+            const uint64_t ma = __builtin_amdgcn_ballot_w64(n_a > k) & binmask, mb = __builtin_amdgcn_ballot_w64(n_b > k) & binmask;
+            if (k < n_a) s_items[off_a + (uint32_t)__builtin_popcountll(ma & lt)] = (uint16_t)(lane | (k << 6));
+            if (k < n_b) s_items[off_b + (uint32_t)__builtin_popcountll(mb & lt)] = (uint16_t)(lane | (k << 6));
+            off_a += (uint32_t)__builtin_popcountll(ma); off_b += (uint32_t)__builtin_popcountll(mb);
         }
     }
     uint32_t cused = 0, ctot = 0, n_flush = 0;
     wave_lds_sync();
     lap(0);
     // the tests: 64 items per round, the records straight from the cell's row (L1 / L2: a chunk is read by the bin's rays side by side)
-    for (uint32_t base = 0; base < it_tot; base += 64u) {
-        const bool ok = base + lane < it_tot;
-        const uint32_t it = s_items[ok ? base + lane : 0u];
-        const uint32_t rl = it & 63u, ch = it >> 6;
-        const float4 ra = s_ray[2u * rl], rb = s_ray[2u * rl + 1u];
-        const uint4* cp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lrec) + __float_as_uint(rb.z)) + ch * LN_CH;
-        uint32_t mask = 0;
+    auto rounds = [&](uint32_t it0, uint32_t it1, auto AB) {
+        constexpr bool kAB = decltype(AB)::value;
+        for (uint32_t base = it0; base < it1; base += 64u) {
+            const bool ok = base + lane < it1;
+            const uint32_t it = s_items[ok ? base + lane : it0];
+            const uint32_t rl = it & 63u, ch = it >> 6;
+            const float4 ra = s_ray[2u * rl], rb = s_ray[2u * rl + 1u];
+            const uint4* cp = reinterpret_cast<const uint4*>((uintptr_t)((uint64_t)__float_as_uint(rb.z) | ((uint64_t)__float_as_uint(rb.w) << 32))) + ch * LN_CH;
+            // (the (B) records of the row lie pp records behind the (A) records; pp by the map of the item's ray)
+            const uint32_t ppi = kAB ? ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rl << 2), (int)map) ? pp01 >> 16 : pp01 & 0xffffu) : 0u;
+            uint32_t mask = 0;
+            constexpr uint32_t NB = kAB ? LN_ABB : LN_AB;            // records in flight per batch
 #pragma unroll 1                                                // (unrolled, the compiler keeps all sixteen in flight: 128 VGPRs and spills)
-        for (uint32_t hf = 0; hf < 2u; ++hf) {                  // eight records in flight, twice
-        uint4 rec[LN_CH / 2u];
+            for (uint32_t hf = 0; hf < LN_CH / NB; ++hf) {
+                uint4 rec[NB], nrc[kAB ? NB : 1u];
 #pragma unroll
-        for (uint32_t i = 0; i < LN_CH / 2u; ++i) rec[i] = cp[hf * (LN_CH / 2u) + i];
+                for (uint32_t i = 0; i < NB; ++i) {
+                    rec[i] = cp[hf * NB + i];
+                    if (kAB) nrc[i] = cp[ppi + hf * NB + i];
+                }
 #pragma unroll
-        for (uint32_t i = 0; i < LN_CH / 2u; ++i) {
-            const uint4 r = rec[i];
-            uint32_t sg;
-            {
-                const float hx = mix_rsub<0>(r.x, ra.x), hy = mix_rsub<1>(r.x, ra.y), hz = mix_rsub<0>(r.y, ra.z);
-                float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
-                float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
-                float u = mix_fms_hi(qq, c_a, r.y);
-                u = __builtin_fmaf(-t, t, u);
-                sg = __float_as_uint(u);
+                for (uint32_t i = 0; i < NB; ++i) {
+                    const uint4 r = rec[i];
+                    uint32_t sg;
+                    {
+                        const float hx = mix_rsub<0>(r.x, ra.x), hy = mix_rsub<1>(r.x, ra.y), hz = mix_rsub<0>(r.y, ra.z);
+                        float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
+                        float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
+                        float u = mix_fms_hi(qq, c_a, r.y);
+                        u = __builtin_fmaf(-t, t, u);
+                        sg = __float_as_uint(u);
+                    }
+                    {
+                        const float hx = mix_rsub<0>(r.z, ra.x), hy = mix_rsub<1>(r.z, ra.y), hz = mix_rsub<0>(r.w, ra.z);
+                        float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
+                        float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
+                        float u = mix_fms_hi(qq, c_a, r.w);
+                        u = __builtin_fmaf(-t, t, u);
+                        sg |= __float_as_uint(u);
+                    }
+                    if (kAB) {      // (B): (n . d)^2 - r2B >= +0 for both triangles, or the pair stays a candidate
+                        const uint4 n = nrc[i];
+                        float t0 = mix_mul<0>(n.x, ra.w); t0 = mix_fma<1>(n.x, rb.x, t0); t0 = mix_fma<0>(n.y, rb.y, t0);
+                        float t1 = mix_mul<0>(n.z, ra.w); t1 = mix_fma<1>(n.z, rb.x, t1); t1 = mix_fma<0>(n.w, rb.y, t1);
+                        sg |= __float_as_uint(mix_fms_hi(t0, t0, n.y)) | __float_as_uint(mix_fms_hi(t1, t1, n.w));
+                    }
+                    mask = __builtin_amdgcn_alignbit(mask, sg, 31);       // (mask << 1) | sign: a pair is a candidate unless every u >= +0
+                }
             }
-            {
-                const float hx = mix_rsub<0>(r.z, ra.x), hy = mix_rsub<1>(r.z, ra.y), hz = mix_rsub<0>(r.w, ra.z);
-                float t = hx * ra.w; t = __builtin_fmaf(hy, rb.x, t); t = __builtin_fmaf(hz, rb.y, t);
-                float qq = hx * hx; qq = __builtin_fmaf(hy, hy, qq); qq = __builtin_fmaf(hz, hz, qq);
-                float u = mix_fms_hi(qq, c_a, r.w);
-                u = __builtin_fmaf(-t, t, u);
-                sg |= __float_as_uint(u);
-            }
-            mask = __builtin_amdgcn_alignbit(mask, sg, 31);       // (mask << 1) | sign: a pair is a candidate unless both u >= +0
+            if (ok) s_cand[rl * LN_MAXCH + ch] = (uint16_t)mask;
         }
-        }
-        if (ok) s_cand[rl * LN_MAXCH + ch] = (uint16_t)mask;
-    }
+    };
+    rounds(0u, ia_tot, std::false_type{});
+    if (ib_tot) rounds(ia_tot, ia_tot + ib_tot, std::true_type{});
     wave_lds_sync();
     lap(2);
     // candidates -> queue entries; the exact phase whenever the queue could not take the next ray's entries (rare) and at the end
     auto flush = [&]() {
         wave_lds_sync();
         lap(3);
-        lane_exact<H>(rays, rtab, lid, pp, s_q, cused, gid, cell, lane, s_bk);
+        lane_exact<H>(rays, rtab0, rtab1, lid0, lid1, pp01, s_q, cused, gid, key, lane, s_bk);
         ctot += cused;
         cused = 0;
         ++n_flush;
@@ -1359,11 +1426,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     if (act) out[gid] = funkey(s_bk[lane]);
     {
         const uint64_t am = n_run >= 64u ? ~0ull : ((1ull << n_run) - 1ull);
-        const uint32_t n_both = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(allc) & am);
+        const uint32_t n_both = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(allc || ab) & am);
         const uint32_t n_askip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u) & am);
         const uint32_t n_fskip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !allc && 2u * L <= nch) & am);
         const uint32_t n_bins = (uint32_t)__builtin_popcountll(heads);
-        if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins | (it_tot << 8) | (n_flush << 26));
+        if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins | ((ia_tot + ib_tot) << 8) | (n_flush << 26));
         if (DIAG && lane == 0u) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) diag[(size_t)wave * 8u + k] = dg[k];
@@ -1396,6 +1463,9 @@ float cull_far_k2(int half, CullProofH ph) {
     return k2;
 }
 
+uint32_t lane_pairs_per_row(uint32_t K8);
+static void lane_build(const int32_t* idx4, const uint4* ctab, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell_size, float shift_x, float shift_y,
+                       const uint32_t* qrow, const float* nz_abs, LaneTables t, int half, CullProofH ph, hipStream_t s);
 // T: the caller's triangle count (ids in map_idx); T_int: slots of the internal numbering (order [T_int], newid [T]).
 // ctab / qrow / far: the f32 proof's tables; ctab_h / qrow_h / far_h: the as-shipped fp16 arithmetic's (CullK<1>); idx4 and rtab serve both.
 hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const uint16_t* verts, uint64_t n_cells, uint32_t K,
@@ -1403,14 +1473,16 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
                              int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
                              float4* far_h, float* nz_scratch,
                              uint32_t* counts /* [5], zeroed: always-candidate triangles, cells without a cone; the same for fp16; cells with a useful far bound */,
-                             CullProofH ph, uint32_t Y, float cell_size, float shift_x, float shift_y, hipStream_t s) {
+                             CullProofH ph, uint32_t Y, float cell_size, float shift_x, float shift_y, LaneTables lane, LaneTables lane_h, hipStream_t s) {
     hipLaunchKernelGGL(rtab_build_kernel, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, tris, verts, T_int, V, order, rtab);
     hipLaunchKernelGGL(ctab_build_kernel<1>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab_h, nz_scratch, counts + 2, ph);
     hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, rtab, Y, cell_size,
                        shift_x, shift_y, idx4, qrow_h, counts + 2);
+    lane_build(idx4, ctab_h, n_cells, K8, Y, cell_size, shift_x, shift_y, qrow_h, nz_scratch, lane_h, 1, ph, s);      // (nz_scratch holds the fp16 proof's cone values here)
     hipLaunchKernelGGL(ctab_build_kernel<0>, dim3(blocks_for(T_int, 256)), dim3(256), 0, s, rtab, T_int, order, ctab, nz_scratch, counts, ph);
     hipLaunchKernelGGL(idx4_build_kernel, dim3((uint32_t)n_cells), dim3(256), 0, s, map_idx, K, K8, T, newid, nz_scratch, rtab, Y, cell_size,
                        shift_x, shift_y, idx4, qrow, counts);
+    lane_build(idx4, ctab, n_cells, K8, Y, cell_size, shift_x, shift_y, qrow, nz_scratch, lane, 0, ph, s);
     float k1, k2;
     cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
     hipLaunchKernelGGL(far_build_kernel, dim3(blocks_for(n_cells, 4)), dim3(256), 0, s, reinterpret_cast<const int4*>(idx4), ctab, n_cells, K8, Y,
@@ -1457,25 +1529,9 @@ static uint32_t cull_slots_per_launch(uint64_t entries) {
     return (uint32_t)(s < 1 ? 1 : (s > 0x7fffffffull ? 0x7fffffffull : s));
 }
 
-#ifdef ROVER_SEQ_RAYS
-__global__ void __launch_bounds__(256) diag_gather_rays_kernel(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted, uint32_t n,
-                                                               RayRec* __restrict__ out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float4* rp = reinterpret_cast<const float4*>(rays + sorted[i]);
-    const float4 a = rp[0], b = rp[1];
-    float4* o = reinterpret_cast<float4*>(out + i);
-    o[0] = a; o[1] = b;
-}
-#endif
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s) {
     const CullGrid g = cull_grid(a.n_sorted, a.n_terrain, a.run);
-#ifdef ROVER_SEQ_RAYS
-    static RayRec* d_seq = nullptr; static uint32_t seq_n = 0;
-    if (seq_n < a.n_sorted) { if (d_seq) (void)hipFree(d_seq); (void)hipMalloc((void**)&d_seq, (size_t)a.n_sorted * sizeof(RayRec)); seq_n = a.n_sorted; }
-    hipLaunchKernelGGL(diag_gather_rays_kernel, dim3(blocks_for(a.n_sorted, 256)), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted, d_seq);
-    a.rays = d_seq;
-#endif
+
     const uint32_t slots = g.t8 + g.r8;                              // block slots per XCD
     const uint32_t per = cull_slots_per_launch(a.queue_entries);
     // one launch, unless the queue regions of all slots exceed the budget the queue was sized for (huge batches): then slices
@@ -1513,14 +1569,16 @@ uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, u
 
 // ---- the staged ray cast (variant 4) ----
 uint32_t lane_pairs_per_row(uint32_t K8) { return ((K8 / 2u + LN_CH - 1u) / LN_CH) * LN_CH; }
+uint32_t lane_lvl_stride() { return LN_LVL; }
 
-hipError_t launch_lane_build(const int32_t* idx4, const uint4* ctab, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell_size, float shift_x,
-                             float shift_y, const uint32_t* qrow, float4* lvl, uint4* lrec, uint2* lid, hipStream_t s) {
+static void lane_build(const int32_t* idx4, const uint4* ctab, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell_size, float shift_x, float shift_y,
+                       const uint32_t* qrow, const float* nz_abs, LaneTables t, int half, CullProofH ph, hipStream_t s) {
+    if (!t.lrec) return;
     float k1, k2;
-    cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    if (half) cull_far_consts(ph.c_a, 1.004, &k1, &k2); else cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
     hipLaunchKernelGGL(lane_build_kernel, dim3((uint32_t)n_cells), dim3(128), 0, s, reinterpret_cast<const int4*>(idx4), ctab, K8, lane_pairs_per_row(K8),
-                       Y, cell_size, shift_x, shift_y, k1, CullK<0>::tau2, CullK<0>::c_rho, qrow, lvl, lrec, lid);
-    return hipGetLastError();
+                       Y, cell_size, shift_x, shift_y, k1, half ? ph.tau2 : CullK<0>::tau2, half ? ph.c_rho : CullK<0>::c_rho, qrow, nz_abs, t.lvl, t.lrec,
+                       t.lid, half, half ? LN_QGOOD_H : LN_QGOOD);
 }
 
 uint32_t lane_waves(uint32_t n_rays, uint32_t run) {
@@ -1530,27 +1588,36 @@ uint32_t lane_waves(uint32_t n_rays, uint32_t run) {
 
 hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
     if (a.n_sorted == 0u) return hipSuccess;
-    const CullGrid g = cull_grid(a.n_sorted, a.n_sorted, a.run);           // every block is a "terrain" block: runs of g.run
-    float k1, k2;
-    cull_far_consts(CullK<0>::c_a, 1.00001, &k1, &k2);
+    CullGrid g = cull_grid(a.n_sorted, a.n_terrain, a.run);
+    {   // the rocks part in runs as long as the terrain's (its waves are short anyway: most rock rays clear their whole cell: 440 -> 423 us)
+        g.run_r = g.run;
+        const uint64_t covered = (uint64_t)g.split * 4u * g.run;
+        g.n_blocks = covered >= a.n_sorted ? g.split : g.split + blocks_for(blocks_for(a.n_sorted - (uint32_t)covered, g.run_r), 4);
+        g.chr = 31u; g.r8 = blocks_for(g.n_blocks - g.split, 8);
+    }
+    const float k2 = a.k2_far, c_a = a.half ? a.c_a_h : CullK<0>::c_a;
     static const bool want_diag = getenv("ROVER_LANE_DIAG") != nullptr;
     static uint32_t* d_diag = nullptr; static uint32_t diag_waves = 0; static int diag_left = 3;
     const uint32_t waves = g.n_blocks * 4u;
-    if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 16u) * sizeof(uint32_t)); diag_waves = waves; }
-    if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 16u) * sizeof(uint32_t), s);
-    hipLaunchKernelGGL((want_diag && d_diag ? lane_scan_kernel<0, 1> : lane_scan_kernel<0, 0>), dim3(g.t8 * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted,
-                       a.n_sorted, a.lvl, a.lrec, a.lid, reinterpret_cast<const RawTri*>(a.rtab), a.pp, g.run, g.n_blocks, g.t8, g.chs, a.out, a.stats, k2,
-                       CullK<0>::c_a, want_diag ? d_diag : nullptr);
+    if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 32u) * sizeof(uint32_t)); diag_waves = waves; }
+    if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 32u) * sizeof(uint32_t), s);
+    auto kern = a.half ? lane_scan_kernel<1, 0> : (want_diag && d_diag ? lane_scan_kernel<0, 1> : lane_scan_kernel<0, 0>);
+    hipLaunchKernelGGL(kern, dim3((g.t8 + g.r8) * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted,
+                       a.n_sorted, a.lvl[0], a.lvl[1], a.lrec[0], a.lrec[1], a.lid[0], a.lid[1], reinterpret_cast<const RawTri*>(a.rtab[0]),
+                       reinterpret_cast<const RawTri*>(a.rtab[1]), a.pp[0] | (a.pp[1] << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8),
+                       g.run_r, a.out, a.stats, k2, c_a, (want_diag && !a.half) ? d_diag : nullptr);
     if (want_diag && d_diag && diag_left > 0) {      // where a wave's time goes: mean shader-clock cycles per wave and phase (synchronises: a diagnostic)
         --diag_left;
-        std::vector<uint32_t> h((size_t)waves * 8u + 16u);
+        std::vector<uint32_t> h((size_t)waves * 8u + 32u);
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), d_diag, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t i = 0; i < (size_t)waves * 8u; ++i) sum[i & 7u] += h[i];
             const uint32_t* hg = h.data() + (size_t)waves * 8u;
-            fprintf(stderr, "lane_scan_kernel, %u waves, mean cycles per wave: prologue loads %.0f | bins/scans %.0f | (unused) %.0f | items %.0f | entries %.0f | exact %.0f"
-                    " ; rays by level 0..8: %u %u %u %u %u %u %u %u %u, untested (all pairs candidates): %u\n", waves,
-                    sum[5] / waves, sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves, hg[0], hg[1], hg[2], hg[3], hg[4], hg[5], hg[6], hg[7], hg[8], hg[9]);
+            fprintf(stderr, "lane_scan_kernel, %u waves, mean ticks per wave: prologue loads %.0f | bins/scans %.0f | items %.0f | entries %.0f | exact %.0f"
+                    " ; terrain rays by level 0..8: %u %u %u %u %u %u %u %u %u, wild (all pairs candidates): %u, off the cone (tests A and B): %u"
+                    " ; rock rays: %u %u %u %u %u %u %u %u %u, wild %u, off the cone %u\n", waves,
+                    sum[5] / waves, sum[0] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves, hg[0], hg[1], hg[2], hg[3], hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10],
+                    hg[12], hg[13], hg[14], hg[15], hg[16], hg[17], hg[18], hg[19], hg[20], hg[21], hg[22]);
         }
     }
     return hipGetLastError();

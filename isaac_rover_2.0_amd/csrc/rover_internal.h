@@ -59,6 +59,8 @@ struct PrepArgs {
 struct CullProofH { double kappa, c_rho; float c_a, tau2; };
 CullProofH cull_proof_h(double eta);
 
+struct LaneTables { float4* lvl; uint4* lrec; uint2* lid; };      // the staged ray cast's tables of one map for one proof (null: not built)
+
 // raycast_culled_kernel (rover_cull.hip)
 struct CullArgs {
     const RayRec* rays;
@@ -82,23 +84,24 @@ struct CullArgs {
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
-// the staged ray cast (raycast variant 4, rover_cull.hip): lane = (ray, chunk of 16 pairs) over per-cell record rows staged in LDS; one map per launch
+// the staged ray cast (raycast variant 4, rover_cull.hip): lane = (ray, chunk of 16 pairs) over per-cell record rows in group-bound order
 struct LaneArgs {
     const RayRec* rays;
-    const uint32_t* sorted;      // the part of the sorted list that belongs to the map
-    uint32_t n_sorted;
-    const float4* lvl;           // [cell][9]: header + 8 suffix bounds
-    const uint4* lrec;           // [cell][pp]: pair records in G order
-    const uint2* lid;            // [cell][pp]: the pairs' triangle ids
-    const uint16_t* rtab;
-    uint32_t pp, run;
+    const uint32_t* sorted;
+    uint32_t n_sorted, n_terrain;
+    const float4* lvl[2];        // per map [cell][10]: header, 8 suffix bounds, the suffixes' cones
+    const uint4* lrec[2];        // [cell][2][pp]: pair records of test (A), then of test (B), in G order
+    const uint2* lid[2];         // [cell][pp]: the pairs' triangle ids
+    const uint16_t* rtab[2];
+    uint32_t pp[2], run;
     float* out;
     uint4* stats;
+    int half;                    // the tables are the as-shipped fp16 arithmetic's, the exact phase runs it
+    float c_a_h, k2_far;         // test (A)'s constant of that proof; the level bound's ray-side constant (cull_far_k2)
 };
 uint32_t lane_pairs_per_row(uint32_t K8);
+uint32_t lane_lvl_stride();
 uint32_t lane_waves(uint32_t n_rays, uint32_t run);
-hipError_t launch_lane_build(const int32_t* idx4, const uint4* ctab, uint64_t n_cells, uint32_t K8, uint32_t Y, float cell_size, float shift_x,
-                             float shift_y, const uint32_t* qrow, float4* lvl, uint4* lrec, uint2* lid, hipStream_t s);
 hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s);
 uint64_t cull_queue_entries(uint64_t n_rays, uint32_t n_terrain, uint32_t run, uint64_t budget_bytes, uint32_t* n_launches);
 
@@ -225,7 +228,7 @@ hipError_t launch_cull_build(const int32_t* map_idx, const int32_t* tris, const 
                              uint32_t K8, uint32_t T, uint32_t T_int, uint32_t V, const uint32_t* order, const uint32_t* newid,
                              int32_t* idx4, uint4* ctab, uint4* ctab_h, uint16_t* rtab, uint32_t* qrow, uint32_t* qrow_h, float4* far,
                              float4* far_h, float* nz_scratch, uint32_t* counts, CullProofH ph, uint32_t Y, float cell_size, float shift_x,
-                             float shift_y, hipStream_t s);
+                             float shift_y, LaneTables lane, LaneTables lane_h, hipStream_t s);
 float cull_far_k2(int half, CullProofH ph);
 hipError_t launch_raycast_culled(CullArgs a, hipStream_t s);
 hipError_t launch_knn_centroids(const float* verts, const int32_t* tris, uint32_t T, uint32_t V, int ref, float* cx, float* cy,

@@ -35,7 +35,7 @@ def test_full_size_invariants(full):
     a = _run(scene, distn, st, variant=3)
     # (1) three independent ray-cast algorithms (culled: conservative sphere / normal test + exact candidates; binned:
     #     register-resident cells, every triangle evaluated; env-order streaming) agree bit for bit
-    for other in (2, 1):
+    for other in (4, 2, 1):
         b = _run(scene, distn, st, variant=other)
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} vs variant {other}")
@@ -267,7 +267,7 @@ def _all_envs_vs_oracle(scene, distn, st, label, budget=None):
     assert f_reset <= b["flags32"] and f_coll <= b["flags32"]
 
     outs = {}
-    for variant in (3, 2):
+    for variant in (4, 3, 2):
         eng = make_engine(scene, distn, n, variant=variant)
         eng.set_option("ray_precision", 2)
         assert eng.info().raycast_variant == variant
@@ -277,6 +277,7 @@ def _all_envs_vs_oracle(scene, distn, st, label, budget=None):
         eng.close()
     for k in outs[3]:
         np.testing.assert_array_equal(outs[3][k], outs[2][k], err_msg=f"{label} as shipped: {k}, culled vs every-triangle kernel")
+        np.testing.assert_array_equal(outs[4][k], outs[2][k], err_msg=f"{label} as shipped: {k}, staged vs every-triangle kernel")
     want16 = orc.step(t, r, st, *distn, num_envs_global=n, precision="fp16_as_shipped")
     moved16 = (src16[:, 26:].view(np.uint32) != want16["ray_sources"].reshape(src16[:, 26:].shape).view(np.uint32)).any(axis=2)
     bad = {k: float((outs[3][k] != want16[k]).mean()) for k in ("ray_dist", "wheel_dist", "body_dist")}

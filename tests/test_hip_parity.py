@@ -210,7 +210,7 @@ def test_odd_shapes_match_oracle(num_envs, n_x, n_y, k_t, k_r, dist_name, shift)
     r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices, shift=shift[0:2])
     want = orc.step(t, r, st, *distn)
     results = []
-    for variant in (3, 2, 1):
+    for variant in (4, 3, 2, 1):
         eng = _lib.Engine(num_envs, device=0)
         eng.set_scene(scene, distn)
         eng.set_option("raycast_variant", variant)
@@ -287,72 +287,74 @@ def test_culled_raycast_changes_no_bit(k, cells):
         assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
-@pytest.mark.parametrize("k,cells,rays", [(200, 96, "120"), (200, 96, "37"), (40, 96, "120"), (255, 48, "37"), (8, 64, "9")])
-def test_staged_raycast_changes_no_bit(k, cells, rays):
-    """The staged kernel (variant 4: lane = (ray, chunk of 16 pairs) over LDS-staged per-cell record rows, fp16 records relative to the
-    cell, suffix bounds every 16 pairs) against the binned kernel with its early out off — every triangle evaluated — on the batch of
-    test_culled_raycast_changes_no_bit: steep tilts, arbitrary orientations, rays in facet planes, poses far outside the map, NaN."""
-    from hip_helpers import hip_step, make_engine
+def _adversarial_states(n, extent, seed=78, heightfn=None, margin_m=None):
     from isaac_rover_amd import synth
-    n = 3000
-    scene = synth.make_scene(n_cells=cells, k=k, n_stones=40)
-    distn = synth.ray_distribution(rays)
-    st = synth.make_states(n, cells * 0.1, seed=78)
+    kw = {} if heightfn is None else dict(heightfn=heightfn, margin_m=margin_m)
+    st = synth.make_states(n, extent, seed=seed, **kw)
     g = torch.Generator().manual_seed(5)
     st["quat"] = synth.quat_from_euler(0.5 * torch.randn(n, generator=g), 0.5 * torch.randn(n, generator=g), 3.0 * torch.randn(n, generator=g))
     st["quat"][0:600] = synth.quat_from_euler(0.08 * torch.randn(600, generator=g), 0.08 * torch.randn(600, generator=g), 3.0 * torch.randn(600, generator=g))
     q = torch.randn(1000, 4, generator=g)
-    st["quat"][1000:2000] = q / q.norm(dim=1, keepdim=True)
+    st["quat"][1000:2000] = q / q.norm(dim=1, keepdim=True)                      # arbitrary orientations
     axis = torch.tensor([[1.0, 0, 0, 0], [0.70710678, 0.70710678, 0, 0], [0.70710678, 0, 0.70710678, 0], [0, 1.0, 0, 0]])
-    st["quat"][2000:2900] = axis[torch.randint(0, 4, (900,), generator=g)]
+    st["quat"][2000:2900] = axis[torch.randint(0, 4, (900,), generator=g)]       # rays in facet planes, through vertices
     st["pos"][2000:2900, 0:2] = torch.round(st["pos"][2000:2900, 0:2] * 20) / 20
-    st["pos"][2900:2950] *= 1.0e4
+    st["pos"][2900:2950] *= 1.0e4                                                 # far outside the map
     st["pos"][2950:2960] = float("nan")
-    st["pos"][2960:2970, 2] += 500.0
-    eng = make_engine(scene, distn, n, variant=2)
-    eng.set_option("raycast_early_out", 0)
-    ref = hip_step(eng, st)
-    eng.close()
-    eng = make_engine(scene, distn, n, variant=4)
-    assert eng.info().raycast_variant == 4
-    got = hip_step(eng, st)
-    got2 = hip_step(eng, st)
-    ci = eng.cull_info()
-    eng.close()
-    for key in ref:
-        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
-        np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} (second step)")
-    assert ci["rays"] == n * (distn[0].shape[0] + 26)
+    st["pos"][2960:2970, 2] += 500.0                                              # high above the terrain
+    return st
+
+
+def _staged_against_every_triangle(scene, distn, st):
+    """variant 4 (both ways of casting the rocks part, short and long runs) against the binned kernel with its early out off, in the f32
+    arithmetic and in the reference's as-shipped fp16 arithmetic: every output identical."""
+    from hip_helpers import hip_step, make_engine
+    n = st["pos"].shape[0]
+    for precision in (0, 2):
+        eng = make_engine(scene, distn, n, variant=2)
+        eng.set_option("ray_precision", precision)
+        eng.set_option("raycast_early_out", 0)
+        ref = hip_step(eng, st)
+        eng.close()
+        for lane_rocks, run in ((0, None), (1, None), (1, 7), (0, 64)):
+            eng = make_engine(scene, distn, n, variant=4, run=run)
+            eng.set_option("ray_precision", precision)
+            eng.set_option("lane_rocks", lane_rocks)
+            assert eng.info().raycast_variant == 4
+            got = hip_step(eng, st)
+            got2 = hip_step(eng, st)
+            ci = eng.cull_info()
+            eng.close()
+            for key in ref:
+                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} precision={precision} lane_rocks={lane_rocks} run={run}")
+                np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} precision={precision} lane_rocks={lane_rocks} run={run} (second step)")
+            assert ci["rays"] == n * (distn[0].shape[0] + 26)
+    return ref
+
+
+@pytest.mark.parametrize("k,cells,rays", [(200, 96, "120"), (200, 96, "37"), (40, 96, "120"), (255, 48, "37"), (8, 64, "9")])
+def test_staged_raycast_changes_no_bit(k, cells, rays):
+    """The staged kernel (variant 4: lane = (ray, chunk of 16 pairs) over per-cell record rows in group-bound order — fp16 records
+    relative to the cell, suffix bounds and suffix cones every 16 pairs, tests (A) and (B) for rays off their cell's cone) against the
+    binned kernel with its early out off — every triangle evaluated — on the batch of test_culled_raycast_changes_no_bit: steep tilts,
+    arbitrary orientations, rays in facet planes, poses far outside the map, NaN."""
+    from isaac_rover_amd import synth
+    scene = synth.make_scene(n_cells=cells, k=k, n_stones=40)
+    ref = _staged_against_every_triangle(scene, synth.ray_distribution(rays), _adversarial_states(3000, cells * 0.1))
     assert (ref["ray_dist"] < 11.0).mean() > 0.3
 
 
 @pytest.mark.parametrize("seed,k,coarse,fine", [(1, 200, 1.2, 0.0375), (2, 64, 3.0, 0.05)])
 def test_staged_raycast_changes_no_bit_on_irregular_meshes(seed, k, coarse, fine):
-    """The same on irregular meshes (needles, flanks, always-candidate triangles, cells without a cone: rays off the cone path take
-    every pair of their cell as a candidate)."""
-    from hip_helpers import hip_step, make_engine
+    """The same on irregular meshes (needles, flanks, always-candidate triangles, cells without a cone: most rays run both tests, the
+    steep triangles sit in front of their cells' rows)."""
     from isaac_rover_amd import _lib, assets, synth
-    n = 3000
     spec = synth.IrregularSpec(extent_x=12.0, extent_y=12.0, n_rocks=24, seed=seed, coarse=coarse, fine=fine)
     tool = _lib.Engine(8, device=0)
     scene, zf = assets.build_irregular_scene(tool, spec, k)
     tool.close()
     distn = synth.ray_distribution("120" if seed != 2 else "37")
-    st = synth.make_states(n, 12.0, seed=80 + seed, heightfn=zf, margin_m=1.0)
-    g = torch.Generator().manual_seed(seed)
-    st["quat"][1000:2000] = synth.quat_from_euler(0.5 * torch.randn(1000, generator=g), 0.5 * torch.randn(1000, generator=g), 3.0 * torch.randn(1000, generator=g))
-    st["pos"][2900:2950] *= 1.0e4
-    st["pos"][2950:2960] = float("nan")
-    eng = make_engine(scene, distn, n, variant=2)
-    eng.set_option("raycast_early_out", 0)
-    ref = hip_step(eng, st)
-    eng.close()
-    eng = make_engine(scene, distn, n, variant=4)
-    assert eng.info().raycast_variant == 4
-    got = hip_step(eng, st)
-    eng.close()
-    for key in ref:
-        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+    _staged_against_every_triangle(scene, distn, _adversarial_states(3000, 12.0, seed=80 + seed, heightfn=zf, margin_m=1.0))
 
 
 @pytest.mark.parametrize("name,precision", [("step_irregular_p37_fp32", 0), ("step_irregular_native_fp32", 0),
@@ -370,7 +372,7 @@ def test_irregular_mesh_and_k200_all_variants(name, precision):
     st = states_of(fx)
     distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
     outs = {}
-    for variant in (3, 2, 1):
+    for variant in (4, 3, 2, 1):
         if precision == 2 and variant == 1:
             continue                                  # the env-order kernel has no as-shipped fp16 arithmetic
         eng = make_engine(scene, distn, st["pos"].shape[0], variant=variant)
@@ -386,7 +388,7 @@ def test_irregular_mesh_and_k200_all_variants(name, precision):
                 assert ci["always_candidate_triangles"][0] > 0 and (ci["cells_without_cone"][0] > 0 or precision == 2)
                 assert ci["rays_both_tests"] > 0 and ci["candidate_pairs"] > 0
         eng.close()
-    assert 2 in outs and (3 in outs or precision == 2)
+    assert 2 in outs and 4 in outs and (3 in outs or precision == 2)
     for variant, out in outs.items():
         if precision == 2:
             for key in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
@@ -981,7 +983,7 @@ def test_get_depths_returns_the_reference_triple(precision, tag):
     distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
     e, p_n = fx["in_pos"].shape[0], fx["distribution"].shape[0]
     want_d, want_pt, want_src = fx[f"out_{tag}_dist"], fx[f"out_{tag}_pt"], fx[f"out_{tag}_src"]
-    for variant in (3, 2, 1) if precision == 0 else (3, 2):
+    for variant in (4, 3, 2, 1) if precision == 0 else (4, 3, 2):
         eng = make_engine(scene, distn, e, variant=variant)
         eng.set_option("ray_precision", precision)
         dev = eng.device
@@ -1023,7 +1025,7 @@ def test_get_collisions_matches_the_reference(precision, name):
     scene = scene_for(fx)
     distn = (fx["distribution"], fx["sparse_idx"], fx["dense_idx"])
     e = fx["in_pos"].shape[0]
-    for variant in (3, 2, 1) if precision == 0 else (3, 2):
+    for variant in (4, 3, 2, 1) if precision == 0 else (4, 3, 2):
         eng = make_engine(scene, distn, e, variant=variant)
         eng.set_option("ray_precision", precision)
         dev = eng.device
@@ -1060,7 +1062,7 @@ def test_ray_phase_on_exported_and_supplied_rays(precision, name):
     e = st["pos"].shape[0]
     t = orc.KnnMap(scene.terrain.map_indices, scene.terrain.triangles, scene.terrain.vertices)
     r = orc.KnnMap(scene.rocks.map_indices, scene.rocks.triangles, scene.rocks.vertices)
-    for variant in (3, 2, 1) if precision == 0 else (3, 2):
+    for variant in (4, 3, 2, 1) if precision == 0 else (4, 3, 2):
         eng = make_engine(scene, distn, e, variant=variant)
         eng.set_option("ray_precision", precision)
         got = hip_step(eng, st)
