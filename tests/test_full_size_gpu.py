@@ -218,11 +218,14 @@ def _rays_vs_oracle(eng, maps, half, label):
     t, r = maps
     want_rock = orc.raycast_unit(r, src[:, :26], dirs[:, :26], half=half).reshape(dist[:, :26].shape)
     want_terr = orc.raycast_unit(t, src[:, 26:], dirs[:, 26:], half=half).reshape(dist[:, 26:].shape)
-    n_bad = int((dist[:, :26].view(np.uint32) != want_rock.view(np.uint32)).sum()) + \
-        int((dist[:, 26:].view(np.uint32) != want_terr.view(np.uint32)).sum())
-    print(f"[{label}] ray phase on the device's own rays vs the oracle: {n_bad} of {dist.size} distances differ")
+    # equal as IEEE values (a distance of exactly zero may come out as +0 from one triangle and -0 from another: which of the two equal
+    # values a min returns is the reduction order's business — torch.min's too; 1 ray of 9.6 M at configs[4]), NaN where the oracle has NaN
     want_all = np.concatenate((want_rock, want_terr), axis=1)
-    for e, sl in list(zip(*np.nonzero(dist.view(np.uint32) != want_all.view(np.uint32))))[:8]:
+    differ = ~((dist == want_all) | (np.isnan(dist) & np.isnan(want_all)))
+    n_bad = int(differ.sum())
+    n_bits = int((dist.view(np.uint32) != want_all.view(np.uint32)).sum())
+    print(f"[{label}] ray phase on the device's own rays vs the oracle: {n_bad} of {dist.size} distances differ ({n_bits} in their bits: +0 / -0)")
+    for e, sl in list(zip(*np.nonzero(differ)))[:8]:
         print(f"   env {e} slot {sl}: src {src[e, sl].tolist()} ({src[e, sl].view(np.uint32).tolist()}) dir {dirs[e, sl].tolist()} "
               f"({dirs[e, sl].view(np.uint32).tolist()}) cell {cell[e, sl]}: device {dist[e, sl]!r} oracle {want_all[e, sl]!r}")
     assert n_bad == 0, f"{label}: {n_bad} of {dist.size} ray distances differ from the oracle on IDENTICAL rays"

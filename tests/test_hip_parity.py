@@ -1073,7 +1073,7 @@ def test_ray_phase_on_exported_and_supplied_rays(precision, name):
         np.testing.assert_array_equal(dist_[:, :24], got["wheel_dist"])
         want = np.concatenate((orc.raycast_unit(r, s_[:, :26], d_[:, :26], half=precision == 2).reshape(e, 26),
                                orc.raycast_unit(t, s_[:, 26:], d_[:, 26:], half=precision == 2).reshape(e, -1)), axis=1)
-        np.testing.assert_array_equal(dist_.view(np.uint32), want.view(np.uint32), err_msg=f"{name} v{variant}")
+        np.testing.assert_array_equal(dist_, want, err_msg=f"{name} v{variant}")          # (IEEE equality: NaN == NaN here, +0 == -0)
         again = eng.cast_rays(src, dirs)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(again.cpu().numpy().view(np.uint32), dist_.view(np.uint32), err_msg=f"{name} v{variant} cast_rays")
@@ -1086,7 +1086,7 @@ def test_ray_phase_on_exported_and_supplied_rays(precision, name):
         s2n, d2n = s2.cpu().numpy(), d2.cpu().numpy()
         want2 = np.concatenate((orc.raycast_unit(r, s2n[:, :26], d2n[:, :26], half=precision == 2).reshape(e, 26),
                                 orc.raycast_unit(t, s2n[:, 26:], d2n[:, 26:], half=precision == 2).reshape(e, -1)), axis=1)
-        np.testing.assert_array_equal(got2.view(np.uint32), want2.view(np.uint32), err_msg=f"{name} v{variant} supplied rays")
+        np.testing.assert_array_equal(got2, want2, err_msg=f"{name} v{variant} supplied rays")
         eng.close()
 
 
