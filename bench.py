@@ -91,7 +91,11 @@ def parse(argv=None):
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` object of the default N = 1 run: the same 65 536-env batch on the irregular (decimated-style) mesh "
                          "and in the reference's as-shipped fp16 arithmetic, timed in the same process after the headline pass")
-    ap.add_argument("--also-steps", type=int, default=50, help="timed steps of each `also` workload (>= 20)")
+    ap.add_argument("--also-steps", type=int, default=50, help="timed steps per pass of each `also` workload (>= 20)")
+    ap.add_argument("--passes", type=int, default=30,
+                    help="back-to-back timed passes of --steps steps (each bracketed by barrier + device sync); value / ms_per_step are the MEDIAN "
+                         "pass, min / max in `passes`")
+    ap.add_argument("--also-passes", type=int, default=5)
     ap.add_argument("--rank-timeout-s", type=float, default=900.0,
                     help="N > 1 self-launch: kill every rank and exit 124 when the run has not finished after this many seconds")
     return ap.parse_args(argv)
@@ -357,20 +361,24 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
     stale = bool(profiled_lib) and bool(lib_version) and profiled_lib != lib_version
     if (valu or traf) and not profiled_lib:
         stale = True                               # an entry from before the library carried a source hash
-    # The bound is whichever resource the kernel uses the larger fraction of (both from profiles/ counters at the live time)
-    hbm_bound = hbm is not None and (frac is None or hbm["frac_of_8TBps"] >= frac)
-    if stale or (hbm is None and frac is None):
+    # The line leads with the counter-measured HBM fraction (north star: "rocprof HBM GB/s against the 8 TB/s roofline"); the VALU issue
+    # model is the secondary entry `valu`, and `stall_frac` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (the share of the resident waves' cycles spent
+    # in s_waitcnt) says how far from either roof the kernel's own latency chains keep it.
+    stall = valu.get("stall_frac") if valu else None
+    if stale or hbm is None:
         # no counters for this workload key, or counters of another build of the library: no bound and no fraction is claimed
         # (the live launch time and the no-reuse byte model below are still this run's)
         head = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
                 "profile_missing": not (valu or traf)}
         if stale:
             hbm = None
+            stall = None
             valu_obj.update({"achieved": None, "frac": None})
-    elif hbm_bound:
-        head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     else:
-        head = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": valu_obj["unit"], "frac": frac}
+        head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
+    head["stall_frac"] = stall
+    head["limited_by"] = (None if head["frac"] is None else
+                          ("hbm" if head["frac"] >= 0.7 else ("valu issue" if (valu_obj["frac"] or 0) >= 0.7 else "latency (neither roof reached)")))
     head.update({"kernel": {4: "lane_scan_kernel", 3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "launches_timed_every": int(getattr(args, "event_every", 1)), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
@@ -383,6 +391,36 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
                          "8(d)'s no-reuse byte model (18 B per (ray, triangle) pair), which the kernel beats by not touching provably "
                          "rejected triangles: reuse_factor = model bytes / measured bytes; formulas in profiles/README.md"})
     return head
+
+
+def config_label(args, E, world, E_global):
+    """The BASELINE.json config a run IS — only when batch size, ray set, K, cells, stones, mesh, arithmetic and GPU count all match —
+    else a plain description."""
+    std = (args.k == 200 and args.cells == 600 and args.stones == 1024 and args.mesh == "grid" and args.ray_precision == "fp32"
+           and not args.graph)
+    plain37 = std and args.rays == "37" and not args.validate_goals
+    if plain37 and world == 1 and E == 65536:
+        return "BASELINE configs[2]"
+    if plain37 and world == 1 and E == 4096:
+        return "BASELINE configs[1]"
+    if std and world == 1 and E == 65536 and args.rays == "120" and args.validate_goals:
+        return "BASELINE configs[4]"
+    if plain37 and world == 8 and E_global == 262144:
+        return "BASELINE configs[3]"
+    if plain37 and world == 1 and E == 32768:
+        return "one rank's shard of BASELINE configs[3] (32 768 of its 262 144 envs, no gather)"
+    if plain37 and world > 1 and E == 65536:
+        return f"weak scaling of BASELINE configs[2] ({E_global} envs in total)"
+    return "custom workload (no BASELINE config)"
+
+
+def _median_pass(times):
+    """(median, min, max) of the passes' elapsed times; the median of an even count is the upper middle one (a pass that ran)."""
+    t = sorted(times)
+    return t[len(t) // 2], t[0], t[-1]
+
+
+_SCENES = {}
 
 
 def _checksums(torch, obs, rew, done):
@@ -405,7 +443,11 @@ def measure_also(args, device, local_rank, **override):
     for k, v in override.items():
         setattr(a, k, v)
     E = a.envs_per_gpu
-    scene, zf = load_scene(a, device, local_rank)
+    skey = (a.mesh, a.cells, a.k, a.stones)
+    if skey not in _SCENES:
+        _SCENES.clear()                      # one scene resident at a time
+        _SCENES[skey] = load_scene(a, device, local_rank)
+    scene, zf = _SCENES[skey]
     distn = synth.ray_distribution(a.rays)
     n_rays = int(distn[0].shape[0])
     eng = _make_engine(E, local_rank, E, 0)
@@ -433,29 +475,50 @@ def measure_also(args, device, local_rank, **override):
     sins = [eng.make_in(b["pos"], b["quat"], b["joints"], b["target"], b["lin_hist"], b["ang_hist"], b["euler_pre"], b["progress"])
             for b in batches]
     steps = max(20, int(a.also_steps))
+    if a.validate_goals:
+        n_used = torch.zeros(1, dtype=torch.int32, device=device)
+        initial = [b["pos"].clone() for b in batches]
+        joint_vel = torch.zeros(E, 13, device=device)
+
+    def step(i):
+        eng.step(sins[i % 4], sout, increment_progress=True, compact=True)
+        if a.validate_goals:                 # configs[4]: the device-side reset + goal re-draw / validation of the envs the step flagged done
+            st = batches[i % 4]
+            eng.reset_envs(reset_ids, initial[i % 4], st["pos"], st["quat"], reset, st["progress"], n_reset_dev=n_reset,
+                           joint_pos13=st["joints"], joint_vel13=joint_vel, target3=st["target"], radius=8.0, seed=i,
+                           max_draws=256, n_draws_used=n_used)
+
     eng.set_profiling(True)
     if a.preroll_ms > 0:                     # the scene build left the GPU idle: the same untimed clock ramp as the headline gets
         t_pre, i_pre = time.perf_counter(), 0
         while time.perf_counter() - t_pre < a.preroll_ms * 1e-3:
             for _ in range(8):
-                eng.step(sins[i_pre % 4], sout, increment_progress=True, compact=True)
+                step(i_pre)
                 i_pre += 1
             _sync()
     for i in range(max(10, a.warmup)):
-        eng.step(sins[i % 4], sout, increment_progress=True, compact=True)
+        step(i)
     _sync()
     eng.set_profiling(True, every=a.event_every)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        eng.step(sins[i % 4], sout, increment_progress=True, compact=True)
-    _sync()
-    elapsed = time.perf_counter() - t0
+    times, i_step = [], 0
+    for _ in range(max(1, int(a.also_passes))):
+        t0 = time.perf_counter()
+        for _i in range(steps):
+            step(i_step)
+            i_step += 1
+        _sync()
+        times.append(time.perf_counter() - t0)
+    elapsed, t_min, t_max = _median_pass(times)
     prof = eng.get_profile()
     eng.set_profiling(False)
     out = {"value": E * steps / elapsed, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+           "passes": {"n": len(times), "min_ms_per_step": 1e3 * t_min / steps, "max_ms_per_step": 1e3 * t_max / steps,
+                      "spread": (t_max - t_min) / elapsed},
            "raycast_ms": prof.raycast_ms / max(prof.launches, 1), "dtype": "f16" if a.ray_precision == "fp16_as_shipped" else "f32",
-           "workload": f"{E} envs x ({a.rays} + 26) rays, K={a.k}, {a.cells}x{a.cells} cells, mesh={a.mesh}, ray_precision={a.ray_precision}, "
-                       f"cell_index_mode={a.cell_index_mode}",
+           "workload": f"{config_label(a, E, 1, E)}: {E} envs x ({a.rays} + 26) rays, K={a.k}, {a.cells}x{a.cells} cells, mesh={a.mesh}, "
+                       f"ray_precision={a.ray_precision}, cell_index_mode={a.cell_index_mode}"
+                       + (", + goal validation" if a.validate_goals else ""),
+           "raycast_variant": int(info.raycast_variant),
            "roofline": roofline(a, E, n_rays, prof, info, _lib_version())}
     if info.raycast_variant >= 3:
         ci = eng.cull_info()
@@ -465,6 +528,17 @@ def measure_also(args, device, local_rank, **override):
     del batches, sins, sout, obs
     torch.cuda.empty_cache()
     return out
+
+
+def also_workloads(args, device, local_rank):
+    """The other single-GPU workloads of BASELINE.json and the two representative variants of the headline, each under this run's
+    clock (the driver times one command): configs[1], configs[4], one rank's shard of configs[3]; the geometry the reference's real
+    terrain has (a decimated mesh, utils/terrain_utils/terrain_generation.py:217-243) and its real arithmetic (fp16, camera.py:55)."""
+    return {"configs1": measure_also(args, device, local_rank, envs_per_gpu=4096, also_steps=max(200, args.also_steps)),
+            "configs3_shard": measure_also(args, device, local_rank, envs_per_gpu=32768),
+            "configs4": measure_also(args, device, local_rank, rays="120", validate_goals=True),
+            "fp16_as_shipped": measure_also(args, device, local_rank, ray_precision="fp16_as_shipped"),
+            "mesh_irregular": measure_also(args, device, local_rank, mesh="irregular")}
 
 
 def run_rank(args):
@@ -544,17 +618,20 @@ def run_rank(args):
         g.replay()
 
     wait_events = []                         # N > 1: (before, after) pairs around every point where the compute stream waits for a transfer
+    sampled_steps = [0]
 
     def one_step(i, overlap, timed=False):
         b = i % len(batches)
         d = i % depth
         # (timing events on the compute stream cost it ~6 us each: like the in-library ray-cast events they bracket every
         #  --event-every-th step only, and the waits they measure are scaled up — the N > 1 headline then carries what the N = 1 one does)
-        sampled = timed and world > 1 and (i % max(1, args.event_every)) == 0
+        ev = max(1, args.event_every)
+        sampled = timed and world > 1 and ((i + i // ev) % ev) == 0      # one step in `ev`, its phase moving on by one each time: both buffer sets are sampled
         e0 = _gpu_event() if sampled else None
         gather.wait(d)                       # overlapped mode: the transfer that last read buffer set d must be through
         if e0 is not None:
             wait_events.append((e0, _gpu_event()))
+            sampled_steps[0] += 1
         launch_step(b, d)
         e0 = _gpu_event() if (sampled and not overlap) else None
         gather.gather(d, wait=not overlap)   # (obs, rew, done) of this step to the learner rank
@@ -592,12 +669,12 @@ def run_rank(args):
                     ok = ok and bool(torch.equal(_checksums(torch, og[s], rg[s], dg[s]).cpu(), allsums[r][d].cpu()))
         return ok
 
-    def timed_pass(first_step, overlap):
+    def timed_pass(first_step, overlap, check=True):
         fence()
-        eng.set_profiling(True, every=args.event_every)      # resets the in-library ray-cast event counters
         t0 = time.perf_counter()
         stamps, evs = [], []
         wait_events.clear()
+        sampled_steps[0] = 0
         for i in range(args.steps):
             one_step(first_step + i, overlap, timed=True)
             if args.debug_timing:
@@ -613,21 +690,34 @@ def run_rank(args):
             print("gpu ms/step:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(evs[:-1], evs[1:])), file=sys.stderr)
             print("enqueue us/step:", " ".join(f"{x:.0f}" for x in dd), "| enqueue total ms", 1e3 * (t_enq - t0),
                   "| fence ms", 1e3 * (elapsed - (t_enq - t0)), file=sys.stderr)
-        prof = eng.get_profile()
-        ok = gather_check()
+        ok = gather_check() if check else None
         per_rank = None
         if world > 1:
-            # per rank: its own elapsed time and the time its compute stream spent waiting for (obs, rew, done) transfers
-            waited = sum(a.elapsed_time(b) for a, b in wait_events if a is not None and b is not None) * 1e-3 * max(1, args.event_every)
+            # per rank: its own elapsed time and the time its compute stream spent waiting for (obs, rew, done) transfers — EXTRAPOLATED
+            # from the sampled steps (every --event-every-th) to all of them
+            waited = sum(a.elapsed_time(b) for a, b in wait_events if a is not None and b is not None) * 1e-3 \
+                * (args.steps / max(1, sampled_steps[0]))
             mine = torch.tensor([elapsed, waited], dtype=torch.float64, device=device)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
             per_rank = {"ms_per_step": [1e3 * float(x[0]) / args.steps for x in every],
-                        "transfer_wait_ms_per_step": [1e3 * float(x[1]) / args.steps for x in every]}
+                        "transfer_wait_ms_per_step_extrapolated": [1e3 * float(x[1]) / args.steps for x in every]}
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, prof, ok, per_rank
+        return elapsed, ok, per_rank
+
+    def timed_passes(first_step, overlap, n):
+        """n back-to-back passes of exactly --steps steps, each bracketed by barrier + device sync on both sides with the max over the
+        ranks as its time; -> (median pass's time, min, max, gather check of the last pass, per-rank record of the median pass, steps run)"""
+        eng.set_profiling(True, every=args.event_every)      # resets the in-library ray-cast event counters
+        recs = []
+        for p in range(n):
+            e, ok_p, pr = timed_pass(first_step + p * args.steps, overlap, check=(p == n - 1))
+            recs.append((e, ok_p, pr))
+        med, t_min, t_max = _median_pass([r[0] for r in recs])
+        pr_med = next(r[2] for r in recs if r[0] == med)
+        return med, t_min, t_max, recs[-1][1], pr_med, n * args.steps
 
     # Event timing is switched on BEFORE the warm-up: the first timed hipEventRecord on a stream makes the runtime
     # enable queue profiling once (tens of ms); the warm-up absorbs that, then the counters are reset.
@@ -644,13 +734,18 @@ def run_rank(args):
     overlap = can_overlap and not args.sync_gather
     for i in range(args.warmup):
         one_step(i, overlap)
-    elapsed, prof, ok, per_rank = timed_pass(args.warmup, overlap)
+    n_pass = max(1, args.passes)
+    elapsed, t_min, t_max, ok, per_rank, ran = timed_passes(args.warmup, overlap, n_pass)
+    prof = eng.get_profile()
     alt = None
     if world > 1 and can_overlap and not args.no_alt_pass:
-        e2, _p2, ok2, pr2 = timed_pass(args.warmup + args.steps, not overlap)
+        e2, e2_min, e2_max, ok2, pr2, _ = timed_passes(args.warmup + ran, not overlap, min(5, n_pass))
         alt = {"mode": "overlapped" if not overlap else "sync_gather", "value": E_global * args.steps / e2,
                "ms_per_step": 1e3 * e2 / args.steps, "gather_check": ok2, "per_rank": pr2}
     eng.set_profiling(False)
+    if world > 1:            # every rank says who it was (a run that dies later still leaves this on stderr)
+        print(f"bench.py: rank {rank}/{world} on cuda:{local_rank} ({torch.cuda.get_device_name(local_rank) if torch.cuda.is_available() else 'cpu'}), "
+              f"backend {dist.get_backend()}, {1e3 * elapsed / args.steps:.4f} ms per step (median of {n_pass} passes)", file=sys.stderr, flush=True)
     # the kernel the line reports is the kernel that ran: the library has no silent change of ray-cast variant, and this guards it
     if eng.info().raycast_variant != info.raycast_variant:
         raise SystemExit(f"bench.py: ray-cast variant changed during the run ({info.raycast_variant} -> {eng.info().raycast_variant})")
@@ -659,17 +754,13 @@ def run_rank(args):
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = E_global * args.steps / elapsed
-        # which BASELINE.json config this run IS: configs[3] only at its own size (262 144 envs in total over the ranks);
-        # any other N > 1 run is weak scaling of configs[2] (the per-GPU workload of the N = 1 line, what SCALE compares)
-        if args.validate_goals:
-            cfg_name = "BASELINE configs[4]"
-        elif world > 1:
-            cfg_name = "BASELINE configs[3]" if E_global == 262144 else f"weak scaling of BASELINE configs[2] ({E_global} envs in total)"
-        else:
-            cfg_name = "BASELINE configs[1]" if E == 4096 else "BASELINE configs[2]"
+        cfg_name = config_label(args, E, world, E_global)
         line = {
             "metric": "env-steps/sec (obs+reward+done)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "passes": {"n": n_pass, "statistic": "median pass of --steps steps (barrier + device sync on both sides, max over ranks)",
+                       "min_ms_per_step": 1e3 * t_min / args.steps, "max_ms_per_step": 1e3 * t_max / args.steps,
+                       "spread": (t_max - t_min) / elapsed},
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.ray_precision == "fp16_as_shipped" else "f32",
             "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {E} envs/GPU x {world} GPU, "
@@ -722,8 +813,8 @@ def run_rank(args):
             eng.close()
             del sins, souts, batches
             torch.cuda.empty_cache()
-            line["also"] = {"mesh_irregular": measure_also(args, device, local_rank, mesh="irregular"),
-                            "fp16_as_shipped": measure_also(args, device, local_rank, ray_precision="fp16_as_shipped")}
+            _SCENES[(args.mesh, args.cells, args.k, args.stones)] = (scene, zf)
+            line["also"] = also_workloads(args, device, local_rank)
         print(json.dumps(line), flush=True)
         if line["lib_built_from_tree"] is False:
             # a number measured on a library built from OTHER sources than the ones next to it is not a number of this tree

@@ -244,7 +244,12 @@ def _all_envs_vs_oracle(scene, distn, st, label, budget=None):
     n = st["pos"].shape[0]
     maps = _oracle_maps(scene)
     t, r = maps
-    b = dict(flips32=2e-4, flags32=1e-4, rays16=2e-3, flags16=2e-3)
+    # Budgets = twice what was MEASURED on MI355X (round 5, gpurun_out/fullsize_2.log; the numbers are printed on every run): fp32 hit <-> miss
+    # flips 4e-7 of the terrain rays (configs[2]; 0 elsewhere), flags 0 (allowed: two envs of 65 536); as shipped 3.3e-5 ... 6.4e-5 of the
+    # terrain rays, <= 2.5e-6 of the wheel rays, <= 7.6e-6 of the body rays, flags 0 — all of it on rays whose ORIGIN the pose trigonometry
+    # moved (26 % of the fp32 origins differ from the host libm's by an ulp, 0.0003 % land in another cell; 0.015 % of the as-shipped
+    # origins round to another fp16 value); on identical rays nothing differs (`_rays_vs_oracle`).
+    b = dict(flips32=1e-6, flags32=3.1e-5, rays16=1.3e-4, flags16=3.1e-5)
     b.update(budget or {})
     eng = make_engine(scene, distn, n, variant=None)                 # the library's own choice of ray-cast kernel
     got = hip_step(eng, st)
