@@ -356,6 +356,8 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
                 "valu_insts_per_ray": insts_per_ray,
                 "cycles_per_inst": (float(valu["valu_simd_cycles_per_launch"]) / float(valu["valu_insts_per_launch"])
                                     if valu and valu.get("valu_simd_cycles_per_launch") else None),
+                "frac_lower_bound": (float(valu["valu_simd_cycles_lower_bound"]) / t / 1e9 / peak
+                                     if valu and valu.get("valu_simd_cycles_lower_bound") and t > 0 else None),
                 "issue_rates": valu.get("issue_rates_cycles") if valu else None}
     profiled_lib = (valu or traf or {}).get("lib")
     stale = bool(profiled_lib) and bool(lib_version) and profiled_lib != lib_version

@@ -36,6 +36,7 @@ struct rover_ctx {
     // tables of the staged ray cast (variant 4; f32 proof): per cell the pair records in group-bound order, their ids, the suffix bounds
     LaneTables lane[2]{}, lane_h[2]{};  // per map: f32 proof / as-shipped fp16 proof
     uint32_t lane_pp[2]{0, 0};
+    int lane_env_order = -1;            // variant 4 without the sort (the ray slots in env order): -1 auto (mid-size batches), 0 / 1 (option "lane_env_order")
     int lane_rocks = -1;                // variant 4: the rocks part of the sorted list through the staged kernel too: -1 auto, 0 / 1 (option "lane_rocks", ROVER_LANE_ROCKS)
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
@@ -175,11 +176,16 @@ static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_env
 // measurement, when the ray cast behind the sort was the every-triangle kernel.)
 #define ROVER_AUTO_CULL_RAYS_F32 49152u
 #define ROVER_AUTO_CULL_RAYS_F16 24576u
-#define ROVER_AUTO_LANE_RAYS 393216u
+// The staged ray cast: from 24 576 rays (f32 arithmetic), in env order — no sort — while a terrain cell holds fewer than 1.5 heightmap rays (lane_env_order).  Whole step, M env-steps/s, 37 + 26
+// rays, one call per size, env-order kernel / culled / staged behind the sort / staged in env order: 512 envs 11.3 / 10.5 / 8.8 / 12.7,
+// 1 024: 14.6 / 17.8 / 15.2 / 22.3, 2 048: 17.3 / 27.5 / 24.1 / 36.5, 4 096: 18.5 / 39.8 / 39.4 / 46.6, 8 192: 19.0 / 54.5 / 57.5 / 58.0,
+// 16 384: 19.3 / 72.2 / 76.8 / 67.8, 32 768: 19.5 / 98.7 / 109.4 / 73.5; 120 + 26 rays at 4 096 envs 8.5 / 26.3 / 28.9 / 32.6.
+#define ROVER_AUTO_LANE_RAYS 24576u
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
-    if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) <= ROVER_AUTO_CULL_RAYS_F32) return 1;
+    const bool v4_ok = c->lane[0].lrec && c->lane[1].lrec && c->lane_h[0].lrec && c->lane_h[1].lrec;
+    if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) < (v4_ok ? ROVER_AUTO_LANE_RAYS : ROVER_AUTO_CULL_RAYS_F32 + 1u)) return 1;
     if (c->variant == 0 && c->precision == 2 && c->have_dist && valid_rays(c) <= ROVER_AUTO_CULL_RAYS_F16) return 2;      // small batches, as shipped: binned
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
@@ -189,7 +195,6 @@ static int effective_variant(const rover_ctx* c) {
     // f32 65 536 envs 121 / 132, 32 768: 98 / 110, 16 384: 72 / 78, 8 192: 55 / 58, 4 096: 40 / 40, 2 048: 27 / 25; 120 + 26 rays 56.5 / 68.2;
     // the native 1 634 + 26 rays at 4 096 envs 4.63 / 5.47, at 512 envs 2.64 / 2.36; irregular mesh 81 / 100.  As shipped (fp16 proof: a
     // third of the rays lie off their cell's narrow cone and test every pair both ways) 89.8 / 81.4: stays on the culled kernel.
-    const bool v4_ok = c->lane[0].lrec && c->lane[1].lrec && c->lane_h[0].lrec && c->lane_h[1].lrec;
     if (v4_ok && (c->variant == 4 || (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) >= ROVER_AUTO_LANE_RAYS))) return 4;
     return 3;
 }
@@ -422,6 +427,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
+    if (const char* v = getenv("ROVER_LANE_ENV_ORDER")) c->lane_env_order = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("ROVER_LANE_ROCKS")) c->lane_rocks = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 4) ? x : 0; }
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
@@ -749,6 +755,17 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     return a;
 }
 
+// The staged ray cast needs no bins: where a (map, cell) bin holds a ray or none — small and mid-size batches — the sort's three launches
+// (18 us) buy it nothing and it walks the ray slots in env order (a run = 64 consecutive slots: a rover's 37 heightmap rays still share cells).
+// Measured (MI355X, 37 + 26 rays, whole step, one call per size): see ROVER_AUTO_ENVORDER_* below.
+static bool lane_env_order(const rover_ctx* c, int variant) {
+    if (variant != 4) return false;
+    if (c->lane_env_order >= 0) return c->lane_env_order != 0;
+    // what decides is the heightmap rays per terrain cell (rovers spread over the map): below ~1.5 the sort buys no sharing
+    // (4 096 envs x 120 rays: 1.37, env order 32.6 against 28.9 M env-steps/s; 8 192 x 37: 0.84, 58.0 / 57.5; 16 384 x 37: 1.68, 67.8 / 76.8)
+    return c->have_dist && 2ull * (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 3ull * (uint64_t)c->cull_cells[0];
+}
+
 // the ray-cast launch(es) of a step for the variant in force, on the ray records / sorted list in the workspace
 static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
     const uint32_t E = (uint32_t)c->cfg.num_envs;
@@ -765,6 +782,11 @@ static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t 
             l.half = lh ? 1 : 0; l.c_a_h = ph.c_a; l.k2_far = cull_far_k2(l.half, ph);
         }
         l.run = effective_run(c); l.out = c->d_dist_out; l.stats = c->d_cull_stats;
+        if (lane_env_order(c, variant)) {      // every slot (padding included), in env order, one launch
+            l.sorted = nullptr; l.n_sorted = E * c->R8; l.n_terrain = l.n_sorted; l.run = 64u;
+            HIP_TRY(c, launch_raycast_lane(l, s));
+            return ROVER_OK;
+        }
         // The rocks part too?  On a regular rocks mesh no: its rays are few per bin and a tenth of them lie off every cone (the horizontal body
         // rays, which test every pair of their cell both ways) — the staged kernel reads a cell's whole 3.5 KB row for one such ray where the
         // culled kernel reads 800 bytes of ids (65 536 envs: 440 us in one launch against 259 + 137).  On an irregular rocks mesh — most cells
@@ -811,13 +833,14 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
         return fail(c, ROVER_E_STATE, "the culled ray cast's candidate queue is not allocated for the options in force");
     const uint32_t n_valid = E * (26u + (uint32_t)c->P);
     p.rocks_bin_offset = (uint32_t)((uint64_t)c->map[0].X * c->map[0].Y);
-    if (variant >= 2) p.bin_out = c->d_bins;
+    const bool sorts = variant >= 2 && !lane_env_order(c, variant);
+    if (sorts) p.bin_out = c->d_bins;
     p.precision = c->precision;
     p.cell_rcp = c->cell_rcp;
     // the sort's first pass (keys per coarse bucket and tile) inside prep_rays_kernel where a 64-env block's keys lie in one tile: the
     // table is zero between steps (allocation, then the sort's last kernel) — unless a step failed half way
     // (caller-supplied rays, rover_cast_rays: import_rays_kernel writes the records and keys, the sort counts its keys itself)
-    const bool hist_fused = !import_src && variant >= 2 && bin_hist_fused(E * c->R8, c->R8, c->n_bins, c->low_bits, &p.hist_blocks_per_tile);
+    const bool hist_fused = !import_src && sorts && bin_hist_fused(E * c->R8, c->R8, c->n_bins, c->low_bits, &p.hist_blocks_per_tile);
     if (hist_fused) {
         if (c->bkt_table_dirty) HIP_TRY(c, hipMemsetAsync(c->d_bkt_table, 0, c->bkt_table_bytes, s));
         c->bkt_table_dirty = true;
@@ -825,15 +848,15 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
     }
     if (import_src) {
         HIP_TRY(c, launch_import_rays(import_src, import_dir, E, c->R8, (uint32_t)c->P, c->map[0], c->map[1], p.rocks_bin_offset, c->precision,
-                                      c->cell_rcp, c->d_rays, variant >= 2 ? c->d_bins : nullptr, s));
+                                      c->cell_rcp, c->d_rays, sorts ? c->d_bins : nullptr, s));
     } else {
         HIP_TRY(c, launch_prep(p, s));
     }
-    if (variant >= 2)
+    if (sorts)
         HIP_TRY(c, launch_bin_rays(c->d_bins, E * c->R8, n_valid, c->n_bins, c->low_bits, c->d_bkt_table, c->d_pairs,
                                    c->d_block_sums, c->d_sorted, hist_fused, s));
     // fused histogram: bucket_sort_kernel has cleared the table again; otherwise the table (if the sort ran) holds this step's offsets
-    if (variant >= 2) c->bkt_table_dirty = !hist_fused;        // (variant 1 does not touch the table)
+    if (sorts) c->bkt_table_dirty = !hist_fused;        // (variant 1 does not touch the table)
     const bool timed = c->profiling && (c->prof_seen++ % c->prof_every) == 0;
     if (timed) {
         if (c->prof_pending == kProfRing && prof_drain(c)) return fail(c, ROVER_E_HIP, "profiling: event drain failed");
@@ -846,7 +869,7 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
         ++c->prof_launches;
     }
     c->last_variant = variant;
-    c->sorted_valid = variant >= 2;
+    c->sorted_valid = sorts;
     c->rays_valid = true;
     return ROVER_OK;
 }
@@ -1402,6 +1425,11 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->variant = (int)value;
         return alloc_cull_queue(c);
     }
+    if (!strcmp(name, "lane_env_order")) {
+        if (value < -1 || value > 1) return fail(c, ROVER_E_INVALID, "lane_env_order must be -1 (auto), 0 or 1");
+        c->lane_env_order = (int)value;
+        return ROVER_OK;
+    }
     if (!strcmp(name, "lane_rocks")) {
         if (value < -1 || value > 1) return fail(c, ROVER_E_INVALID, "lane_rocks must be -1 (auto), 0 or 1");
         c->lane_rocks = (int)value;
@@ -1485,7 +1513,7 @@ int rover_replay_raycast(rover_ctx* c, void* stream) {
     if (!c->rays_valid) return fail(c, ROVER_E_STATE, "replay_raycast: no ray records yet (run a step first)");
     USE_DEVICE(c);
     int v = effective_variant(c);
-    if (v >= 2 && !c->sorted_valid) v = 1;       // no sorted list from the last step: only the env-order kernel can replay
+    if (v >= 2 && !c->sorted_valid && !lane_env_order(c, v)) v = 1;       // no sorted list from the last step: only an env-order kernel can replay
     const uint32_t n_valid = (uint32_t)c->cfg.num_envs * (26u + (uint32_t)c->P);
     hipStream_t s = (hipStream_t)stream;
     if (v >= 3 && (!c->d_cull_queue || !c->d_cull_stats || c->cull_run != effective_run(c)))

@@ -1229,11 +1229,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     const uint32_t i0 = lb < split ? wave * run : split * 4u * run + (wave - split * 4u) * run_r;
     if (i0 >= n_sorted) return;
     const uint32_t n_run = min(my_run, n_sorted - i0);
-    const bool act = lane < n_run;
+    const bool in_run = lane < n_run;
     const uint64_t t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    const uint32_t gid = sorted[i0 + (act ? lane : n_run - 1u)];
+    // sorted == NULL: the ray slots in env order (small batches: a bin holds a ray or none, the sort's three launches buy nothing; a run is
+    // then 64 consecutive slots, padding slots — flags bit 1 clear — take no part)
+    const uint32_t gid = sorted ? sorted[i0 + (in_run ? lane : n_run - 1u)] : i0 + (in_run ? lane : n_run - 1u);
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid)[0], rsb = reinterpret_cast<const float4*>(rays + gid)[1];
     const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w), map = rflags & 1u;
+    const bool act = in_run && (rflags & 2u) != 0u;
     const uint32_t pp = map ? pp01 >> 16 : pp01 & 0xffffu, nch = pp / LN_CH;
     const float4* lp = (map ? lvl1 : lvl0) + (uint64_t)cell * LN_LVL;
     const float4 hdr = lp[0];
@@ -1396,11 +1399,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
             cm[k] = m; cnt += (uint32_t)__builtin_popcount(m);
         }
         const uint32_t e_incl = wave_incl_scan(cnt, lane), e_pre = e_incl - cnt;
+        const uint64_t actm = __builtin_amdgcn_ballot_w64(act);
+        const uint32_t r_end = actm ? 64u - (uint32_t)__builtin_clzll(actm) : 0u;          // one past the last ray that takes part (env order: padding slots do not)
         uint32_t r_lo = 0;
-        for (;;) {
+        while (r_lo < r_end) {
             const uint32_t base_e = (uint32_t)__builtin_amdgcn_readlane((int)e_pre, (int)r_lo);
-            const uint64_t fm = __builtin_amdgcn_ballot_w64(act && lane >= r_lo && e_incl - base_e <= LN_QCAP - cused);
-            if (!fm) { flush(); continue; }                    // (an empty queue takes any one ray: <= 128 entries)
+            // (lanes that take no part have no entries: they "fit" wherever their prefix does, so the fitting lanes stay one contiguous range)
+            const uint64_t fm = __builtin_amdgcn_ballot_w64(lane >= r_lo && lane < r_end && e_incl - base_e <= LN_QCAP - cused);
+            if (!fm) {
+                if (cused == 0u) break;                        // (cannot happen: an empty queue takes any one ray's <= 128 entries)
+                flush();
+                continue;
+            }
             const uint32_t r_hi = 64u - (uint32_t)__builtin_clzll(fm);
             if (act && lane >= r_lo && lane < r_hi) {
                 uint32_t at = cused + (e_pre - base_e);
@@ -1415,9 +1425,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
                 }
             }
             cused += (uint32_t)__builtin_amdgcn_readlane((int)e_incl, (int)(r_hi - 1u)) - base_e;
-            if (r_hi >= n_run) break;
             r_lo = r_hi;
-            flush();
+            if (r_lo < r_end) flush();
         }
     }
     lap(3);
@@ -1430,7 +1439,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         const uint32_t n_askip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && L == 0u) & am);
         const uint32_t n_fskip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !allc && 2u * L <= nch) & am);
         const uint32_t n_bins = (uint32_t)__builtin_popcountll(heads);
-        if (lane == 0u) stats[wave] = make_uint4(ctot, n_run | (n_fskip << 8), n_both | (n_askip << 8), n_bins | ((ia_tot + ib_tot) << 8) | (n_flush << 26));
+        const uint32_t n_rays = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));          // (env order: without the padding slots)
+        if (lane == 0u) stats[wave] = make_uint4(ctot, n_rays | (n_fskip << 8), n_both | (n_askip << 8), n_bins | ((ia_tot + ib_tot) << 8) | (n_flush << 26));
         if (DIAG && lane == 0u) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) diag[(size_t)wave * 8u + k] = dg[k];

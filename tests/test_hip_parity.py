@@ -316,10 +316,11 @@ def _staged_against_every_triangle(scene, distn, st):
         eng.set_option("raycast_early_out", 0)
         ref = hip_step(eng, st)
         eng.close()
-        for lane_rocks, run in ((0, None), (1, None), (1, 7), (0, 64)):
+        for lane_rocks, run, env_order in ((0, None, 0), (1, None, 0), (1, 7, 0), (0, 64, 0), (1, None, 1)):
             eng = make_engine(scene, distn, n, variant=4, run=run)
             eng.set_option("ray_precision", precision)
             eng.set_option("lane_rocks", lane_rocks)
+            eng.set_option("lane_env_order", env_order)         # 1: no sort, the ray slots in env order (padding slots skipped)
             assert eng.info().raycast_variant == 4
             got = hip_step(eng, st)
             got2 = hip_step(eng, st)
@@ -328,7 +329,7 @@ def _staged_against_every_triangle(scene, distn, st):
             for key in ref:
                 np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} precision={precision} lane_rocks={lane_rocks} run={run}")
                 np.testing.assert_array_equal(got2[key], ref[key], err_msg=f"{key} precision={precision} lane_rocks={lane_rocks} run={run} (second step)")
-            assert ci["rays"] == n * (distn[0].shape[0] + 26)
+            assert ci["rays"] == n * (distn[0].shape[0] + 26), (lane_rocks, run, env_order)
     return ref
 
 
@@ -642,8 +643,9 @@ def test_rays_that_clear_their_cell_are_not_scanned():
 
 
 def test_auto_variant_and_run_selection():
-    """raycast_variant 0 (auto): the env-order kernel up to 49 152 rays per step, the culled kernel above (as shipped: the binned
-    kernel up to 24 576 rays, the culled one above); K8 > 256 always falls back to the env-order kernel."""
+    """raycast_variant 0 (auto), f32 arithmetic: the env-order kernel below 24 576 rays per step, the staged kernel (4) from there on —
+    in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays —; as shipped: the binned kernel up to 24 576 rays,
+    the culled one above; K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=16, n_stones=8)
@@ -652,16 +654,16 @@ def test_auto_variant_and_run_selection():
     assert small.info().raycast_variant == 1
     small.set_option("ray_precision", 2)
     assert small.info().raycast_variant == 2
-    for n, want32, want16 in ((512, 1, 3), (1024, 3, 3)):          # 32 256 / 64 512 rays: either side of the f32 switch, both above the fp16 one
+    for n, want32, want16 in ((384, 1, 2), (512, 4, 3), (1024, 4, 3)):   # 24 192 / 32 256 / 64 512 rays: either side of the f32 and of the fp16 switch
         mid = make_engine(scene, distn, n, variant=None)
-        assert mid.info().raycast_variant == want32
+        assert mid.info().raycast_variant == want32, n
         mid.set_option("ray_precision", 2)
-        assert mid.info().raycast_variant == want16
+        assert mid.info().raycast_variant == want16, n
         mid.close()
     big = make_engine(scene, distn, 4096, variant=None)
-    assert big.info().raycast_variant == 3
+    assert big.info().raycast_variant == 4
     big.set_option("ray_precision", 2)
-    assert big.info().raycast_variant == 3            # the culled kernel runs the as-shipped arithmetic too (its own proof tables)
+    assert big.info().raycast_variant == 3            # as shipped: the culled kernel (its own proof tables)
     big.set_option("ray_precision", 0)
     st = synth.make_states(4096, 6.4, seed=3)
     a = hip_step(big, st)                                   # auto run length

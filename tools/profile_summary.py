@@ -45,8 +45,10 @@ if pmc:
 if pmc and a.workload_key:
     # the ray-cast stage that ran in these passes: the binned f32 / binned fp16 / env-order kernel, or the culled ray cast's
     # two kernels (cull_scan + cull_exact: counters summed per step, bench.py times the pair with one HIP-event bracket)
-    cull = [k for k in pmc if "cull_scan" in k or "cull_exact" in k]
-    cands = [k for k in pmc if ("raycast" in k or "cull_scan" in k) and "SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k]]
+    # (round 5: the staged ray cast — lane_scan_kernel for the terrain part, cull_scan_kernel for the rocks part on regular meshes: the
+    #  counters of the two launches of a step are summed, as bench.py's one HIP-event bracket times both)
+    cull = [k for k in pmc if "cull_scan" in k or "cull_exact" in k or "lane_scan" in k]
+    cands = [k for k in pmc if ("raycast" in k or "cull_scan" in k or "lane_scan" in k) and "SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k]]
     if len(cull) == 2 and all("SQ_INSTS_VALU" in pmc[k] and "FETCH_SIZE" in pmc[k] for k in cull):
         name = "+".join(sorted(k.split("(")[0].replace("rover::", "") for k in cull))
         pmc[name] = {cn: {"n": min(pmc[k][cn]["n"] for k in cull), "mean": sum(pmc[k][cn]["mean"] for k in cull)}
@@ -72,14 +74,21 @@ if pmc and a.workload_key:
         r_pk = max(rates[k + "@8"]["cycles_per_inst"] for k in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"))
         r_cvt, r_int, r_oth = rates["v_cvt_f32_f16@8"]["cycles_per_inst"], rates["v_and_b32@8"]["cycles_per_inst"], rates["v_cmp_gt_f32@8"]["cycles_per_inst"]
         kinds = {n: c.get("SQ_INSTS_VALU_" + n, {}).get("mean") for n in ("ADD_F32", "MUL_F32", "FMA_F32", "CVT", "INT32", "TRANS_F32")}
-        simd_cycles = None
+        simd_cycles = simd_cycles_lo = None
         if all(v is not None for v in kinds.values()):
             arith = kinds["ADD_F32"] + kinds["MUL_F32"] + kinds["FMA_F32"]
             other = c["SQ_INSTS_VALU"]["mean"] - arith - kinds["CVT"] - kinds["INT32"]
             simd_cycles = arith * r_pk + kinds["CVT"] * r_cvt + kinds["INT32"] * r_int + max(other, 0.0) * r_oth
+            # lane_scan_kernel's tests are plain v_mul / v_fma_f32 (2.2-2.3 cycles) next to v_fma_mix_f32 and packed forms (4.1): the kind
+            # counters do not tell them apart, so the figure above (every f32 instruction at the packed rate) is an UPPER bound there;
+            # the lower bound prices them all at the plain rate
+            r_plain = rates["v_fma_f32@8"]["cycles_per_inst"]
+            simd_cycles_lo = arith * r_plain + kinds["CVT"] * r_cvt + kinds["INT32"] * r_int + max(other, 0.0) * r_oth
+        stall = (c["SQ_WAIT_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"]) if ("SQ_WAIT_ANY" in c and c["SQ_WAVE_CYCLES"]["mean"]) else None
         lib = a.lib
         v = {a.workload_key: {"valu_insts_per_launch": c["SQ_INSTS_VALU"]["mean"], "valu_kind_counts_per_launch": kinds,
-                              "valu_simd_cycles_per_launch": simd_cycles,
+                              "valu_simd_cycles_per_launch": simd_cycles, "valu_simd_cycles_lower_bound": simd_cycles_lo,
+                              "stall_frac": stall,
                               "issue_rates_cycles": {"packed_f32": r_pk, "cvt": r_cvt, "int32": r_int, "other": r_oth},
                               "valu_active_quadcycles_per_launch": c["SQ_ACTIVE_INST_VALU"]["mean"],
                               "wave_quadcycles_per_launch": c["SQ_WAVE_CYCLES"]["mean"], "salu_insts_per_launch": c["SQ_INSTS_SALU"]["mean"],
