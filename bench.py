@@ -665,10 +665,9 @@ def run_rank(args):
         ok = True
         if rank == 0:
             for d in range(depth):
-                og, rg, dg = gather.global_views(d)
+                og, rg, dg = gather.global_views(d)            # [N, E, W], [N, E], [N, E]: shard r = rank r's packed message
                 for r in range(world):
-                    s = slice(r * E, (r + 1) * E)
-                    ok = ok and bool(torch.equal(_checksums(torch, og[s], rg[s], dg[s]).cpu(), allsums[r][d].cpu()))
+                    ok = ok and bool(torch.equal(_checksums(torch, og[r], rg[r], dg[r]).cpu(), allsums[r][d].cpu()))
         return ok
 
     def timed_pass(first_step, overlap, check=True):
@@ -773,7 +772,7 @@ def run_rank(args):
                                    + (f", ray_precision={args.ray_precision}" if args.ray_precision != "fp32" else "")
                                    + f", cell_index_mode={args.cell_index_mode}"
                                    + (", step replayed from a hipGraph" if args.graph else "")
-                                   + ((", RCCL gather(obs f32, rew f32, done u8)->rank0"
+                                   + ((", RCCL gather(one packed message per rank: obs f32 | rew f32 | done u8)->rank0"
                                        + (" overlapped with the next step" if overlap else " serialised with the steps"))
                                       if world > 1 else ""),
                        "envs_total": E_global, "rays_per_env": n_rays + 26, "obs_dim": W,
@@ -801,6 +800,7 @@ def run_rank(args):
             line["gather_check"] = ok
             line["per_rank"] = per_rank          # [rank]: ms per step of that rank; ms per step its compute stream waited for a transfer (rank 0 = the root's receive time that was not hidden)
             line["gather_bytes_per_rank_per_step"] = E * (4 * W + 4 + 1)
+            line["gather_messages_per_peer_per_step"] = 1                   # the packed shard (isaac_rover_amd.distributed.shard_bytes, padded to 256 B)
             if alt is not None:
                 line["alt_" + alt.pop("mode")] = alt
             if ok is False or (alt is not None and alt.get("gather_check") is False):

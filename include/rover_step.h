@@ -340,7 +340,11 @@ typedef struct {
     int32_t K[2], K8[2], X[2], Y[2];
     uint64_t table_bytes[2];       /* re-packed per-cell fp16 tables + cull tables */
     uint64_t workspace_bytes;
-    int32_t raycast_variant;       /* the variant the next step will run (1, 2 or 3) */
+    int32_t raycast_variant;       /* the variant the next step will run: 1 env order, 2 binned, 3 culled, 4 staged (csrc/rover_cull.hip) */
+    int32_t cell_index_mode;       /* option "cell_index_mode" in force: 0 cpu_div, 1 cuda_rcp (tests pin the mode a fixture was captured with) */
+    int32_t ray_precision;         /* option "ray_precision" in force */
+    int32_t raycast_sorted;        /* 1: the step sorts the rays by (map, cell) bin; 0: the ray cast walks the slots in env order */
+    int32_t raycast_rocks_staged;  /* variant 4: 1 = the rocks part of the sorted list runs on the staged kernel too, 0 = on the culled one */
 } rover_info;
 ROVER_API int rover_get_info(const rover_ctx *ctx, rover_info *info);
 /* Diagnostics of the culled ray cast (variant 3, csrc/rover_cull.hip).  Per map: how many triangles its conservative

@@ -55,7 +55,9 @@ class StepOut(C.Structure):
 class Info(C.Structure):
     _fields_ = [("P", C.c_int32), ("Ns", C.c_int32), ("Nd", C.c_int32), ("rays_per_env_padded", C.c_int32),
                 ("K", C.c_int32 * 2), ("K8", C.c_int32 * 2), ("X", C.c_int32 * 2), ("Y", C.c_int32 * 2),
-                ("table_bytes", C.c_uint64 * 2), ("workspace_bytes", C.c_uint64), ("raycast_variant", C.c_int32)]
+                ("table_bytes", C.c_uint64 * 2), ("workspace_bytes", C.c_uint64), ("raycast_variant", C.c_int32),
+                ("cell_index_mode", C.c_int32), ("ray_precision", C.c_int32), ("raycast_sorted", C.c_int32),
+                ("raycast_rocks_staged", C.c_int32)]
 
 
 class CullInfo(C.Structure):

@@ -766,6 +766,8 @@ static bool lane_env_order(const rover_ctx* c, int variant) {
     return c->have_dist && 2ull * (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 3ull * (uint64_t)c->cull_cells[0];
 }
 
+static bool lane_rocks_too(const rover_ctx* c) { return c->lane_rocks < 0 ? 2 * c->cull_farok[1] < c->cull_cells[1] : c->lane_rocks != 0; }
+
 // the ray-cast launch(es) of a step for the variant in force, on the ray records / sorted list in the workspace
 static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
     const uint32_t E = (uint32_t)c->cfg.num_envs;
@@ -791,8 +793,7 @@ static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t 
         // rays, which test every pair of their cell both ways) — the staged kernel reads a cell's whole 3.5 KB row for one such ray where the
         // culled kernel reads 800 bytes of ids (65 536 envs: 440 us in one launch against 259 + 137).  On an irregular rocks mesh — most cells
         // without a usable far bound — yes (555 us against 327 + 270).
-        const bool rocks_too = c->lane_rocks < 0 ? 2 * c->cull_farok[1] < c->cull_cells[1] : c->lane_rocks != 0;
-        if (rocks_too) {
+        if (lane_rocks_too(c)) {
             HIP_TRY(c, launch_raycast_lane(l, s));
         } else {
             // the terrain rays (the first E x P of the sorted list: terrain bins sort first) through the staged kernel, the rock rays — few per
@@ -1168,6 +1169,9 @@ int rover_get_info(const rover_ctx* c, rover_info* info) {
     info->workspace_bytes = c->workspace_bytes + (c->d_cull_queue ? c->cull_entries * sizeof(uint2) : 0) +
                             (c->d_cull_stats ? (uint64_t)c->cull_stat_slots * sizeof(uint4) : 0);
     info->raycast_variant = (c->have_map[0] && c->have_map[1]) ? effective_variant(c) : 0;
+    info->cell_index_mode = c->cell_rcp; info->ray_precision = c->precision;
+    info->raycast_sorted = info->raycast_variant >= 2 && !lane_env_order(c, info->raycast_variant);
+    info->raycast_rocks_staged = info->raycast_variant == 4 && (!info->raycast_sorted || lane_rocks_too(c)) ? 1 : 0;
     return ROVER_OK;
 }
 

@@ -236,10 +236,14 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
         if (task < 3u) {
             // one atan2 / asin and one sin / cos pair (yaw: also the heading): a third of the dependent chain each (one wave doing all
             // three angles kept the other seven waiting 1.5 us at the barrier)
-            const float* qp = a.euler_in ? a.euler_in : a.quat + 4ull * ec;
-            const float q[4] = {qp[0], qp[1], qp[2], a.euler_in ? 0.0f : qp[3]};
-            float ang = task == 0u ? quat_roll(q) : (task == 1u ? quat_pitch(q) : quat_yaw(q));
-            if (a.euler_in) ang = a.euler_in[3ull * ec + task];
+            float ang;
+            if (a.euler_in) {                   // (wave-uniform) the pose's euler angles as given: rover_get_depths / rover_get_collisions
+                ang = a.euler_in[3ull * ec + task];
+            } else {
+                const float* qp = a.quat + 4ull * ec;
+                const float q[4] = {qp[0], qp[1], qp[2], qp[3]};
+                ang = task == 0u ? quat_roll(q) : (task == 1u ? quat_pitch(q) : quat_yaw(q));
+            }
             s_trig[task][lane] = make_float2(sinf(-ang), cosf(-ang));
             if (blockIdx.y == 0u && live) {
                 if (a.euler) a.euler[3ull * e + task] = ang;

@@ -4,11 +4,14 @@ The reference is single-device (``rover.py:90`` hard-codes ``cuda:0``) and has n
 Envs are independent, terrain / rock / stone tables are read-only and replicated on every GPU, so the
 only exchange of a step is handing (obs f32, reward f32, done u8) of every shard to the learner rank — done
 travels as one byte per env (``rover_step_out.done_u8``, written by the is_done stage next to the int64
-``reset_buf``), not as the 8-byte flag.  That is done
-as ONE grouped point-to-point operation (``batch_isend_irecv`` = a single ncclGroup of send/recv on RCCL):
-each rank sends its three buffers straight into the root's global tensors, so the 7 inbound shards of an
-8-GPU node arrive over 7 distinct xGMI links and nothing is re-packed or copied afterwards.  (A ring
-all-gather would be per-link bound: 7 hops instead of 1.)
+``reset_buf``), not as the 8-byte flag.
+
+A rank's three outputs live in ONE contiguous byte buffer, laid out by the step kernels themselves (they take plain
+pointers: ``obs`` with its row stride, ``rew`` and ``done_u8`` behind it), so a step costs one message per peer: every
+non-root rank posts ONE send, the root ONE receive per peer, straight into that rank's slice of the root's buffer —
+7 receives on an 8-GPU node, over 7 distinct xGMI links, nothing re-packed or copied afterwards.  (A ring all-gather
+would be per-link bound: 7 hops instead of 1; three messages per peer — obs, rew, done apart — were 21 receives.)
+The sends and receives of a step go out as one ``batch_isend_irecv`` (a single ncclGroup on RCCL).
 
 The same code runs on ``gloo`` (CPU tensors) for the world_size-2 tests.
 """
@@ -16,6 +19,12 @@ from __future__ import annotations
 
 import torch
 import torch.distributed as dist
+
+
+def shard_bytes(num_envs_local: int, obs_dim: int) -> int:
+    """Bytes of one rank's packed (obs f32 [E, W] | rew f32 [E] | done u8 [E]) shard, padded to 256 B so that every shard (and every
+    view inside it) starts aligned."""
+    return (num_envs_local * (4 * obs_dim + 4 + 1) + 255) // 256 * 256
 
 
 def shard_range(num_envs_global: int, world: int, rank: int):
@@ -44,29 +53,43 @@ class StepGather:
         self.E, self.W, self.world, self.rank, self.root, self.group = num_envs_local, obs_dim, world, rank, root, group
         self.is_root = rank == root
         self.depth = depth
-        n = num_envs_local * (world if self.is_root else 1)
-        lo = rank * num_envs_local if self.is_root else 0
-        self._sets = []
+        self.sb = shard_bytes(num_envs_local, obs_dim)
+        n_shards = world if self.is_root else 1
+        self._mine = rank if self.is_root else 0             # index of this rank's own shard in its buffer
+        self._bufs = []
         for _ in range(depth):
-            obs_g = torch.zeros(n, obs_dim, dtype=torch.float32, device=device)
-            rew_g = torch.zeros(n, dtype=torch.float32, device=device)
-            reset_g = torch.ones(n, dtype=torch.uint8, device=device)     # done flags, 1 B per env (reset_buf starts at 1, rl_task.py:105)
-            self._sets.append((obs_g, rew_g, reset_g))
+            buf = torch.zeros(n_shards * self.sb, dtype=torch.uint8, device=device)
+            self._bufs.append(buf)
+            for k in range(n_shards):
+                self._views(buf, k)[2].fill_(1)              # done flags start at 1 (reset_buf, rl_task.py:105)
         self._pending = [None] * depth
-        self._lo = lo
-        # depth-1 interface (kept): the global tensors and the local views of set 0
-        self.obs_g, self.rew_g, self.reset_g = self._sets[0]
+        # depth-1 interface (kept): the local views of set 0
         self.obs, self.rew, self.reset = self.local_views(0)
 
+    def _views(self, buf, k):
+        """(obs f32 [E, W], rew f32 [E], done u8 [E]) of shard ``k`` of a packed buffer: views, no copies."""
+        e, w, base = self.E, self.W, k * self.sb
+        o = buf[base: base + 4 * e * w].view(torch.float32).view(e, w)
+        r = buf[base + 4 * e * w: base + 4 * e * w + 4 * e].view(torch.float32)
+        z = buf[base + 4 * e * w + 4 * e: base + 4 * e * w + 5 * e]
+        return o, r, z
+
     def local_views(self, d: int = 0):
-        o, r, z = self._sets[d]
-        s = slice(self._lo, self._lo + self.E)
-        return o[s], r[s], z[s]
+        """What the step kernels of this rank write for buffer set ``d``: obs [E, W] (contiguous rows), rew [E], done u8 [E]."""
+        return self._views(self._bufs[d], self._mine)
 
     def global_views(self, d: int = 0):
-        """The gathered (obs f32 [N*E, W], rew f32 [N*E], done u8 [N*E]) of set ``d`` on the root (None elsewhere); valid after
-        ``wait(d)``."""
-        return self._sets[d] if self.is_root else None
+        """The gathered shards of set ``d`` on the root (None elsewhere) as strided views of the packed buffer — obs f32 [N, E, W],
+        rew f32 [N, E], done u8 [N, E], shard r = rank r's envs —; valid after ``wait(d)``.  (``.reshape(N * E, ...)`` copies: a
+        learner that wants one flat batch pays that copy once, or indexes by [rank, env].)"""
+        if not self.is_root:
+            return None
+        buf, e, w, n, sb = self._bufs[d], self.E, self.W, self.world, self.sb
+        f = buf.view(torch.float32)                          # (sb is a multiple of 256: every shard starts on a float)
+        obs = torch.as_strided(f, (n, e, w), (sb // 4, w, 1))
+        rew = torch.as_strided(f, (n, e), (sb // 4, 1), storage_offset=e * w)
+        done = torch.as_strided(buf, (n, e), (sb, 1), storage_offset=4 * e * w + 4 * e)
+        return obs, rew, done
 
     def wait(self, d: int = 0):
         """Order the current stream behind the outstanding transfer of set ``d`` (no-op if there is none)."""
@@ -77,26 +100,16 @@ class StepGather:
         self._pending[d] = None
 
     def gather(self, d: int = 0, wait: bool = True):
-        """After the step kernels of every rank were enqueued: returns the global (obs, rew, reset) on root."""
+        """After the step kernels of every rank were enqueued: ONE message per peer — the rank's packed shard — to the root."""
         if self.world == 1:
-            return self._sets[d]
+            return self.global_views(d)
         self.wait(d)
-        obs_g, rew_g, reset_g = self._sets[d]
-        ops = []
+        buf, sb = self._bufs[d], self.sb
         if self.is_root:
-            for r in range(self.world):
-                if r == self.root:
-                    continue
-                s = slice(r * self.E, (r + 1) * self.E)
-                ops += [dist.P2POp(dist.irecv, obs_g[s], r, self.group),
-                        dist.P2POp(dist.irecv, rew_g[s], r, self.group),
-                        dist.P2POp(dist.irecv, reset_g[s], r, self.group)]
+            ops = [dist.P2POp(dist.irecv, buf[r * sb:(r + 1) * sb], r, self.group) for r in range(self.world) if r != self.root]
         else:
-            obs, rew, reset = self.local_views(d)
-            ops = [dist.P2POp(dist.isend, obs, self.root, self.group),
-                   dist.P2POp(dist.isend, rew, self.root, self.group),
-                   dist.P2POp(dist.isend, reset, self.root, self.group)]
+            ops = [dist.P2POp(dist.isend, buf, self.root, self.group)]
         self._pending[d] = dist.batch_isend_irecv(ops)
         if wait:
             self.wait(d)
-        return self._sets[d] if self.is_root else None
+        return self.global_views(d)

@@ -1,6 +1,7 @@
 """CPU: host-side logic around the hot path — distribution table, asset formats, history buffer, sharding,
 the world_size-2 gather, and that the C-ABI library loads and exports every declared symbol."""
 import os
+import types
 import re
 import subprocess
 import sys
@@ -156,7 +157,8 @@ for step in range(3):
     reset.copy_((torch.arange(lo, hi) + step) % 2)
     out = g.gather()
     if rank == 0:
-        O, R, D = out
+        O, R, D = (t.reshape(E * world, *t.shape[2:]) for t in out)      # packed shards [N, E, ...] -> one flat batch
+        assert out[0].shape == (world, E, W) and out[2].dtype == torch.uint8
         allids = torch.arange(E * world, dtype=torch.float32)
         assert torch.equal(O, allids[:, None] * 10 + torch.arange(W) + step)
         assert torch.equal(R, allids + 0.5 * step)
@@ -170,7 +172,7 @@ for step in range(5):
     d = step % 2
     g2.wait(d)
     if rank == 0 and step >= 2:                      # the learner reads step - 2 before the set is overwritten
-        O, R, D = g2.global_views(d)
+        O, R, D = (t.reshape(E * world, *t.shape[2:]) for t in g2.global_views(d))
         allids = torch.arange(E * world, dtype=torch.float32)
         assert torch.equal(O, allids[:, None] * 10 + torch.arange(W) + (step - 2))
         assert torch.equal(D.long(), (torch.arange(E * world) + step - 2) % 2)
@@ -184,7 +186,13 @@ for d in range(2):
     g2.wait(d)
 if rank == 0:
     O, R, D = g2.global_views(0)
-    assert torch.equal(R, torch.arange(E * world, dtype=torch.float32) + 0.5 * 4)
+    assert torch.equal(R.reshape(-1), torch.arange(E * world, dtype=torch.float32) + 0.5 * 4)
+    # one message per peer: the root's buffer is world x shard_bytes, a sender's exactly one shard
+    from isaac_rover_amd.distributed import shard_bytes
+    assert g2._bufs[0].numel() == world * shard_bytes(E, W) and shard_bytes(E, W) % 256 == 0
+else:
+    from isaac_rover_amd.distributed import shard_bytes
+    assert g2._bufs[0].numel() == shard_bytes(E, W)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -221,11 +229,10 @@ for i in range(STEPS):
     d = i % 2
     g.wait(d)                                    # the transfer that last read / filled set d (step i - 2) must be through ...
     if rank == 0 and i >= 2:                     # ... and then the root holds step i - 2 of EVERY shard, whatever happened to the other set since
-        O, R, D = g.global_views(d)
+        O, R, D = g.global_views(d)                  # [N, E, W], [N, E], [N, E]: shard r = rank r
         for r in range(world):
-            s = slice(r * E, (r + 1) * E)
-            assert torch.all(O[s] == value(i - 2, r)), (i, r, O[s][0, 0].item())
-            assert torch.all(R[s] == value(i - 2, r) + 1.0) and torch.all(D[s] == (i - 2 + r) % 2)
+            assert torch.all(O[r] == value(i - 2, r)), (i, r, O[r][0, 0].item())
+            assert torch.all(R[r] == value(i - 2, r) + 1.0) and torch.all(D[r] == (i - 2 + r) % 2)
         seen.append(i - 2)
     o, rw, dn = g.local_views(d)                 # "the step kernels" of step i write set d
     o.fill_(value(i, rank)); rw.fill_(value(i, rank) + 1.0); dn.fill_((i + rank) % 2)
@@ -240,7 +247,7 @@ if rank == 0:
     for i in (STEPS - 2, STEPS - 1):
         O, R, D = g.global_views(i % 2)
         for r in range(world):
-            assert torch.all(O[r * E:(r + 1) * E] == value(i, r)), (i, r)
+            assert torch.all(O[r] == value(i, r)), (i, r)
     assert seen == list(range(STEPS - 2))
 dist.barrier()
 dist.destroy_process_group()
@@ -305,7 +312,7 @@ print("rank", os.environ["RANK"], "done", file=sys.stderr)
 sys.exit(rc)
 """
 
-_BENCH_ARGS = ["--steps", "7", "--warmup", "3", "--envs-per-gpu", "64", "--preroll-ms", "20"]
+_BENCH_ARGS = ["--steps", "7", "--warmup", "3", "--envs-per-gpu", "64", "--preroll-ms", "20", "--passes", "3"]
 
 
 def _check_bench_line(out, extra):
@@ -322,8 +329,27 @@ def _check_bench_line(out, extra):
     assert len(d["per_rank"]["ms_per_step"]) == 2 and all(x > 0 for x in d["per_rank"]["ms_per_step"])
     alt = d["alt_sync_gather" if extra == "" else "alt_overlapped"]
     assert alt["gather_check"] is True and alt["value"] > 0
-    assert d["gather_bytes_per_rank_per_step"] == 64 * (4 * 41 + 4 + 1)
+    assert d["gather_bytes_per_rank_per_step"] == 64 * (4 * 41 + 4 + 1) and d["gather_messages_per_peer_per_step"] == 1
+    assert d["passes"]["n"] == 3 and d["passes"]["min_ms_per_step"] <= d["ms_per_step"] <= d["passes"]["max_ms_per_step"]
+    assert "BASELINE configs" not in d["config"]["workload"]      # 64 envs per rank is none of BASELINE.json's configs
     return d
+
+
+def test_bench_labels_name_a_baseline_config_only_when_everything_matches():
+    """bench.config_label: "BASELINE configs[k]" needs the batch size, the ray set, K, cells, stones, mesh, arithmetic and GPU count of
+    that config (BASELINE.json); `--gpus 8 --envs-per-gpu 32768` IS configs[3], 8 x 65 536 is weak scaling of configs[2]."""
+    import bench
+    base = dict(k=200, cells=600, stones=1024, mesh="grid", ray_precision="fp32", graph=False, rays="37", validate_goals=False)
+    A = lambda **kw: types.SimpleNamespace(**{**base, **kw})
+    assert bench.config_label(A(), 65536, 1, 65536) == "BASELINE configs[2]"
+    assert bench.config_label(A(), 4096, 1, 4096) == "BASELINE configs[1]"
+    assert bench.config_label(A(rays="120", validate_goals=True), 65536, 1, 65536) == "BASELINE configs[4]"
+    assert bench.config_label(A(), 32768, 8, 262144) == "BASELINE configs[3]"
+    assert "shard of BASELINE configs[3]" in bench.config_label(A(), 32768, 1, 32768)
+    assert bench.config_label(A(), 65536, 8, 524288).startswith("weak scaling of BASELINE configs[2]")
+    for kw, e in ((dict(rays="native"), 4096), (dict(mesh="irregular"), 65536), (dict(ray_precision="fp16_as_shipped"), 65536), (dict(k=64), 65536),
+                  (dict(cells=300), 4096), (dict(rays="120"), 65536), (dict(), 512), (dict(), 32000)):
+        assert "BASELINE" not in bench.config_label(A(**kw), e, 1, e).replace("no BASELINE config", ""), (kw, e)
 
 
 @pytest.mark.parametrize("extra", ["", "--sync-gather"])
