@@ -36,6 +36,10 @@ struct rover_ctx {
     // tables of the staged ray cast (variant 4; f32 proof): per cell the pair records in group-bound order, their ids, the suffix bounds
     LaneTables lane[2]{}, lane_h[2]{};  // per map: f32 proof / as-shipped fp16 proof
     uint32_t lane_pp[2]{0, 0};
+    hipStream_t side = nullptr;         // variant 4: the rocks part's launch runs beside the terrain part's, on this stream, between two events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int lane_side_stream = 0;           // ROVER_LANE_SIDE_STREAM=1: side by side (measured: 125 against 127 M env-steps/s one after the other — the two launches
+                                        // slow each other down by more than the rocks launch's ramp and tail cost; kept as a switch)
     int lane_env_order = -1;            // variant 4 without the sort (the ray slots in env order): -1 auto (mid-size batches), 0 / 1 (option "lane_env_order")
     int lane_rocks = -1;                // variant 4: the rocks part of the sorted list through the staged kernel too: -1 auto, 0 / 1 (option "lane_rocks", ROVER_LANE_ROCKS)
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
@@ -427,6 +431,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.num_envs_global <= 0) c->cfg.num_envs_global = c->cfg.num_envs;
     if (c->cfg.max_episode_length <= 0) c->cfg.max_episode_length = 3000;
+    if (const char* v = getenv("ROVER_LANE_SIDE_STREAM")) c->lane_side_stream = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("ROVER_LANE_ENV_ORDER")) c->lane_env_order = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("ROVER_LANE_ROCKS")) c->lane_rocks = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 4) ? x : 0; }
@@ -441,6 +446,11 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_goal_work, 2 * (size_t)cfg->num_envs * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ids_work, (size_t)cfg->num_envs * sizeof(int64_t));
     if (e != hipSuccess) { delete c; return fail(nullptr, ROVER_E_HIP, "rover_create: %s", hipGetErrorString(e)); }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        c->side = nullptr;              // (no side stream: the launches run one after the other)
+    }
     *out = c;
     return ROVER_OK;
 }
@@ -459,6 +469,9 @@ void rover_destroy(rover_ctx* c) {
     dfree(c->d_block_cnt);
     dfree(c->d_goal_work);
     dfree(c->d_cull_queue); dfree(c->d_cull_stats); dfree(c->d_mlp_scratch);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& e : c->ev0) (void)hipEventDestroy(e);
     for (auto& e : c->ev1) (void)hipEventDestroy(e);
     delete c;
@@ -801,10 +814,20 @@ static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t 
             // where the staged kernel reads the 3.5 KB of a cell's whole row for one such ray
             CullArgs a = cull_args(c, n_valid);
             l.n_sorted = l.n_terrain < n_valid ? l.n_terrain : n_valid;
-            HIP_TRY(c, launch_raycast_lane(l, s));
             a.sorted += l.n_sorted; a.n_sorted -= l.n_sorted; a.n_terrain = 0;
             a.stats += lane_waves(l.n_sorted, l.run);
-            if (a.n_sorted) HIP_TRY(c, launch_raycast_culled(a, s));
+            // the two launches touch disjoint rays, results and counters and could run side by side (fork / join by events); measured, that is
+            // no faster than one after the other (lane_side_stream)
+            const bool beside = c->lane_side_stream && c->side && a.n_sorted;
+            if (beside) {
+                HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+                HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                HIP_TRY(c, launch_raycast_culled(a, c->side));
+                HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+            }
+            HIP_TRY(c, launch_raycast_lane(l, s));
+            if (beside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+            else if (a.n_sorted) HIP_TRY(c, launch_raycast_culled(a, s));
         }
     } else if (variant == 3)
         HIP_TRY(c, launch_raycast_culled(cull_args(c, n_valid), s));

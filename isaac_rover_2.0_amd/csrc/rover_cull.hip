@@ -919,15 +919,15 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // pair of their cell is a candidate.  The kernel serves ONE map; the host runs it on the terrain part of the sorted list.
 //
 // Test (A) on these records.  A pair record holds, per triangle, m' = fp16(m - C) (m: ctab's sphere centre, C = (cell centre, z_c) in
-// f32) and r2' (fp16, rounded up) >= 1.19 (rho~ + e + 1e-3)^2 with rho~ >= the radius of the padded triangle about m (from ctab's own r2)
+// f32) and r2' (fp16, rounded up) >= 1.19 (rho~ + e + p)^2 (p = LN_PAD = 5e-5) with rho~ >= the radius of the padded triangle about m (from ctab's own r2)
 // and e = |C + m' - m| the encoding's displacement, computed in double from the decoded values: the sphere about M = C + m' of radius
 // rho' = rho~ + e contains the padded triangle.  A lane computes s' = fl(s - C), h^ = fl(s' - m') (each component within 2.4e-7 |h| +
 // 5e-7 of the true h = s - M: two roundings of magnitudes <= |h| + |m'|, |m'| <= 4 m enforced by the builder), q = |h^|^2, t = h^ . d,
 // u = fl(fl(0.995 q - r2') - t^2) and culls iff u >= +0.  Rounding of q, t, u moves the inequality by < 3e-6 |h^|^2 + 3e-7 r2', so
-// u >= 0 gives W^ ^2 >= 0.004997 |h^|^2 + 1.19 (1 - 3e-7) (rho' + 1e-3)^2 for the distance W^ from M to the line through M + h^; by
-// Cauchy-Schwarz W^ >= 0.02126 |h^| + 1.0404 (rho' + 1e-3), and the true line is within |h - h^| <= 4.2e-7 |h| + 8.7e-7 of that one:
-// W >= 0.0212 |h| + 1.0404 rho' + 1.03e-3 > rho' + 0.02 (|h| + 2 rho'), which is all the rejection proof at the top of this file uses
-// of test (A).  The millimetre in r2' is what pays for the relative coordinates (a per cent of a 0.1 m triangle's radius).
+// u >= 0 gives W^ ^2 >= 0.004997 |h^|^2 + 1.19 (1 - 3e-7) (rho' + p)^2 for the distance W^ from M to the line through M + h^; by
+// Cauchy-Schwarz W^ >= 0.02126 |h^| + 1.0404 (rho' + p), and the true line is within |h - h^| <= 4.2e-7 |h| + 8.7e-7 of that one:
+// W >= 0.02125 |h| + 1.0404 rho' + 1.04 p - 9e-7 > rho' + 0.02 (|h| + 2 rho') for every p >= 1e-6, which is all the rejection proof at the
+// top of this file uses of test (A).  (p = 1e-3 cost a tenth more candidates: 3.95 pairs per ray against 3.6 with 5e-5.)
 // Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are treated like rays off the cone path.
 // ---------------------------------------------------------------------------------------------------
 #define LN_CH 16u                    // pairs per chunk (one 256-byte piece of a cell's record row; one 16-bit candidate mask)
@@ -943,6 +943,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 #define LN_QGOOD_H 0.2f
 #endif                // a triangle whose normal is farther than 60 degrees from the vertical is ordered in front of the others (so that the suffixes keep a cone)
 #define LN_QCAP 1024u                // 2-byte queue entries per wave
+#define LN_PAD 5.0e-5                // added to a triangle's radius: what pays for the relative coordinates' rounding (header comment: >= 1e-6 would do)
 #ifndef LN_AB
 #define LN_AB 8u                     // pair records an item keeps in flight (test (A) only / tests (A) and (B): two records per pair)
 #endif
@@ -1017,7 +1018,7 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
                          ez = (double)zc + (double)(float)hz - (double)mz;
             const double enc = sqrt(ex * ex + ey * ey + ez * ez);
             const double rho = sqrt((double)r2c / c_rho);                     // >= rho + 1e-4 of the ctab record (its r2 >= c_rho (rho + 1e-4)^2)
-            const double need = c_rho * (rho + enc + 1.0e-3) * (rho + enc + 1.0e-3) * 1.000001;
+            const double need = c_rho * (rho + enc + LN_PAD) * (rho + enc + LN_PAD) * 1.000001;
             if (need < 6.0e4) {
                 r2b = half_bits_up((float)(need * 1.0000001));
                 if (r2b < 0x0400u) r2b = 0x0400u;                              // no fp16 denormals
@@ -1139,7 +1140,8 @@ template <int HI> __device__ __forceinline__ float mix_fma(uint32_t packed, floa
 template <int H>
 __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, const RawTri* __restrict__ rt0, const RawTri* __restrict__ rt1,
                                            const uint2* __restrict__ lid0, const uint2* __restrict__ lid1, uint32_t pp01, const uint16_t* q, uint32_t n,
-                                           uint32_t gid, uint32_t cellm, uint32_t lane, uint32_t* bk) {
+                                           const float4* s_abs /* LDS: per run position {origin, -}, {direction, -} as the ray record holds them */,
+                                           uint32_t cellm, uint32_t lane, uint32_t* bk) {
     if (n == 0u) return;
     auto ids_of = [&](uint32_t i, uint32_t& pos, uint32_t& map) {
         const uint32_t e = q[min(i, n - 1u)];
@@ -1149,19 +1151,32 @@ __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, cons
         const uint32_t pp = map ? pp01 >> 16 : pp01 & 0xffffu;
         return (map ? lid1 : lid0)[(uint64_t)(c & 0x7fffffffu) * pp + (e >> 6)];
     };
+    // Two rounds in flight: while round k's 64 entries are evaluated, round k + 1's triangle / ray records (addressed through its ids,
+    // which arrived during round k - 1) and round k + 2's ids are on their way — a round waits for memory only where the arithmetic of
+    // the round before was shorter than a gather's latency.
+    struct Recs { RawTri r0, r1; float4 ra, rb; uint32_t id0, id1, pos; };
+    auto recs_of = [&](uint2 idp, uint32_t pos, uint32_t map) {
+        Recs x;
+        const RawTri* rt = map ? rt1 : rt0;
+        x.id0 = idp.x; x.id1 = idp.y; x.pos = pos;
+        x.r0 = rt[x.id0 == CULL_NOID ? 0u : x.id0]; x.r1 = rt[x.id1 == CULL_NOID ? 0u : x.id1];
+        x.ra = s_abs[2u * pos]; x.rb = s_abs[2u * pos + 1u];          // (from LDS: two gathers less per round)
+        return x;
+    };
     uint32_t pos_next, map_next;
     uint2 id_next = ids_of(lane, pos_next, map_next);
+    Recs nx = recs_of(id_next, pos_next, map_next);
+    if (64u < n) id_next = ids_of(64u + lane, pos_next, map_next);
     for (uint32_t base = 0; base < n; base += 64u) {
         const bool live = base + lane < n;
-        const uint2 idp = id_next;
-        const uint32_t pos = pos_next;
-        const RawTri* rt = map_next ? rt1 : rt0;
-        const uint32_t id0 = idp.x, id1 = idp.y;
-        const RawTri r0 = rt[id0 == CULL_NOID ? 0u : id0], r1 = rt[id1 == CULL_NOID ? 0u : id1];
-        const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)gid);
-        const float4* rp = reinterpret_cast<const float4*>(rays + g);
-        const float4 ra = rp[0], rb = rp[1];
-        if (base + 64u < n) id_next = ids_of(base + 64u + lane, pos_next, map_next);
+        const Recs cur = nx;
+        if (base + 64u < n) {
+            nx = recs_of(id_next, pos_next, map_next);
+            if (base + 128u < n) id_next = ids_of(base + 128u + lane, pos_next, map_next);
+        }
+        const RawTri r0 = cur.r0, r1 = cur.r1;
+        const float4 ra = cur.ra, rb = cur.rb;
+        const uint32_t id0 = cur.id0, id1 = cur.id1, pos = cur.pos;
         float best;
         if (H) {
             h2 v[9];
@@ -1211,6 +1226,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     __shared__ uint16_t s_cand[64 * LN_MAXCH];            // candidate mask of (ray, chunk): bit 15 - i = pair i of the chunk
     __shared__ uint16_t s_q[LN_QCAP];                     // ray | pair position << 6
     __shared__ uint32_t s_bk[64];
+    __shared__ float4 s_abs[128];                         // the ray records' origins and directions, for the exact phase
     const uint32_t lane = threadIdx.x, x = blockIdx.x & 7u, qx = blockIdx.x >> 3, w = qx & 3u, jslot = qx >> 2;
     // blocks [0, split): runs of `run` rays of the terrain part of the sorted list, then runs of `run_r` rays of the rocks part, dealt
     // to the XCDs like cull_scan_kernel's (chunks of blocks round robin: neighbouring bins share an L2)
@@ -1308,6 +1324,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     {
         const char* rowp = reinterpret_cast<const char*>(map ? lrec1 : lrec0) + (uint64_t)cell * (2u * 16u) * pp;
         const uint64_t ra64 = (uint64_t)reinterpret_cast<uintptr_t>(rowp);
+        s_abs[2u * lane] = rsa; s_abs[2u * lane + 1u] = rsb;
         s_ray[2u * lane] = make_float4(sx, sy, sz, rsb.x);
         s_ray[2u * lane + 1u] = make_float4(rsb.y, rsb.z, __uint_as_float((uint32_t)ra64), __uint_as_float((uint32_t)(ra64 >> 32)));
         uint32_t off_a = base_a, off_b = base_b;
@@ -1383,7 +1400,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     auto flush = [&]() {
         wave_lds_sync();
         lap(3);
-        lane_exact<H>(rays, rtab0, rtab1, lid0, lid1, pp01, s_q, cused, gid, key, lane, s_bk);
+        lane_exact<H>(rays, rtab0, rtab1, lid0, lid1, pp01, s_q, cused, s_abs, key, lane, s_bk);
         ctot += cused;
         cused = 0;
         ++n_flush;
