@@ -379,8 +379,13 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
     else:
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     head["stall_frac"] = stall
+    # (the staged kernel's plain and mixed / packed f32 instructions share the kind counters: its VALU figure is a bracket — the lower bound
+    #  prices every f32 instruction at the plain rate — and the verdict uses the bracket's middle)
+    v_est = valu_obj["frac"]
+    if v_est is not None and valu_obj.get("frac_lower_bound") is not None and info.raycast_variant == 4:
+        v_est = 0.5 * (v_est + valu_obj["frac_lower_bound"])
     head["limited_by"] = (None if head["frac"] is None else
-                          ("hbm" if head["frac"] >= 0.7 else ("valu issue" if (valu_obj["frac"] or 0) >= 0.7 else "latency (neither roof reached)")))
+                          ("hbm" if head["frac"] >= 0.7 else ("valu issue" if (v_est or 0) >= 0.7 else "latency (neither roof reached)")))
     head.update({"kernel": {4: "lane_scan_kernel", 3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "launches_timed_every": int(getattr(args, "event_every", 1)), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
