@@ -30,18 +30,21 @@ for c in range(cases):
     scene = synth.make_scene(n_cells=cells, k=k, n_stones=8)
     outs = {}
     base = 2 if prec == 2 else 1        # (the as-shipped fp16 arithmetic exists in the sorted kernels only)
-    for variant in (base, 3, 2):
+    for variant in (base, 3, 2, 4, 40, 41):          # 4: staged; 40: staged in env order (no sort); 41: staged, rocks part too
         if variant in outs:
             continue
-        eng = make_engine(scene, distn, n, variant=variant)
+        eng = make_engine(scene, distn, n, variant=min(variant, 4))
         eng.set_option("ray_precision", prec)
+        if variant >= 4:
+            eng.set_option("lane_env_order", 1 if variant == 40 else 0)
+            eng.set_option("lane_rocks", 1 if variant == 41 else 0)
         res = []
         for step in range(2):
             st = synth.make_states(n, cells * 0.1, seed=1000 * c + step)
             res.append(hip_step(eng, st))
         eng.close()
         outs[variant] = res
-    for variant in (3, 2):
+    for variant in (3, 2, 4, 40, 41):
         for step in range(2):
             for key in outs[base][step]:
                 a, b = outs[base][step][key], outs[variant][step][key]
@@ -49,4 +52,4 @@ for c in range(cases):
                     raise SystemExit(f"MISMATCH case {c}: envs {n} points {p} cells {cells} K {k} precision {prec} variant {variant} step {step}: {key}")
     rays += 2 * n * (26 + p)
     print(f"case {c}: envs {n}, {p} + 26 rays (R8 = {(26 + p + 7) // 8 * 8}), {cells} x {cells} cells, K = {k}, precision {prec}: ok", flush=True)
-print(f"fuzz ok: {cases} shapes, {rays / 1e6:.1f} M rays x 2 comparisons, all bit-identical")
+print(f"fuzz ok: {cases} shapes, {rays / 1e6:.1f} M rays x 5 comparisons, all bit-identical")

@@ -83,10 +83,14 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
     P = distn[0].shape[0]
     engs = {}
     for name, (variant, early, prec) in {"culled": (3, 1, 0), "culled_other": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
-                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2)}.items():
+                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2),
+                                         "staged": (4, 1, 0), "staged_rocks": (4, 1, 0), "staged_envorder": (4, 1, 0), "h_staged": (4, 1, 2)}.items():
         e = make_engine(name)
         e.set_scene(scene, distn)
         e.set_option("raycast_variant", variant); e.set_option("raycast_early_out", early); e.set_option("ray_precision", prec)
+        if variant == 4:       # the staged kernel: rocks part on the culled kernel / on the staged kernel too / no sort at all
+            e.set_option("lane_rocks", 1 if name in ("staged_rocks", "h_staged") else 0)
+            e.set_option("lane_env_order", 1 if name == "staged_envorder" else 0)
         engs[name] = e
     other_kernel(engs, scene, distn)
     print(f"irregular seed {seed}: {scene.terrain.triangles.shape[0]} triangles ({scene.rocks.triangles.shape[0]} on rocks), K={k}, {extent} m", flush=True)
@@ -105,7 +109,8 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
             st["pos"][:, 0] = torch.from_numpy(x).float(); st["pos"][:, 1] = torch.from_numpy(y).float()
             st["pos"][:, 2] = torch.from_numpy(zf(x, y)).float() + 0.3
         outs = run_engines(engs, st, P)
-        compare(outs, (("culled", "envorder"), ("culled_other", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"), ("h_culled", "h_noearly")),
+        compare(outs, (("culled", "envorder"), ("culled_other", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"), ("h", "h_noearly"), ("h_culled", "h_noearly"),
+                      ("staged", "binned_noearly"), ("staged_rocks", "binned_noearly"), ("staged_envorder", "binned_noearly"), ("h_staged", "h_noearly")),
                 f"irregular seed={seed} K={k} round={r}")
         ci = engs["culled"].cull_info()
         irr_total += E * (P + 26)
@@ -116,17 +121,21 @@ for seed, k, extent, n_rocks, coarse, fine, dist_name in ((11, 200, 24.0, 110, 1
     for e in engs.values():
         e.close()
 if irr_rounds > 0:
-    print(f"irregular soak ok: {irr_total / 1e6:.1f} M rays x 7 comparisons on irregular meshes, all bit-identical", flush=True)
+    print(f"irregular soak ok: {irr_total / 1e6:.1f} M rays x 11 comparisons on irregular meshes, all bit-identical", flush=True)
 
 for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"), (16, 128, "9")):
     scene = synth.make_scene(n_cells=cells, k=k, n_stones=max(8, cells * cells // 400), device="cuda")
     distn = synth.ray_distribution(dist_name)
     engs = {}
     for name, (variant, early, prec) in {"culled": (3, 1, 0), "culled_other": (3, 1, 0), "binned": (2, 1, 0), "binned_noearly": (2, 0, 0), "envorder": (1, 0, 0),
-                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2)}.items():
+                                         "h": (2, 1, 2), "h_noearly": (2, 0, 2), "h_culled": (3, 1, 2),
+                                         "staged": (4, 1, 0), "staged_rocks": (4, 1, 0), "staged_envorder": (4, 1, 0), "h_staged": (4, 1, 2)}.items():
         e = make_engine(name)
         e.set_scene(scene, distn)
         e.set_option("raycast_variant", variant); e.set_option("raycast_early_out", early); e.set_option("ray_precision", prec)
+        if variant == 4:       # the staged kernel: rocks part on the culled kernel / on the staged kernel too / no sort at all
+            e.set_option("lane_rocks", 1 if name in ("staged_rocks", "h_staged") else 0)
+            e.set_option("lane_env_order", 1 if name == "staged_envorder" else 0)
         engs[name] = e
     other_kernel(engs, scene, distn)
     P = distn[0].shape[0]
@@ -150,7 +159,8 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
             torch.cuda.synchronize()
             outs[name] = (bufs["ray_dist"], bufs["wheel_dist"], bufs["body_dist"], bufs["rock_collision"], bufs["reset"])
         for a, b in (("culled", "envorder"), ("culled_other", "envorder"), ("culled", "binned_noearly"), ("binned", "envorder"), ("binned", "binned_noearly"),
-                     ("h", "h_noearly"), ("h_culled", "h_noearly")):
+                     ("h", "h_noearly"), ("h_culled", "h_noearly"),
+                     ("staged", "binned_noearly"), ("staged_rocks", "binned_noearly"), ("staged_envorder", "binned_noearly"), ("h_staged", "h_noearly")):
             for x, y, what in zip(outs[a], outs[b], ("ray", "wheel", "body", "coll", "reset")):
                 same = torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all())
                 if not same:
@@ -162,4 +172,4 @@ for k, cells, dist_name in ((200, 300, "120"), (100, 200, "37"), (40, 160, "120"
         print(f"K={k} round {r}: ok, terrain hit rate {hit:.3f}, rays not scanned (on-demand kernel) {ns:.3f}", flush=True)
     for e in engs.values():
         e.close()
-print(f"soak ok: {total / 1e6:.1f} M rays x 7 comparisons, all bit-identical")
+print(f"soak ok: {total / 1e6:.1f} M rays x 11 comparisons, all bit-identical")
