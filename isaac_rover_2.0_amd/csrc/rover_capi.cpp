@@ -46,6 +46,7 @@ struct rover_ctx {
     uint64_t cull_entries = 0;
     uint4* d_cull_stats = nullptr;      // per-wave counters of the last culled launch (rover_get_cull_info)
     uint32_t cull_stat_slots = 0;
+    uint64_t stats_sig = 0;             // how the last launch that wrote the counters cast its rays (run_raycast)
     int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
     int64_t cull_always_h[2]{0, 0}, cull_nocone_h[2]{0, 0};
     int64_t cull_farok[2]{0, 0}, cull_cells[2]{0, 0};      // cells whose far bound can hold for a usual ray (far_build_kernel) / cells
@@ -220,6 +221,10 @@ static uint32_t effective_run(const rover_ctx* c) {
     //  8 192: 39.0 / 39.7 / 37.8 / 36.7; 16 384: 49.1 / 53.0 / 52.7 / 51.3; 32 768: 58.8 / 66.0 / 68.2 / 67.2; 65 536: 66.0 / 77.7 / 82.4 / 81.8;
     //  fp16 at 8 192 envs: 36.3 / 36.0 / 34.8 / 34.1): they keep the older table.  The native ray set on the regular mesh: 512 envs run 16 / 32 /
     //  64 -> 2.56 / 2.61 / 2.46, 1 024 envs 3.10 / 3.33 / 3.32.)
+    // the staged kernel behind the sort wants long runs — a chunk read is shared by the run's rays that test it, a round is fuller —
+    // (whole step, M env-steps/s, runs of 16 / 32 / 64: 8 192 envs 54.5 / 57.6 / 56.0; 16 384: 68.5 / 77.0 / 79.3; 32 768: 82.8 / 98.1 / 110.5;
+    //  65 536: 91.9 / 111.8 / 133.0; 120 + 26 rays 38.5 / 53.9 / 65.0; irregular mesh 67.8 / 92.4 / 104.7)
+    if (effective_variant(c) == 4) return r < 12 ? 32u : 64u;
     if (effective_variant(c) >= 3) {
         const bool quick_rays = c->precision != 2 && 2 * c->cull_farok[0] >= c->cull_cells[0];      // regular mesh (most cells have a far bound), f32 arithmetic
         if (quick_rays) return r < 3 ? 8u : (r < 6 ? 16u : (r < 20 ? 32u : 64u));                   // powers of two: 63 instead of 64 cost 6 %
@@ -271,7 +276,8 @@ static int alloc_cull_queue(rover_ctx* c) {
     const uint64_t entries = cull_queue_entries(valid_rays(c), (uint32_t)c->cfg.num_envs * (uint32_t)c->P, run, c->cull_budget, &c->cull_launches);
     // (the per-wave counters are sized by the RAY count, the queue — once capped by the budget — is not: a second
     //  rover_set_distribution with more rays must grow the counters even when the queue keeps its size)
-    const uint32_t slots = rover::cull_stat_slots(valid_rays(c), run);
+    // (by the PADDED slot count: in env order the staged kernel walks every slot of every env, and its runs are never shorter than `run`)
+    const uint32_t slots = rover::cull_stat_slots((uint64_t)c->cfg.num_envs * c->R8, run < 16u ? run : 16u);
     if (c->d_cull_queue && c->d_cull_stats && entries == c->cull_entries && run == c->cull_run && slots == c->cull_stat_slots) return ROVER_OK;
     dfree(c->d_cull_queue); dfree(c->d_cull_stats);
     c->cull_stat_slots = 0;
@@ -286,6 +292,7 @@ static int alloc_cull_queue(rover_ctx* c) {
     c->cull_entries = entries; c->cull_run = run;
     HIP_TRY(c, hipMalloc((void**)&c->d_cull_stats, (size_t)slots * sizeof(uint4)));
     c->cull_stat_slots = slots;
+    c->stats_sig = 0;
     HIP_TRY(c, hipMemset(c->d_cull_stats, 0, (size_t)c->cull_stat_slots * sizeof(uint4)));
     return ROVER_OK;
 }
@@ -784,6 +791,16 @@ static bool lane_rocks_too(const rover_ctx* c) { return c->lane_rocks < 0 ? 2 * 
 // the ray-cast launch(es) of a step for the variant in force, on the ray records / sorted list in the workspace
 static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
     const uint32_t E = (uint32_t)c->cfg.num_envs;
+    if (variant >= 3 && c->d_cull_stats) {
+        // the per-wave counters of rover_get_cull_info: a launch writes the slots of its own waves; when the way the rays are cast changed
+        // since the last launch (another kernel, order or run length: another number of waves) the slots are cleared first
+        const uint64_t sig = (uint64_t)variant | ((uint64_t)lane_env_order(c, variant) << 8) | ((uint64_t)lane_rocks_too(c) << 9) | ((uint64_t)effective_run(c) << 16) |
+                             ((uint64_t)c->precision << 32);
+        if (sig != c->stats_sig) {
+            HIP_TRY(c, hipMemsetAsync(c->d_cull_stats, 0, (size_t)c->cull_stat_slots * sizeof(uint4), s));
+            c->stats_sig = sig;
+        }
+    }
     if (variant == 4) {
         LaneArgs l{};
         l.rays = c->d_rays; l.sorted = c->d_sorted; l.n_sorted = n_valid; l.n_terrain = E * (uint32_t)c->P;
@@ -798,7 +815,11 @@ static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t 
         }
         l.run = effective_run(c); l.out = c->d_dist_out; l.stats = c->d_cull_stats;
         if (lane_env_order(c, variant)) {      // every slot (padding included), in env order, one launch
-            l.sorted = nullptr; l.n_sorted = E * c->R8; l.n_terrain = l.n_sorted; l.run = 64u;
+            l.sorted = nullptr; l.n_sorted = E * c->R8; l.n_terrain = l.n_sorted;
+            // slots per wave: enough waves to fill 1 024 SIMDs (4 096 envs x 64 slots in runs of 64 are one wave per SIMD).  Whole step, M
+            // env-steps/s, runs of 8 / 16 / 32 / 64: 512 envs 15.0 / 16.3 / 14.9 / 12.7; 1 024: 21.2 / 26.7 / 26.3 / 22.1; 2 048: 27.5 / 35.3 / 37.1 /
+            // 36.6; 4 096: - / 45.0 / 49.8 / 47.2; 8 192: - / 52.6 / 60.1 / 59.2; 120 + 26 rays at 4 096 envs: 19.9 / - / 35.5 / 33.2
+            l.run = c->run ? (c->run > 64u ? 64u : c->run) : ((uint64_t)E * c->R8 >= (1ull << 20) ? 64u : ((uint64_t)E * c->R8 >= (1ull << 17) ? 32u : 16u));
             HIP_TRY(c, launch_raycast_lane(l, s));
             return ROVER_OK;
         }
