@@ -930,9 +930,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // top of this file uses of test (A).  (p = 1e-3 cost a tenth more candidates: 3.95 pairs per ray against 3.6 with 5e-5.)
 // Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are treated like rays off the cone path.
 // ---------------------------------------------------------------------------------------------------
-#define LN_CH 16u                    // pairs per chunk (one 256-byte piece of a cell's record row; one 16-bit candidate mask)
-#define LN_MAXCH 8u                  // chunks per row at most (K8 <= 256: 128 pairs)
-#define LN_LVL 10u                   // float4 per cell of the level table: header {Cx, Cy, z_c, q16}, 8 levels {G, z0, z1, rho_out}, the levels' 8 x 16-bit cones
+#define LN_CH 8u                     // pairs per chunk: one 128-byte line of a cell's record row, one 8-bit candidate mask (16 pairs per chunk: a ray needs
+                                     // 2.4 chunks = 38 pairs on average where 8-pair chunks cover the same prefixes with 28: a third less to test)
+#define LN_MAXCH 16u                 // chunks per row at most (K8 <= 256: 128 pairs)
+#define LN_LVL 11u                   // float4 per cell of the level table: header {Cx, Cy, z_c, q16}, 16 levels x 8 B {G, z0, z1, rho_out} as fp16 (G, z0
+                                     // rounded down, z1, rho_out up), the levels' 16 x 16-bit cones
 // A pair with a triangle whose cone value (f32 proof: |N_z| / |N|; fp16 proof: the largest ray angle it admits, over pi / 2) is below this
 // is ordered in FRONT of the others, so that the suffixes keep a cone rays lie in (0: off.  Grid mesh: 0 / 0.25 / 0.35 / 0.5 -> ray cast 440 /
 // 440 / 440 / 494 us — at 0.5 half of the pairs of a bumpy heightfield are "steep" and every ray's prefix grows —; irregular mesh 811 / 559 / 560 us)
@@ -1077,6 +1079,7 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
     }
     // levels: the bound of the suffix behind the first 16 j pairs
     __shared__ uint32_t s_q16[LN_MAXCH];
+    __shared__ uint2 s_lv[LN_MAXCH];
     if (p < LN_MAXCH) {
         float g = __builtin_inff(), z0 = __builtin_inff(), z1 = -__builtin_inff(), ro = 0.0f, qn = 2.0f;
         for (uint32_t q = p * LN_CH; q < 128u; ++q) {
@@ -1084,7 +1087,12 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
             g = fminf(g, s_g[src]); z0 = fminf(z0, s_z0[src]); z1 = fmaxf(z1, s_z1[src]); ro = fmaxf(ro, s_ro[src]); qn = fminf(qn, s_qn[src]);
         }
         if (!(z0 <= z1)) { z0 = 0.0f; z1 = 0.0f; }
-        lvl[(uint64_t)cell * LN_LVL + 1u + p] = make_float4(g, z0, z1, ro);
+        // fp16, each rounded to the side that keeps the bound a bound (z0, z1 are fp16 values already: the centres' decoded z)
+        auto down = [](float v) { _Float16 h = (_Float16)v; uint16_t b = __builtin_bit_cast(uint16_t, h);
+                                  if ((float)h > v) b = (uint16_t)((b & 0x8000u) ? b + 1u : (b == 0u ? 0x8001u : b - 1u)); return b; };
+        auto up = [](float v) { _Float16 h = (_Float16)v; uint16_t b = __builtin_bit_cast(uint16_t, h);
+                                if ((float)h < v) b = (uint16_t)((b & 0x8000u) ? (b == 0x8000u ? 1u : b - 1u) : b + 1u); return b; };
+        s_lv[p] = make_uint2((uint32_t)down(g) | ((uint32_t)down(z0) << 16), (uint32_t)up(z1) | ((uint32_t)up(ro) << 16));
         // the suffix's normal cone, as idx4_build_kernel encodes a cell's (an empty suffix, or one of always-candidates only — whose G is -inf
         // anyway —: the widest)
         uint32_t q16 = 0xfffeu;
@@ -1092,10 +1100,14 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
         s_q16[p] = q16;
     }
     __syncthreads();
-    if (p == 0) {
-        lvl[(uint64_t)cell * LN_LVL] = make_float4(ccx, ccy, zc, __uint_as_float(qrow[cell]));
-        lvl[(uint64_t)cell * LN_LVL + 9u] = make_float4(__uint_as_float(s_q16[0] | (s_q16[1] << 16)), __uint_as_float(s_q16[2] | (s_q16[3] << 16)),
-                                                        __uint_as_float(s_q16[4] | (s_q16[5] << 16)), __uint_as_float(s_q16[6] | (s_q16[7] << 16)));
+    if (p == 0) lvl[(uint64_t)cell * LN_LVL] = make_float4(ccx, ccy, zc, __uint_as_float(qrow[cell]));
+    if (p < 8u) {           // levels 2p, 2p + 1 in one float4
+        lvl[(uint64_t)cell * LN_LVL + 1u + p] = make_float4(__uint_as_float(s_lv[2u * p].x), __uint_as_float(s_lv[2u * p].y),
+                                                            __uint_as_float(s_lv[2u * p + 1u].x), __uint_as_float(s_lv[2u * p + 1u].y));
+    } else if (p < 10u) {   // cones of levels 8 (p - 8) ... + 7
+        const uint32_t b = 8u * (p - 8u);
+        lvl[(uint64_t)cell * LN_LVL + 9u + (p - 8u)] = make_float4(__uint_as_float(s_q16[b] | (s_q16[b + 1u] << 16)), __uint_as_float(s_q16[b + 2u] | (s_q16[b + 3u] << 16)),
+                                                                 __uint_as_float(s_q16[b + 4u] | (s_q16[b + 5u] << 16)), __uint_as_float(s_q16[b + 6u] | (s_q16[b + 7u] << 16)));
     }
 }
 
@@ -1223,7 +1235,7 @@ template <int H, int DIAG>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
     __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, the cell's record row (64-bit address)}
     __shared__ uint16_t s_items[64 * LN_MAXCH];           // ray | chunk << 6: the items that run test (A) only, behind them the ones that run (A) and (B)
-    __shared__ uint16_t s_cand[64 * LN_MAXCH];            // candidate mask of (ray, chunk): bit 15 - i = pair i of the chunk
+    __shared__ __attribute__((aligned(16))) uint8_t s_cand[64 * LN_MAXCH];             // candidate mask of (ray, chunk): bit 7 - i = pair i of the chunk
     __shared__ uint16_t s_q[LN_QCAP];                     // ray | pair position << 6
     __shared__ uint32_t s_bk[64];
     __shared__ float4 s_abs[128];                         // the ray records' origins and directions, for the exact phase
@@ -1256,10 +1268,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     const uint32_t pp = map ? pp01 >> 16 : pp01 & 0xffffu, nch = pp / LN_CH;
     const float4* lp = (map ? lvl1 : lvl0) + (uint64_t)cell * LN_LVL;
     const float4 hdr = lp[0];
-    float4 lv[LN_MAXCH];
+    float4 lv[8];                                             // 16 levels x {G, z0 | z1, rho_out} (fp16)
 #pragma unroll
-    for (int k = 0; k < (int)LN_MAXCH; ++k) lv[k] = lp[1 + k];
-    const float4 lq = lp[9];                                  // the suffixes' cones, 16 bits each
+    for (int k = 0; k < 8; ++k) lv[k] = lp[1 + k];
+    const float4 lq0 = lp[9], lq1 = lp[10];                   // the suffixes' cones, 16 bits each
     s_bk[lane] = fkey(RAY_MISS);
     // the ray relative to its cell; its level = the first suffix it clears as a group: by distance (far_build_kernel's inequality on the
     // suffix's bound) and, for test (B), by lying inside the suffix's normal cone
@@ -1273,13 +1285,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         const float dxy2 = rsb.x * rsb.x + rsb.y * rsb.y, adz = fabsf(rsb.z), sq = __builtin_amdgcn_sqrtf(dxy2);
         const bool steep = adz * adz >= 0.81f * (dxy2 + adz * adz) * 1.0001f;
         const float dxy1 = sq * 1.0001f;
-        const uint32_t qw[4] = {__float_as_uint(lq.x), __float_as_uint(lq.y), __float_as_uint(lq.z), __float_as_uint(lq.w)};
+        const uint32_t qw[8] = {__float_as_uint(lq0.x), __float_as_uint(lq0.y), __float_as_uint(lq0.z), __float_as_uint(lq0.w),
+                                __float_as_uint(lq1.x), __float_as_uint(lq1.y), __float_as_uint(lq1.z), __float_as_uint(lq1.w)};
 #pragma unroll
         for (int k = (int)LN_MAXCH - 1; k >= 0; --k) {
-            const float dzm = fmaxf(fabsf(sz - lv[k].y), fabsf(sz - lv[k].z));
+            const f2 gz = cvt2(__float_as_uint((k & 1) ? lv[k >> 1].z : lv[k >> 1].x)), zr = cvt2(__float_as_uint((k & 1) ? lv[k >> 1].w : lv[k >> 1].y));
+            const float dzm = fmaxf(fabsf(sz - gz.y), fabsf(sz - zr.x));
             const float e_adz = o * adz + dzm * sq * 1.0001f;
-            const float amax = (dzm * adz + (o + lv[k].w) * dxy1) * 1.0001f;
-            const bool clears = steep && (lv[k].x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * amax * adz) * 1.0001f;
+            const float amax = (dzm * adz + (o + zr.y) * dxy1) * 1.0001f;
+            const bool clears = steep && (gz.x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * amax * adz) * 1.0001f;
             const uint32_t q16 = (k & 1) ? qw[k >> 1] >> 16 : qw[k >> 1] & 0xffffu;
             if ((uint32_t)k < nch && clears && q16 >= rq) L = (uint32_t)k;
         }
@@ -1297,11 +1311,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
         dg[5] = (uint32_t)(tq - t_start);
-        for (uint32_t v = 0; v < 11u; ++v) {                                                  // histogram of the rays' levels behind the per-wave rows
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !map && (allc ? 9u : (ab ? 10u : L)) == v));
-            const uint32_t cnt1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && map && (allc ? 9u : (ab ? 10u : L)) == v));
+        for (uint32_t v = 0; v < 19u; ++v) {                                                  // histogram of the rays' levels behind the per-wave rows
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !map && (allc ? 17u : (ab ? 18u : L)) == v));
+            const uint32_t cnt1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && map && (allc ? 17u : (ab ? 18u : L)) == v));
             if (lane == 0u && cnt) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + v, cnt);
-            if (lane == 0u && cnt1) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + 12u + v, cnt1);
+            if (lane == 0u && cnt1) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + 20u + v, cnt1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
@@ -1389,7 +1403,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
                     mask = __builtin_amdgcn_alignbit(mask, sg, 31);       // (mask << 1) | sign: a pair is a candidate unless every u >= +0
                 }
             }
-            if (ok) s_cand[rl * LN_MAXCH + ch] = (uint16_t)mask;
+            if (ok) s_cand[rl * LN_MAXCH + ch] = (uint8_t)mask;
         }
     };
     rounds(0u, ia_tot, std::false_type{});
@@ -1408,12 +1422,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
         lap(4);
     };
     {
-        uint32_t cm[LN_MAXCH], cnt = 0;
+        uint32_t cm[LN_MAXCH / 4u], cnt = 0;                      // the ray's masks, four chunks per register (chunk k in byte k % 4 of word k / 4)
 #pragma unroll
-        for (uint32_t k = 0; k < LN_MAXCH; ++k) {
-            uint32_t m = 0;
-            if (act && k < L) m = allc ? 0xffffu : (uint32_t)s_cand[lane * LN_MAXCH + k];
-            cm[k] = m; cnt += (uint32_t)__builtin_popcount(m);
+        for (uint32_t k4 = 0; k4 < LN_MAXCH / 4u; ++k4) {
+            uint32_t w4 = allc ? 0xffffffffu : *reinterpret_cast<const uint32_t*>(&s_cand[lane * LN_MAXCH + 4u * k4]);
+            // chunks at and behind the ray's level hold nothing of this step
+            const uint32_t keep = L >= 4u * k4 + 4u ? 0xffffffffu : (L > 4u * k4 ? (1u << (8u * (L - 4u * k4))) - 1u : 0u);
+            w4 = act ? w4 & keep : 0u;
+            cm[k4] = w4; cnt += (uint32_t)__builtin_popcount(w4);
         }
         const uint32_t e_incl = wave_incl_scan(cnt, lane), e_pre = e_incl - cnt;
         const uint64_t actm = __builtin_amdgcn_ballot_w64(act);
@@ -1432,12 +1448,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
             if (act && lane >= r_lo && lane < r_hi) {
                 uint32_t at = cused + (e_pre - base_e);
 #pragma unroll
-                for (uint32_t k = 0; k < LN_MAXCH; ++k) {
-                    uint32_t m = cm[k];
-                    while (m) {
-                        const uint32_t b = 31u - (uint32_t)__builtin_clz(m);           // bit 15 - i = pair i
-                        m &= ~(1u << b);
-                        s_q[at++] = (uint16_t)(lane | ((k * LN_CH + (15u - b)) << 6));
+                for (uint32_t k4 = 0; k4 < LN_MAXCH / 4u; ++k4) {
+                    uint32_t m = cm[k4];
+                    while (m) {             // bit 8 c + 7 - i of the word = pair i of chunk 4 k4 + c
+                        const uint32_t b = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1u;
+                        s_q[at++] = (uint16_t)(lane | (((4u * k4 + (b >> 3)) * LN_CH + (7u - (b & 7u))) << 6));
                     }
                 }
             }
@@ -1626,8 +1642,8 @@ hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
     static const bool want_diag = getenv("ROVER_LANE_DIAG") != nullptr;
     static uint32_t* d_diag = nullptr; static uint32_t diag_waves = 0; static int diag_left = 3;
     const uint32_t waves = g.n_blocks * 4u;
-    if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 32u) * sizeof(uint32_t)); diag_waves = waves; }
-    if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 32u) * sizeof(uint32_t), s);
+    if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 40u) * sizeof(uint32_t)); diag_waves = waves; }
+    if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 40u) * sizeof(uint32_t), s);
     auto kern = a.half ? lane_scan_kernel<1, 0> : (want_diag && d_diag ? lane_scan_kernel<0, 1> : lane_scan_kernel<0, 0>);
     hipLaunchKernelGGL(kern, dim3((g.t8 + g.r8) * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted,
                        a.n_sorted, a.lvl[0], a.lvl[1], a.lrec[0], a.lrec[1], a.lid[0], a.lid[1], reinterpret_cast<const RawTri*>(a.rtab[0]),
@@ -1635,16 +1651,18 @@ hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
                        g.run_r, a.out, a.stats, k2, c_a, (want_diag && !a.half) ? d_diag : nullptr);
     if (want_diag && d_diag && diag_left > 0) {      // where a wave's time goes: mean shader-clock cycles per wave and phase (synchronises: a diagnostic)
         --diag_left;
-        std::vector<uint32_t> h((size_t)waves * 8u + 32u);
+        std::vector<uint32_t> h((size_t)waves * 8u + 40u);
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), d_diag, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t i = 0; i < (size_t)waves * 8u; ++i) sum[i & 7u] += h[i];
             const uint32_t* hg = h.data() + (size_t)waves * 8u;
-            fprintf(stderr, "lane_scan_kernel, %u waves, mean ticks per wave: prologue loads %.0f | bins/scans %.0f | items %.0f | entries %.0f | exact %.0f"
-                    " ; terrain rays by level 0..8: %u %u %u %u %u %u %u %u %u, wild (all pairs candidates): %u, off the cone (tests A and B): %u"
-                    " ; rock rays: %u %u %u %u %u %u %u %u %u, wild %u, off the cone %u\n", waves,
-                    sum[5] / waves, sum[0] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves, hg[0], hg[1], hg[2], hg[3], hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10],
-                    hg[12], hg[13], hg[14], hg[15], hg[16], hg[17], hg[18], hg[19], hg[20], hg[21], hg[22]);
+            fprintf(stderr, "lane_scan_kernel, %u waves, mean ticks per wave: prologue loads %.0f | bins/scans %.0f | items %.0f | entries %.0f | exact %.0f\n", waves,
+                    sum[5] / waves, sum[0] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves);
+            for (int m = 0; m < 2; ++m) {
+                fprintf(stderr, "  %s rays by level 0..16:", m ? "rock" : "terrain");
+                for (int v = 0; v < 17; ++v) fprintf(stderr, " %u", hg[20 * m + v]);
+                fprintf(stderr, ", wild (all pairs candidates): %u, off the cone (tests A and B): %u\n", hg[20 * m + 17], hg[20 * m + 18]);
+            }
         }
     }
     return hipGetLastError();
