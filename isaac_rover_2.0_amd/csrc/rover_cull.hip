@@ -477,7 +477,15 @@ __device__ __forceinline__ void cull_exact(const RayRec* __restrict__ rays, cons
                                            const uint2* lq, uint32_t lcap, const uint2* qw, uint32_t n,
                                            uint32_t gid /* per lane: ray id of run position `lane` */, uint32_t lane, uint32_t* bk) {
     // entry i of the wave's queue: the first lcap in LDS, the rest in its global region
-    auto entry = [&](uint32_t i) { return i < lcap ? lq[i] : qw[i - lcap]; };
+    // (each side through a pointer of its own address space: one generic pointer selected between the two makes the load a FLAT one, which
+    // counts on both wait counters — the compiler then drains every load in flight before it)
+    typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+    auto entry = [&](uint32_t i) {
+        U2 e;
+        if (i < lcap) e = ((const U2 __attribute__((address_space(3)))*)lq)[i];
+        else e = ((const U2 __attribute__((address_space(1)))*)qw)[i - lcap];
+        return make_uint2(e.x, e.y);
+    };
     // The queue entries are read one round ahead: a round then waits for ONE memory round trip (the gathers its entries
     // address: two triangle records and the ray, 72 bytes per lane), not two.
     if (n == 0u) return;
@@ -1092,7 +1100,9 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
                                   if ((float)h > v) b = (uint16_t)((b & 0x8000u) ? b + 1u : (b == 0u ? 0x8001u : b - 1u)); return b; };
         auto up = [](float v) { _Float16 h = (_Float16)v; uint16_t b = __builtin_bit_cast(uint16_t, h);
                                 if ((float)h < v) b = (uint16_t)((b & 0x8000u) ? (b == 0x8000u ? 1u : b - 1u) : b + 1u); return b; };
-        s_lv[p] = make_uint2((uint32_t)down(g) | ((uint32_t)down(z0) << 16), (uint32_t)up(z1) | ((uint32_t)up(ro) << 16));
+        // G with the scan's margins folded in (lane_scan_kernel's level loop); the levels behind the row's last chunk clear nothing
+        const uint16_t gq = p * LN_CH < pp ? down(g * 0.9999f - 1.0e-5f) : (uint16_t)0xfc00u;
+        s_lv[p] = make_uint2((uint32_t)gq | ((uint32_t)down(z0) << 16), (uint32_t)up(z1) | ((uint32_t)up(ro) << 16));
         // the suffix's normal cone, as idx4_build_kernel encodes a cell's (an empty suffix, or one of always-candidates only — whose G is -inf
         // anyway —: the widest)
         uint32_t q16 = 0xfffeu;
@@ -1232,11 +1242,19 @@ __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, cons
         uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
 
 template <int H, int DIAG>
-__global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
+#ifndef LN_WAVES
+#define LN_WAVES 5
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
     __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, the cell's record row (64-bit address)}
-    __shared__ uint16_t s_items[64 * LN_MAXCH];           // ray | chunk << 6: the items that run test (A) only, behind them the ones that run (A) and (B)
+    __shared__ uint16_t s_q[LN_QCAP];                     // the queue of the exact phase: ray | pair position << 6; before it, while the tests run:
+    static_assert(LN_QCAP >= 64 * LN_MAXCH, "the items share the queue's array");
+    uint16_t* const s_items = s_q;                        // ray | chunk << 6: the items that run test (A) only, behind them the ones that run (A) and (B)
+#ifdef LN_LDS_PAD
+    __shared__ uint32_t s_pad[LN_LDS_PAD];
+    if (n_blocks == 0xffffffffu) out[0] = (float)s_pad[threadIdx.x];
+#endif
     __shared__ __attribute__((aligned(16))) uint8_t s_cand[64 * LN_MAXCH];             // candidate mask of (ray, chunk): bit 7 - i = pair i of the chunk
-    __shared__ uint16_t s_q[LN_QCAP];                     // ray | pair position << 6
     __shared__ uint32_t s_bk[64];
     __shared__ float4 s_abs[128];                         // the ray records' origins and directions, for the exact phase
     const uint32_t lane = threadIdx.x, x = blockIdx.x & 7u, qx = blockIdx.x >> 3, w = qx & 3u, jslot = qx >> 2;
@@ -1281,22 +1299,29 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     const bool cone = __float_as_uint(hdr.w) >= rq;           // the whole cell's cone covers the ray: test (A) alone decides
     uint32_t L = nch;
     {
+        // suffix k is cleared as a group when   G_k |dz| > e_max |dz| + k2 a_max |dz|   (far_build_kernel's inequality times |dz|) with
+        // e_max |dz| = o |dz| + dzm |dxy|,  a_max = dzm |dz| + (o + rho_k) |dxy|,  o = the origin's distance from the cell centre, dzm =
+        // the largest height difference to the suffix.  Sorted by what depends on the level:
+        //     |dz| G_k - c3 rho_k - (|dz| + c3) o  >  dzm_k (|dxy| + k2 |dz|^2),     c3 = k2 |dz| |dxy|
+        // every term of the right-hand sides with the factor 1.0004 (>= the 1.0001^3 the unsorted form gives its largest term), G_k with
+        // its 0.9999 G - 1e-5 from lane_build_kernel: two v_fma_mix and a compare per level instead of twenty operations
         const float o = __builtin_amdgcn_sqrtf(sx * sx + sy * sy);
         const float dxy2 = rsb.x * rsb.x + rsb.y * rsb.y, adz = fabsf(rsb.z), sq = __builtin_amdgcn_sqrtf(dxy2);
         const bool steep = adz * adz >= 0.81f * (dxy2 + adz * adz) * 1.0001f;
-        const float dxy1 = sq * 1.0001f;
+        const float c3 = k2_far * adz * sq * 1.0004f, nc3 = -c3;
+        const float c4 = (sq + k2_far * adz * adz) * 1.0004f;
+        const float base = -((adz * 1.0004f + c3) * o);
         const uint32_t qw[8] = {__float_as_uint(lq0.x), __float_as_uint(lq0.y), __float_as_uint(lq0.z), __float_as_uint(lq0.w),
                                 __float_as_uint(lq1.x), __float_as_uint(lq1.y), __float_as_uint(lq1.z), __float_as_uint(lq1.w)};
 #pragma unroll
         for (int k = (int)LN_MAXCH - 1; k >= 0; --k) {
-            const f2 gz = cvt2(__float_as_uint((k & 1) ? lv[k >> 1].z : lv[k >> 1].x)), zr = cvt2(__float_as_uint((k & 1) ? lv[k >> 1].w : lv[k >> 1].y));
-            const float dzm = fmaxf(fabsf(sz - gz.y), fabsf(sz - zr.x));
-            const float e_adz = o * adz + dzm * sq * 1.0001f;
-            const float amax = (dzm * adz + (o + zr.y) * dxy1) * 1.0001f;
-            const bool clears = steep && (gz.x * 0.9999f - 1.0e-5f) * adz > (e_adz + k2_far * amax * adz) * 1.0001f;
+            const uint32_t w0 = __float_as_uint((k & 1) ? lv[k >> 1].z : lv[k >> 1].x), w1 = __float_as_uint((k & 1) ? lv[k >> 1].w : lv[k >> 1].y);
+            const float dzm = fmaxf(fabsf(mix_rsub<1>(w0, sz)), fabsf(mix_rsub<0>(w1, sz)));
+            const float lhs = mix_fma<0>(w0, adz, mix_fma<1>(w1, nc3, base));
             const uint32_t q16 = (k & 1) ? qw[k >> 1] >> 16 : qw[k >> 1] & 0xffffu;
-            if ((uint32_t)k < nch && clears && q16 >= rq) L = (uint32_t)k;
+            L = (lhs > dzm * c4) & (q16 >= rq) ? (uint32_t)k : L;
         }
+        if (!steep) L = nch;
     }
     const bool allc = act && !tame;                           // a wild ray: every pair of the cell is a candidate, nothing is tested
     const bool ab = act && tame && !cone;                     // off the cell's cone: the prefix runs tests (A) and (B)
@@ -1361,7 +1386,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
             const uint32_t it = s_items[ok ? base + lane : it0];
             const uint32_t rl = it & 63u, ch = it >> 6;
             const float4 ra = s_ray[2u * rl], rb = s_ray[2u * rl + 1u];
+            // (the row's address comes out of LDS as an integer: say that it is global memory, or the loads are FLAT ones — which count on
+            // both wait counters and so cannot be waited for one by one)
+            typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+            typedef const U4 __attribute__((address_space(1))) * GRow;
+#ifdef LN_FLAT
             const uint4* cp = reinterpret_cast<const uint4*>((uintptr_t)((uint64_t)__float_as_uint(rb.z) | ((uint64_t)__float_as_uint(rb.w) << 32))) + ch * LN_CH;
+#else
+            const GRow cp = (GRow)((uintptr_t)((uint64_t)__float_as_uint(rb.z) | ((uint64_t)__float_as_uint(rb.w) << 32))) + ch * LN_CH;
+#endif
             // (the (B) records of the row lie pp records behind the (A) records; pp by the map of the item's ray)
             const uint32_t ppi = kAB ? ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rl << 2), (int)map) ? pp01 >> 16 : pp01 & 0xffffu) : 0u;
             uint32_t mask = 0;
@@ -1371,8 +1404,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
                 uint4 rec[NB], nrc[kAB ? NB : 1u];
 #pragma unroll
                 for (uint32_t i = 0; i < NB; ++i) {
+#ifdef LN_FLAT
                     rec[i] = cp[hf * NB + i];
                     if (kAB) nrc[i] = cp[ppi + hf * NB + i];
+#else
+                    { const U4 v = cp[hf * NB + i]; rec[i] = make_uint4(v.x, v.y, v.z, v.w); }
+                    if (kAB) { const U4 v = cp[ppi + hf * NB + i]; nrc[i] = make_uint4(v.x, v.y, v.z, v.w); }
+#endif
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < NB; ++i) {
