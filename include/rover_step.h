@@ -306,8 +306,14 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        (16 B per triangle, built at rover_set_knn_map) first proves for most (ray, triangle) pairs that ray_casting.py:59
  *        rejects them, and only the remaining candidates get the exact arithmetic (csrc/rover_cull.hip) — in f32 or, with
  *        ray_precision = 2, in the reference's as-shipped fp16 arithmetic (its own, wider proof margins).
- *        All give bit-identical results; auto picks 3 when a step casts more than 49 152 rays (24 576 with ray_precision = 2); below
- *        that the binning passes cost more than the culling saves: 1, or 2 with ray_precision = 2.
+ *        4 = staged: the proof of 3 on per-cell record rows ordered by a distance bound (16 suffix levels per cell: a ray tests only the
+ *        prefix it cannot clear as a group), one lane per (ray, chunk of 8 pairs), then the same exact phase.
+ *        All give bit-identical results.  auto: fp32 arithmetic (ray_precision 0, 1) — 4 from 24 576 rays per step, 1 below;
+ *        ray_precision = 2 — 3 from 24 576 rays per step, 2 below.
+ * name = "lane_env_order" (variant 4): 1 = no sort, the ray slots in env order; 0 = rays sorted by (map, cell); -1 (default) = auto: env
+ *        order while a step's heightmap rays are fewer than 1.5 per terrain cell.
+ * name = "lane_rocks" (variant 4, sorted): 1 = the rock rays through the staged kernel too, 0 = through the culled one (3); -1 (default)
+ *        = auto: 1 when fewer than half of the rocks map's cells have a usable far bound (an irregular rocks mesh).
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
  *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
  *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.
@@ -364,7 +370,7 @@ typedef struct {
     int64_t cells_with_far_bound[2];  /* per map: cells whose far bound is wide enough to hold for a usual ray (f32 proof tables) */
     uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them, and does not scan rays that clear their whole cell (rays_not_scanned) */
     uint64_t rays_not_scanned;        /* rays that cleared BOTH halves of their cell's triangles as groups (no candidate: the distance is the miss value) */
-    uint64_t lane_items, lane_passes, lane_flushes;   /* staged ray cast (variant 4): (ray, chunk of 16 pairs) items tested, staging passes, exact-phase rounds of runs */
+    uint64_t lane_items, lane_passes, lane_flushes;   /* staged ray cast (variant 4): (ray, chunk of 8 pairs) items tested, staging passes, exact-phase rounds of runs */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

@@ -1336,7 +1336,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
         dg[5] = (uint32_t)(tq - t_start);
-        for (uint32_t v = 0; v < 19u; ++v) {                                                  // histogram of the rays' levels behind the per-wave rows
+        for (uint32_t v = 0; v < (diag[(size_t)n_blocks * 4u * 8u + 39u] ? 19u : 0u); ++v) {    // (ROVER_LANE_DIAG=2) histogram of the rays' levels behind the per-wave rows: its atomics distort the times
             const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !map && (allc ? 17u : (ab ? 18u : L)) == v));
             const uint32_t cnt1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && map && (allc ? 17u : (ab ? 18u : L)) == v));
             if (lane == 0u && cnt) atomicAdd(diag + (size_t)n_blocks * 4u * 8u + v, cnt);
@@ -1678,25 +1678,35 @@ hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
     }
     const float k2 = a.k2_far, c_a = a.half ? a.c_a_h : CullK<0>::c_a;
     static const bool want_diag = getenv("ROVER_LANE_DIAG") != nullptr;
-    static uint32_t* d_diag = nullptr; static uint32_t diag_waves = 0; static int diag_left = 3;
+    static uint32_t* d_diag = nullptr; static uint32_t diag_waves = 0; static int diag_left = 2;
     const uint32_t waves = g.n_blocks * 4u;
     if (want_diag && diag_waves < waves) { if (d_diag) (void)hipFree(d_diag); (void)hipMalloc((void**)&d_diag, ((size_t)waves * 8u + 40u) * sizeof(uint32_t)); diag_waves = waves; }
-    if (want_diag && d_diag) (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 40u) * sizeof(uint32_t), s);
+    if (want_diag && d_diag) {
+        (void)hipMemsetAsync(d_diag, 0, ((size_t)waves * 8u + 40u) * sizeof(uint32_t), s);
+        static const bool want_hist = atoi(getenv("ROVER_LANE_DIAG")) >= 2;      // the level histogram too
+        if (want_hist) (void)hipMemsetAsync(d_diag + (size_t)waves * 8u + 39u, 1, 1, s);
+    }
     auto kern = a.half ? lane_scan_kernel<1, 0> : (want_diag && d_diag ? lane_scan_kernel<0, 1> : lane_scan_kernel<0, 0>);
     hipLaunchKernelGGL(kern, dim3((g.t8 + g.r8) * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted,
                        a.n_sorted, a.lvl[0], a.lvl[1], a.lrec[0], a.lrec[1], a.lid[0], a.lid[1], reinterpret_cast<const RawTri*>(a.rtab[0]),
                        reinterpret_cast<const RawTri*>(a.rtab[1]), a.pp[0] | (a.pp[1] << 16), g.run, g.n_blocks, g.split, g.t8, g.r8, g.chs | (g.chr << 8),
                        g.run_r, a.out, a.stats, k2, c_a, (want_diag && !a.half) ? d_diag : nullptr);
-    if (want_diag && d_diag && diag_left > 0) {      // where a wave's time goes: mean shader-clock cycles per wave and phase (synchronises: a diagnostic)
+    static int diag_seen = 0;
+    if (want_diag && d_diag && ++diag_seen > 8 && diag_left > 0) {       // (not the first launches: cold caches)      // where a wave's time goes: mean shader-clock cycles per wave and phase (synchronises: a diagnostic)
         --diag_left;
         std::vector<uint32_t> h((size_t)waves * 8u + 40u);
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), d_diag, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
-            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (size_t i = 0; i < (size_t)waves * 8u; ++i) sum[i & 7u] += h[i];
             const uint32_t* hg = h.data() + (size_t)waves * 8u;
-            fprintf(stderr, "lane_scan_kernel, %u waves, mean ticks per wave: prologue loads %.0f | bins/scans %.0f | items %.0f | entries %.0f | exact %.0f\n", waves,
-                    sum[5] / waves, sum[0] / waves, sum[2] / waves, sum[3] / waves, sum[4] / waves);
-            for (int m = 0; m < 2; ++m) {
+            for (int part = 0; part < 2; ++part) {           // the waves of the terrain part, then of the rocks part of the sorted list
+                const size_t w0 = part ? (size_t)g.split * 4u : 0u, w1 = part ? waves : std::min<size_t>(waves, (size_t)g.split * 4u);
+                if (w1 <= w0) continue;
+                double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t i = w0 * 8u; i < w1 * 8u; ++i) sum[i & 7u] += h[i];
+                const double nw = (double)(w1 - w0);
+                fprintf(stderr, "lane_scan_kernel, %s part, %zu waves, mean ticks per wave: prologue loads %.0f | bins/scans %.0f | items %.0f | entries %.0f | exact %.0f\n",
+                        part ? "rocks" : "terrain", w1 - w0, sum[5] / nw, sum[0] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
+            }
+            for (int m = 0; m < (hg[39] ? 2 : 0); ++m) {
                 fprintf(stderr, "  %s rays by level 0..16:", m ? "rock" : "terrain");
                 for (int v = 0; v < 17; ++v) fprintf(stderr, " %u", hg[20 * m + v]);
                 fprintf(stderr, ", wild (all pairs candidates): %u, off the cone (tests A and B): %u\n", hg[20 * m + 17], hg[20 * m + 18]);
