@@ -311,7 +311,7 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        All give bit-identical results.  auto: fp32 arithmetic (ray_precision 0, 1) — 4 from 24 576 rays per step, 1 below;
  *        ray_precision = 2 — 3 from 24 576 rays per step, 2 below.
  * name = "lane_env_order" (variant 4): 1 = no sort, the ray slots in env order; 0 = rays sorted by (map, cell); -1 (default) = auto: env
- *        order while a step's heightmap rays are fewer than 1.5 per terrain cell.
+ *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 48 cells.
  * name = "lane_rocks" (variant 4, sorted): 1 = the rock rays through the staged kernel too, 0 = through the culled one (3); -1 (default)
  *        = auto: 1 when fewer than half of the rocks map's cells have a usable far bound (an irregular rocks mesh).
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.

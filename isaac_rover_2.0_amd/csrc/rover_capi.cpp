@@ -781,9 +781,11 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
 static bool lane_env_order(const rover_ctx* c, int variant) {
     if (variant != 4) return false;
     if (c->lane_env_order >= 0) return c->lane_env_order != 0;
-    // what decides is the heightmap rays per terrain cell (rovers spread over the map): below ~1.5 the sort buys no sharing
-    // (4 096 envs x 120 rays: 1.37, env order 32.6 against 28.9 M env-steps/s; 8 192 x 37: 0.84, 58.0 / 57.5; 16 384 x 37: 1.68, 67.8 / 76.8)
-    return c->have_dist && 2ull * (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 3ull * (uint64_t)c->cull_cells[0];
+    // what decides is the heightmap rays per terrain cell (rovers spread over the map): below ~1.5 the sort buys no sharing (4 096 envs x 120
+    // rays: 1.37, env order 35.3 against 30.9 M env-steps/s behind the sort; 16 384 x 37: 1.68, 67.1 / 80.1) — and the rovers per cell: from one per
+    // 48 cells a cell's rays come from several rovers and only the sort brings them together (8 192 x 37: 57.8 / 59.3; 4 096 x 37: 49.2 / 41.1)
+    return c->have_dist && 2ull * (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 3ull * (uint64_t)c->cull_cells[0] &&
+           48ull * (uint64_t)c->cfg.num_envs < (uint64_t)c->cull_cells[0];
 }
 
 static bool lane_rocks_too(const rover_ctx* c) { return c->lane_rocks < 0 ? 2 * c->cull_farok[1] < c->cull_cells[1] : c->lane_rocks != 0; }

@@ -938,28 +938,21 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // top of this file uses of test (A).  (p = 1e-3 cost a tenth more candidates: 3.95 pairs per ray against 3.6 with 5e-5.)
 // Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are treated like rays off the cone path.
 // ---------------------------------------------------------------------------------------------------
-#define LN_CH 8u                     // pairs per chunk: one 128-byte line of a cell's record row, one 8-bit candidate mask (16 pairs per chunk: a ray needs
-                                     // 2.4 chunks = 38 pairs on average where 8-pair chunks cover the same prefixes with 28: a third less to test)
+#define LN_CH 8u                     // pairs per chunk: one 128-byte line of a cell's record row, one 8-bit candidate mask (with 16 pairs per chunk a
+                                     // terrain ray of configs[2] tested 2.4 chunks = 38 pairs on average, with 8 it tests 3.9 chunks = 31)
 #define LN_MAXCH 16u                 // chunks per row at most (K8 <= 256: 128 pairs)
 #define LN_LVL 11u                   // float4 per cell of the level table: header {Cx, Cy, z_c, q16}, 16 levels x 8 B {G, z0, z1, rho_out} as fp16 (G, z0
                                      // rounded down, z1, rho_out up), the levels' 16 x 16-bit cones
 // A pair with a triangle whose cone value (f32 proof: |N_z| / |N|; fp16 proof: the largest ray angle it admits, over pi / 2) is below this
 // is ordered in FRONT of the others, so that the suffixes keep a cone rays lie in (0: off.  Grid mesh: 0 / 0.25 / 0.35 / 0.5 -> ray cast 440 /
 // 440 / 440 / 494 us — at 0.5 half of the pairs of a bumpy heightfield are "steep" and every ray's prefix grows —; irregular mesh 811 / 559 / 560 us)
-#ifndef LN_QGOOD
 #define LN_QGOOD 0.3f
-#endif
-#ifndef LN_QGOOD_H
-#define LN_QGOOD_H 0.2f
-#endif                // a triangle whose normal is farther than 60 degrees from the vertical is ordered in front of the others (so that the suffixes keep a cone)
+#define LN_QGOOD_H 0.2f              // (fp16 proof: 0.2 / 0.35 / 0.5 / 0.7 -> 477 / 506 / 536 / 545 us for the terrain part)
 #define LN_QCAP 1024u                // 2-byte queue entries per wave
 #define LN_PAD 5.0e-5                // added to a triangle's radius: what pays for the relative coordinates' rounding (header comment: >= 1e-6 would do)
-#ifndef LN_AB
-#define LN_AB 8u                     // pair records an item keeps in flight (test (A) only / tests (A) and (B): two records per pair)
-#endif
-#ifndef LN_ABB
-#define LN_ABB 4u
-#endif
+#define LN_AB 8u                     // pairs an item keeps in flight: test (A) only (a record per pair) ...
+#define LN_ABB 4u                    // ... tests (A) and (B) (two records per pair)
+#define LN_WAVES 5                   // waves per SIMD the kernel is compiled for (95 VGPRs, 7.4 KB LDS): 3 / 4 / 5 -> 317 / 253 / 235 us; 6 spills
 
 __device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v >= 0, finite or +inf)
     _Float16 h = (_Float16)v;
@@ -1242,18 +1235,11 @@ __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, cons
         uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
 
 template <int H, int DIAG>
-#ifndef LN_WAVES
-#define LN_WAVES 5
-#endif
 __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
     __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, the cell's record row (64-bit address)}
     __shared__ uint16_t s_q[LN_QCAP];                     // the queue of the exact phase: ray | pair position << 6; before it, while the tests run:
     static_assert(LN_QCAP >= 64 * LN_MAXCH, "the items share the queue's array");
     uint16_t* const s_items = s_q;                        // ray | chunk << 6: the items that run test (A) only, behind them the ones that run (A) and (B)
-#ifdef LN_LDS_PAD
-    __shared__ uint32_t s_pad[LN_LDS_PAD];
-    if (n_blocks == 0xffffffffu) out[0] = (float)s_pad[threadIdx.x];
-#endif
     __shared__ __attribute__((aligned(16))) uint8_t s_cand[64 * LN_MAXCH];             // candidate mask of (ray, chunk): bit 7 - i = pair i of the chunk
     __shared__ uint32_t s_bk[64];
     __shared__ float4 s_abs[128];                         // the ray records' origins and directions, for the exact phase
@@ -1390,11 +1376,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
             // both wait counters and so cannot be waited for one by one)
             typedef uint32_t U4 __attribute__((ext_vector_type(4)));
             typedef const U4 __attribute__((address_space(1))) * GRow;
-#ifdef LN_FLAT
-            const uint4* cp = reinterpret_cast<const uint4*>((uintptr_t)((uint64_t)__float_as_uint(rb.z) | ((uint64_t)__float_as_uint(rb.w) << 32))) + ch * LN_CH;
-#else
             const GRow cp = (GRow)((uintptr_t)((uint64_t)__float_as_uint(rb.z) | ((uint64_t)__float_as_uint(rb.w) << 32))) + ch * LN_CH;
-#endif
             // (the (B) records of the row lie pp records behind the (A) records; pp by the map of the item's ray)
             const uint32_t ppi = kAB ? ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rl << 2), (int)map) ? pp01 >> 16 : pp01 & 0xffffu) : 0u;
             uint32_t mask = 0;
@@ -1404,13 +1386,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
                 uint4 rec[NB], nrc[kAB ? NB : 1u];
 #pragma unroll
                 for (uint32_t i = 0; i < NB; ++i) {
-#ifdef LN_FLAT
-                    rec[i] = cp[hf * NB + i];
-                    if (kAB) nrc[i] = cp[ppi + hf * NB + i];
-#else
                     { const U4 v = cp[hf * NB + i]; rec[i] = make_uint4(v.x, v.y, v.z, v.w); }
                     if (kAB) { const U4 v = cp[ppi + hf * NB + i]; nrc[i] = make_uint4(v.x, v.y, v.z, v.w); }
-#endif
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < NB; ++i) {

@@ -644,7 +644,7 @@ def test_rays_that_clear_their_cell_are_not_scanned():
 
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto), f32 arithmetic: the env-order kernel below 24 576 rays per step, the staged kernel (4) from there on —
-    in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays —; as shipped: the binned kernel up to 24 576 rays,
+    in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays and 48 cells or more hold one rover —; as shipped: the binned kernel up to 24 576 rays,
     the culled one above; K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
@@ -660,8 +660,14 @@ def test_auto_variant_and_run_selection():
         mid.set_option("ray_precision", 2)
         assert mid.info().raycast_variant == want16, n
         mid.close()
+    # the staged kernel without the sort: fewer than 1.5 heightmap rays per terrain cell AND fewer than one rover per 48 cells
+    wide = synth.make_scene(n_cells=160, k=16, n_stones=8)
+    for n, want_sorted in ((400, 0), (1024, 1)):            # 25 600 cells: 64 / 25 cells per rover
+        e = make_engine(wide, distn, n, variant=None)
+        assert e.info().raycast_variant == 4 and e.info().raycast_sorted == want_sorted, n
+        e.close()
     big = make_engine(scene, distn, 4096, variant=None)
-    assert big.info().raycast_variant == 4
+    assert big.info().raycast_variant == 4 and big.info().raycast_sorted == 1
     big.set_option("ray_precision", 2)
     assert big.info().raycast_variant == 3            # as shipped: the culled kernel (its own proof tables)
     big.set_option("ray_precision", 0)
