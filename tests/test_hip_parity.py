@@ -335,8 +335,9 @@ def _staged_against_every_triangle(scene, distn, st):
 
 @pytest.mark.parametrize("k,cells,rays", [(200, 96, "120"), (200, 96, "37"), (40, 96, "120"), (255, 48, "37"), (8, 64, "9")])
 def test_staged_raycast_changes_no_bit(k, cells, rays):
-    """The staged kernel (variant 4: lane = (ray, chunk of 16 pairs) over per-cell record rows in group-bound order — fp16 records
-    relative to the cell, suffix bounds and suffix cones every 16 pairs, tests (A) and (B) for rays off their cell's cone) against the
+    """The staged kernel (variant 4: lane = (ray, chunk of 8 pairs) over per-cell record rows in group-bound order — fp16 records
+    relative to the cell, suffix bounds and suffix cones every 8 pairs (K = 255: all 16 levels in use), tests (A) and (B) for rays off
+    their cell's cone) against the
     binned kernel with its early out off — every triangle evaluated — on the batch of test_culled_raycast_changes_no_bit: steep tilts,
     arbitrary orientations, rays in facet planes, poses far outside the map, NaN."""
     from isaac_rover_amd import synth
