@@ -195,7 +195,7 @@ static int effective_variant(const rover_ctx* c) {
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
-    // variant 4 (staged, rover_cull.hip: lane = (ray, chunk of 16 pairs) over per-cell record rows): either arithmetic, each with its
+    // variant 4 (staged, rover_cull.hip: lane = (ray, chunk of 8 pairs) over per-cell record rows): either arithmetic, each with its
     // proof's tables.  Auto (measured on MI355X, 37 + 26 rays, K = 200, one call per size, whole step in M env-steps/s, culled / staged):
     // f32 65 536 envs 121 / 132, 32 768: 98 / 110, 16 384: 72 / 78, 8 192: 55 / 58, 4 096: 40 / 40, 2 048: 27 / 25; 120 + 26 rays 56.5 / 68.2;
     // the native 1 634 + 26 rays at 4 096 envs 4.63 / 5.47, at 512 envs 2.64 / 2.36; irregular mesh 81 / 100.  As shipped (fp16 proof: a

@@ -1,4 +1,5 @@
-// rover_cull.hip — the culled ray cast (raycast variant 3): the roofline kernel of the step on full batches.
+// rover_cull.hip — the culled ray cast (raycast variant 3: cull_scan_kernel) and the staged ray cast built on its proof (variant 4:
+// lane_scan_kernel, further down — the roofline kernel of the step on full batches since round 5).
 //
 // Reference: tasks/utils/camera/camera.py:60-145 (gather K triangles per ray, ray_distance, min over K),
 //            tasks/utils/camera/ray_casting.py:31-59 (the (ray, triangle) test), rock_detect.py:52-149 (same on the rocks map).
@@ -26,7 +27,7 @@
 //     |det*| W - err  <=  rho (|det*| + err'),   err, err' <= 1e-6 |b||c| (2|g| + rho)   [f32 rounding of nn, mn, det: 16 eps]
 // so with (A):  |det*| <= 2e-6 |b||c| / 0.02 = 1e-4 |b||c|.  But (B) and the sliver bound give
 // |det*| = |N . d| >= (4e-3 - 1e-3) * 0.05 |b||c| = 1.5e-4 |b||c|  — a contradiction: the reference rejects.
-// NaN / inf anywhere makes (A) or (B) compare false, i.e. keeps the triangle a candidate.  DESIGN.md §4.3 has the long form.
+// NaN / inf anywhere makes (A) or (B) compare false, i.e. keeps the triangle a candidate.  DESIGN.md §5 has the long form.
 // (B) for a whole cell at once: with q = min over the cell's triangles of |N_z| / |N| (0 if any is a sliver) and beta the
 // ray's angle from the vertical, every triangle has |N . d| / |N| >= cos(acos q + beta), which exceeds 3.5e-3 iff
 // q > 3.5e-3 |d_z| + sqrt(1 - 3.5e-3^2) |d_xy|.  prep_rays_kernel stores the right-hand side (rounded up to 16 bits) in the
@@ -911,20 +912,23 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 //
 // cull_scan_kernel gives a bin's triangles to the lanes and walks the bin's rays one by one: per ray ~25 wave instructions that test
 // nothing (ray parameters, ballots, queue bookkeeping), per bin a gather round trip (id row -> records) and an unpacking of 200 records
-// of which a steep ray can meet a few dozen.  Here a wave still takes a run of 64 sorted rays, but
-//   * the records a bin's rays can need arrive as ONE contiguous piece per 16 pairs: per cell the pairs' sphere records are stored
-//     ready to test (16 B per pair: centre relative to the cell's own centre and r2, fp16) in the order of the group-bound key G
-//     (far_build_kernel's), with a bound per SUFFIX of the list every 16 pairs ("levels"): a ray that clears the suffix behind 16 j pairs
-//     — the far skip's inequality, from one split to eight — needs the first j chunks only; a bin stages the chunks its rays need
-//     HBM -> LDS (global_load_lds, no registers, no dependent gather);
-//   * the tests are dealt as ITEMS = (ray, chunk) to the lanes, 64 items per round whatever ray or bin they belong to: a lane runs test
-//     (A) for its ray against the chunk's 16 pairs straight from LDS — 24 plain f32 / integer instructions per pair, the fp16 record
-//     read by v_fma_mix_f32 without a conversion — and leaves a 16-bit candidate mask: no per-ray overhead, no bin set-up, and a wave's
-//     work is the sum of its rays' needs, not 64 times the largest;
+// of which a steep ray can meet a few dozen.  Here a wave still takes a run of <= 64 rays (sorted by bin, or 64 slots in env order), but
+//   * a cell's pairs are stored as a ROW ready to test — 16 B per pair: two sphere records {centre relative to the cell's own centre,
+//     r2} in fp16 — in the order of the group-bound key G (far_build_kernel's), with a bound per SUFFIX of the row every LN_CH = 8 pairs
+//     (16 "levels", lane_build_kernel): a ray evaluates the far skip's inequality against the sixteen suffixes once; the first one it
+//     clears — and whose normal cone covers it — is its level L, and only the first L chunks of 8 pairs (one 128-byte line each) are tested;
+//   * the tests are dealt as ITEMS = (ray, chunk) to the lanes, 64 items per round whatever ray or bin they belong to, ordered so that
+//     lanes reading the same line sit side by side: a lane reads its chunk's 8 records straight from the row (L1 / L2; the first
+//     version staged them HBM -> LDS: slower), runs test (A) on them — 11 plain instructions per triangle, the fp16 record read by
+//     v_fma_mix_f32 without a conversion — and leaves an 8-bit candidate mask: no per-ray overhead, no bin set-up, and a wave's work
+//     is the sum of its rays' needs, not 64 times the largest;
+//   * a ray its cell's normal cone does not cover (test (B) is not implied: body rays, steep ground, irregular meshes) runs tests (A)
+//     and (B) on its prefix, the (B) records {n, r2B} from the row's second half; steep pairs are ordered in FRONT of their row so that
+//     the suffixes keep a cone (LN_QGOOD); a wild ray (non-finite, |origin - cell| >= 1e4) takes every pair of its cell as a candidate;
 //   * candidates become 2-byte queue entries (ray position, pair position) in LDS; the exact phase (the same arithmetic as every other
-//     ray-cast kernel, one lane per entry) fetches the pair's triangle ids through the cell's id row.
-// Rays off the cone path (test (B) is not implied by their cell's normal cone: body rays, steep ground) are not tested at all: every
-// pair of their cell is a candidate.  The kernel serves ONE map; the host runs it on the terrain part of the sorted list.
+//     ray-cast kernel, one lane per entry, two rounds in flight) fetches the pair's triangle ids through the cell's id row.
+// One launch serves both maps (a lane's map comes with its ray); on regular rocks meshes the host gives the rocks part of the sorted list
+// to cull_scan_kernel instead (rover_capi.cpp, run_raycast).  Measured history: EXPERIMENTS.md 8.2, 8.2b.
 //
 // Test (A) on these records.  A pair record holds, per triangle, m' = fp16(m - C) (m: ctab's sphere centre, C = (cell centre, z_c) in
 // f32) and r2' (fp16, rounded up) >= 1.19 (rho~ + e + p)^2 (p = LN_PAD = 5e-5) with rho~ >= the radius of the padded triangle about m (from ctab's own r2)
@@ -936,7 +940,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // Cauchy-Schwarz W^ >= 0.02126 |h^| + 1.0404 (rho' + p), and the true line is within |h - h^| <= 4.2e-7 |h| + 8.7e-7 of that one:
 // W >= 0.02125 |h| + 1.0404 rho' + 1.04 p - 9e-7 > rho' + 0.02 (|h| + 2 rho') for every p >= 1e-6, which is all the rejection proof at the
 // top of this file uses of test (A).  (p = 1e-3 cost a tenth more candidates: 3.95 pairs per ray against 3.6 with 5e-5.)
-// Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are treated like rays off the cone path.
+// Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are the wild rays: every pair a candidate.
 // ---------------------------------------------------------------------------------------------------
 #define LN_CH 8u                     // pairs per chunk: one 128-byte line of a cell's record row, one 8-bit candidate mask (with 16 pairs per chunk a
                                      // terrain ray of configs[2] tested 2.4 chunks = 38 pairs on average, with 8 it tests 3.9 chunks = 31)
@@ -1331,7 +1335,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tq = __builtin_amdgcn_s_memtime();
     }
-    // The items, in the order bin by bin, chunk by chunk, the bin's rays that test the chunk: lanes that read the same 256 bytes of a
+    // The items, in the order bin by bin, chunk by chunk, the bin's rays that test the chunk: lanes that read the same 128-byte line of a
     // record row sit next to each other.  Position of item (ray, k) = items of the bins before + items of the bin's chunks before k + the
     // ray's rank among the bin's rays with more than k items.  Two lists: the (A) items, behind them the (A) + (B) items.
     const uint32_t key = cell | (map << 31);
@@ -1381,7 +1385,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
             const uint32_t ppi = kAB ? ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rl << 2), (int)map) ? pp01 >> 16 : pp01 & 0xffffu) : 0u;
             uint32_t mask = 0;
             constexpr uint32_t NB = kAB ? LN_ABB : LN_AB;            // records in flight per batch
-#pragma unroll 1                                                // (unrolled, the compiler keeps all sixteen in flight: 128 VGPRs and spills)
+#pragma unroll 1                                                // (one batch of LN_AB pairs at a time: with 16-pair chunks fully unrolled the compiler kept all in flight, 128 VGPRs and spills)
             for (uint32_t hf = 0; hf < LN_CH / NB; ++hf) {
                 uint4 rec[NB], nrc[kAB ? NB : 1u];
 #pragma unroll

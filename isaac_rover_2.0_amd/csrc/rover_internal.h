@@ -84,12 +84,12 @@ struct CullArgs {
     uint4* stats;                // [waves] per-wave counters of the last launch {queue entries, rays, rays with both tests, bins}
 };
 uint32_t cull_stat_slots(uint64_t n_rays, uint32_t run);
-// the staged ray cast (raycast variant 4, rover_cull.hip): lane = (ray, chunk of 16 pairs) over per-cell record rows in group-bound order
+// the staged ray cast (raycast variant 4, rover_cull.hip): lane = (ray, chunk of 8 pairs) over per-cell record rows in group-bound order
 struct LaneArgs {
     const RayRec* rays;
     const uint32_t* sorted;
     uint32_t n_sorted, n_terrain;
-    const float4* lvl[2];        // per map [cell][10]: header, 8 suffix bounds, the suffixes' cones
+    const float4* lvl[2];        // per map [cell][lane_lvl_stride()]: header, 16 suffix bounds (fp16), the suffixes' cones
     const uint4* lrec[2];        // [cell][2][pp]: pair records of test (A), then of test (B), in G order
     const uint2* lid[2];         // [cell][pp]: the pairs' triangle ids
     const uint16_t* rtab[2];
