@@ -181,10 +181,12 @@ static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_env
 // measurement, when the ray cast behind the sort was the every-triangle kernel.)
 #define ROVER_AUTO_CULL_RAYS_F32 49152u
 #define ROVER_AUTO_CULL_RAYS_F16 24576u
-// The staged ray cast: from 24 576 rays (f32 arithmetic), in env order — no sort — while a terrain cell holds fewer than 1.5 heightmap rays (lane_env_order).  Whole step, M env-steps/s, 37 + 26
-// rays, one call per size, env-order kernel / culled / staged behind the sort / staged in env order: 512 envs 11.3 / 10.5 / 8.8 / 12.7,
-// 1 024: 14.6 / 17.8 / 15.2 / 22.3, 2 048: 17.3 / 27.5 / 24.1 / 36.5, 4 096: 18.5 / 39.8 / 39.4 / 46.6, 8 192: 19.0 / 54.5 / 57.5 / 58.0,
-// 16 384: 19.3 / 72.2 / 76.8 / 67.8, 32 768: 19.5 / 98.7 / 109.4 / 73.5; 120 + 26 rays at 4 096 envs 8.5 / 26.3 / 28.9 / 32.6.
+// The staged ray cast: from 24 576 rays (f32 arithmetic), in env order — no sort — while a terrain cell holds fewer than 1.5 heightmap rays
+// and 48 cells or more hold one rover (lane_env_order).  Whole step, M env-steps/s, 37 + 26 rays, one call (tools/sweep_small.sh,
+// profiles/r05_final_sweep.log), env-order kernel / culled / staged behind the sort / staged in env order: 512 envs 11.4 / 10.5 / 8.2 / 17.0,
+// 1 024: 14.7 / 17.6 / 15.4 / 29.3, 2 048: 17.4 / 27.3 / 26.5 / 37.7, 4 096: 18.3 / 39.9 / 41.1 / 49.1, 8 192: 18.9 / 54.9 / 59.2 / 57.7,
+// 16 384: 19.2 / 72.2 / 79.7 / 66.9, 32 768: 19.3 / 98.4 / 113.6 / 71.1, 65 536: 19.2 / 121.7 / 142.1 / 73.5; 120 + 26 rays at 4 096 envs
+// 8.4 / 26.1 / 30.8 / 35.0, at 65 536 envs 8.5 / 56.2 / 69.9 / 45.4.
 #define ROVER_AUTO_LANE_RAYS 24576u
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
@@ -196,10 +198,9 @@ static int effective_variant(const rover_ctx* c) {
     const bool v3_ok = c->cull_idx[0] && c->cull_idx[1];
     if (c->variant == 2 || !v3_ok) return 2;
     // variant 4 (staged, rover_cull.hip: lane = (ray, chunk of 8 pairs) over per-cell record rows): either arithmetic, each with its
-    // proof's tables.  Auto (measured on MI355X, 37 + 26 rays, K = 200, one call per size, whole step in M env-steps/s, culled / staged):
-    // f32 65 536 envs 121 / 132, 32 768: 98 / 110, 16 384: 72 / 78, 8 192: 55 / 58, 4 096: 40 / 40, 2 048: 27 / 25; 120 + 26 rays 56.5 / 68.2;
-    // the native 1 634 + 26 rays at 4 096 envs 4.63 / 5.47, at 512 envs 2.64 / 2.36; irregular mesh 81 / 100.  As shipped (fp16 proof: a
-    // third of the rays lie off their cell's narrow cone and test every pair both ways) 89.8 / 81.4: stays on the culled kernel.
+    // proof's tables.  Auto: the table above; the native 1 634 + 26 rays at 512 envs on an irregular mesh 2.13 / 2.98 (culled / staged), the
+    // irregular mesh at 65 536 envs 83.5 / 113.8.  As shipped (fp16 proof: a third of the rays lie off their cell's narrow cone and test
+    // every pair both ways) 91.2 / 87.1: stays on the culled kernel.
     if (v4_ok && (c->variant == 4 || (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) >= ROVER_AUTO_LANE_RAYS))) return 4;
     return 3;
 }
@@ -826,9 +827,9 @@ static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t 
             return ROVER_OK;
         }
         // The rocks part too?  On a regular rocks mesh no: its rays are few per bin and a tenth of them lie off every cone (the horizontal body
-        // rays, which test every pair of their cell both ways) — the staged kernel reads a cell's whole 3.5 KB row for one such ray where the
-        // culled kernel reads 800 bytes of ids (65 536 envs: 440 us in one launch against 259 + 137).  On an irregular rocks mesh — most cells
-        // without a usable far bound — yes (555 us against 327 + 270).
+        // rays, which test every pair of their cell both ways) — the staged kernel reads a cell's whole 6.6 KB of (A) and (B) rows for one such
+        // ray where the culled kernel reads 800 bytes of ids and gathers: a tie at 65 536 envs (363-372 us in one launch against 226-233 +
+        // 137-140).  On an irregular rocks mesh — most cells without a usable far bound — yes (465 us against 327 + 270 with the first version).
         if (lane_rocks_too(c)) {
             HIP_TRY(c, launch_raycast_lane(l, s));
         } else {
