@@ -1,0 +1,145 @@
+"""Property test (CPU, numpy) of the staged ray cast's LEVEL bound — `lane_build_kernel` / `lane_scan_kernel` in
+csrc/rover_cull.hip, DESIGN.md §4.5 and §5.3.
+
+A suffix of a cell's record row is skipped as a group when the ray clears its bound {G, z0, z1, rho_out}; the claim is that every
+triangle of the suffix then passes test (A), `c_a |h|^2 - (h.d)^2 > r2`, on its own — with room for the f32 rounding of that test
+(< 3e-6 |h|^2 + 3e-7 r2).  The GPU suites check the consequence (bit-identical distances against the every-triangle
+kernel); this test checks the inequality itself, at its tightest: for random sets of sphere records and random steep rays the set is
+moved towards the ray until the bound (evaluated as the kernel does, in float32 on fp16-rounded level records, with the kernel's
+margins) JUST clears it, and there every record is put through test (A) in float64.
+
+The restatement below follows the kernel's operation order; `v_fma_mix_f32` / `v_fma_f32` are single roundings, numpy rounds each
+operation: the difference is an ulp per operation, three orders of magnitude below the 1.0004 / 0.9999 margins.
+"""
+import math
+
+import numpy as np
+
+f32 = np.float32
+C_A = f32(0.995)                       # CullK<0>::c_a
+
+
+def _far_consts(c_a=0.995, dd=1.00001):
+    """cull_far_consts (rover_cull.hip)."""
+    ca = c_a - 1.0e-5
+    k1 = f32(1.00001 / (0.9 * math.sqrt(ca)))
+    k2 = f32(1.00001 * math.sqrt(dd + 1.0e-5 - ca) / (0.9 * math.sqrt(ca)))
+    return k1, k2
+
+
+def _h_down(v):
+    """fp16 <= v (lane_build_kernel's `down`)."""
+    h = np.float16(v)
+    if np.isfinite(h) and float(h) > float(v):
+        h = np.nextafter(h, np.float16(-np.inf))
+    return h
+
+
+def _h_up(v):
+    """fp16 >= v (lane_build_kernel's `up` / half_bits_up)."""
+    h = np.float16(v)
+    if np.isfinite(h) and float(h) < float(v):
+        h = np.nextafter(h, np.float16(np.inf))
+    return h
+
+
+def _level_record(hx, hy, hz, r2h, k1):
+    """The suffix bound lane_build_kernel stores for a set of sphere records (hx, hy, hz: fp16 values; r2h: the records' fp16 r2)."""
+    hx = hx.astype(f32); hy = hy.astype(f32); hz = hz.astype(f32); r2h = r2h.astype(f32)
+    dxy = np.sqrt(hx * hx + hy * hy, dtype=f32)
+    g = (dxy - k1 * np.sqrt(r2h, dtype=f32) * f32(1.00001)) * f32(0.99999) - f32(1.0e-6)
+    pro = dxy * f32(1.00001)
+    G = f32(g.min()) * f32(0.9999) - f32(1.0e-5)
+    return _h_down(G), _h_down(hz.min()), _h_up(hz.max()), _h_up(pro.max())
+
+
+def _clears(level, s, d, k2):
+    """lane_scan_kernel's level test for a ray with cell-relative origin s and direction d (float32 arithmetic)."""
+    Gq, z0, z1, ro = (f32(x) for x in level)
+    sx, sy, sz = (f32(x) for x in s)
+    dx, dy, dz = (f32(x) for x in d)
+    o = np.sqrt(sx * sx + sy * sy, dtype=f32)
+    dxy2 = dx * dx + dy * dy
+    adz = abs(dz)
+    sq = np.sqrt(dxy2, dtype=f32)
+    steep = adz * adz >= f32(0.81) * (dxy2 + adz * adz) * f32(1.0001)
+    c3 = k2 * adz * sq * f32(1.0004)
+    c4 = (sq + k2 * adz * adz) * f32(1.0004)
+    base = -((adz * f32(1.0004) + c3) * o)
+    dzm = max(abs(sz - z0), abs(sz - z1))
+    lhs = Gq * adz + (ro * (-c3) + base)
+    return bool(steep) and bool(lhs > dzm * c4)
+
+
+def _test_a_margin(hx, hy, hz, r2h, s, d):
+    """c_a |h|^2 - (h.d)^2 - r2 minus the rounding allowance of the f32 test, per record, in float64 (h = s - m)."""
+    h = np.stack([s[0] - hx.astype(np.float64), s[1] - hy.astype(np.float64), s[2] - hz.astype(np.float64)], axis=1)
+    q = (h * h).sum(axis=1)
+    t = h @ np.asarray(d, dtype=np.float64)
+    r2 = r2h.astype(np.float64)
+    return float(C_A) * q - t * t - r2 - (3.0e-6 * q + 3.0e-7 * r2)
+
+
+def _random_case(rng):
+    m = int(rng.integers(1, 40))
+    ang = rng.uniform(0.0, 2.0 * math.pi, m)
+    spread = rng.uniform(0.0, 1.5, m) * rng.uniform(0.0, 1.0)          # how far behind the nearest record the others lie
+    hz = rng.uniform(-0.6, 0.6, m) * rng.uniform(0.05, 1.0)
+    r = rng.uniform(0.01, 0.25, m)
+    # a steep ray (cos beta >= ~0.9) from inside or near the cell, at any height above or below the records
+    tilt = rng.uniform(0.0, 0.44)
+    az = rng.uniform(0.0, 2.0 * math.pi)
+    d64 = np.array([math.sin(tilt) * math.cos(az), math.sin(tilt) * math.sin(az), -math.cos(tilt)]) * rng.choice([1.0, -1.0])
+    d = d64.astype(f32)
+    s = np.array([rng.uniform(-0.08, 0.08), rng.uniform(-0.08, 0.08), rng.uniform(-0.6, 3.0) * rng.choice([1.0, 0.2])]).astype(f32)
+    return ang, spread, hz, r, s, d
+
+
+def _records(D, ang, spread, hz, r):
+    """fp16 sphere records of the set moved to xy distance D (+ spread) from the cell centre; None when one leaves the +-4 m the
+    builder admits (such a triangle is stored as always-a-candidate: no bound depends on it)."""
+    dist = D + spread
+    if dist.max() > 3.9:
+        return None
+    hx = np.float16(dist * np.cos(ang)); hy = np.float16(dist * np.sin(ang)); hzh = np.float16(hz)
+    r2h = np.array([_h_up(f32(1.19) * f32(x) * f32(x)) for x in r], dtype=np.float16)
+    return hx, hy, hzh, r2h
+
+
+def test_a_cleared_suffix_passes_test_a_record_by_record():
+    rng = np.random.default_rng(20251004)
+    k1, k2 = _far_consts()
+    tight = 0
+    worst = math.inf
+    for _ in range(1500):
+        ang, spread, hz, r, s, d = _random_case(rng)
+        lo, hi = 0.0, 3.9 - float(spread.max())
+        rec = _records(hi, ang, spread, hz, r)
+        if rec is None or not _clears(_level_record(*rec, k1), s, d, k2):
+            continue                                   # never cleared inside the builder's range: nothing to check
+        for _ in range(40):                            # the smallest distance at which the set is still cleared
+            mid = 0.5 * (lo + hi)
+            rec = _records(mid, ang, spread, hz, r)
+            if _clears(_level_record(*rec, k1), s, d, k2):
+                hi = mid
+            else:
+                lo = mid
+        rec = _records(hi, ang, spread, hz, r)
+        assert _clears(_level_record(*rec, k1), s, d, k2)
+        margin = _test_a_margin(*rec, s.astype(np.float64), d.astype(np.float64))
+        assert (margin > 0.0).all(), f"cleared as a group at D = {hi}, but a record fails test (A): {margin.min()}"
+        worst = min(worst, float(margin.min()))
+        tight += 1
+    assert tight > 500                                 # the search did reach the bound's edge in most cases
+    assert worst < 0.5                                 # ... and the edge is not far from test (A)'s own (the bound is not vacuous)
+
+
+def test_a_ray_that_is_not_steep_clears_nothing():
+    """cos beta < 0.9: the bound does not apply (the horizontal body rays), whatever the distances."""
+    k1, k2 = _far_consts()
+    rec = _records(3.0, np.array([0.3]), np.array([0.0]), np.array([0.0]), np.array([0.01]))
+    level = _level_record(*rec, k1)
+    for tilt in (0.47, 0.8, 1.2, math.pi / 2):
+        d = np.array([math.sin(tilt), 0.0, -math.cos(tilt)], dtype=f32)
+        assert not _clears(level, np.zeros(3, dtype=f32), d, k2)
+    assert _clears(level, np.zeros(3, dtype=f32), np.array([0.0, 0.0, -1.0], dtype=f32), k2)
