@@ -143,3 +143,74 @@ def test_a_ray_that_is_not_steep_clears_nothing():
         d = np.array([math.sin(tilt), 0.0, -math.cos(tilt)], dtype=f32)
         assert not _clears(level, np.zeros(3, dtype=f32), d, k2)
     assert _clears(level, np.zeros(3, dtype=f32), np.array([0.0, 0.0, -1.0], dtype=f32), k2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Test (A) on the row's cell-relative fp16 records: u >= +0 as lane_scan_kernel computes it must give what
+# the rejection proof uses of test (A): W >= rho + 0.02 (|h| + 2 rho) for the TRUE sphere (centre m, padded radius rho) and the true ray.
+# ---------------------------------------------------------------------------------------------------
+def _fma32(a, b, c):
+    return f32(np.float64(a) * np.float64(b) + np.float64(c))          # one rounding (the products of two f32 are exact in f64)
+
+
+def _record_of(m, C, rho_true):
+    """lane_build_kernel's (A) record of a triangle whose ctab entry has centre m and r2 = 1.19 (rho + 1e-4)^2: m' (fp16), r2' (fp16)."""
+    r2c = f32(1.19 * (rho_true + 1.0e-4) ** 2 * (1.0 + 1.0e-6))
+    rel = (np.asarray(m, dtype=np.float64) - np.asarray(C, dtype=np.float64)).astype(f32)
+    mh = rel.astype(np.float16)
+    enc = float(np.linalg.norm(np.asarray(C, dtype=np.float64) + mh.astype(np.float64) - np.asarray(m, dtype=np.float64)))
+    rho = math.sqrt(float(r2c) / 1.19)
+    need = 1.19 * (rho + enc + 5.0e-5) ** 2 * 1.000001
+    r2h = _h_up(f32(need * 1.0000001))
+    if float(r2h) < 2.0 ** -14:
+        r2h = np.float16(2.0 ** -14)
+    return mh, r2h
+
+
+def _u_of(mh, r2h, C, s, d):
+    """u of test (A) in lane_scan_kernel's operation order (float32; v_fma_mix_f32 and v_fma_f32 round once)."""
+    sp = (np.asarray(s, dtype=f32) - np.asarray(C, dtype=f32)).astype(f32)
+    hx, hy, hz = (f32(sp[i] - f32(mh[i])) for i in range(3))
+    t = _fma32(hz, d[2], _fma32(hy, d[1], f32(hx * d[0])))
+    qq = _fma32(hz, hz, _fma32(hy, hy, f32(hx * hx)))
+    u = _fma32(qq, C_A, -f32(r2h))
+    return _fma32(-t, t, u)
+
+
+def test_test_a_on_cell_relative_fp16_records_implies_the_proofs_premise():
+    rng = np.random.default_rng(77)
+    checked = 0
+    tightest = math.inf
+    for _ in range(3000):
+        C = np.array([rng.uniform(-30.0, 30.0), rng.uniform(-30.0, 30.0), rng.uniform(-2.0, 2.0)]).astype(f32).astype(np.float64)
+        m = C + np.array([rng.uniform(-3.5, 3.5), rng.uniform(-3.5, 3.5), rng.uniform(-1.0, 1.0)]) * rng.choice([1.0, 0.1])
+        m = m.astype(f32).astype(np.float64)                   # ctab holds f32 (x, y) and fp16-decoded z: values the tables can hold
+        rho = float(rng.uniform(0.005, 0.3))
+        mh, r2h = _record_of(m, C, rho)
+        dv = rng.normal(size=3); dv /= np.linalg.norm(dv)
+        d = dv.astype(f32)
+        dhat = d.astype(np.float64) / np.linalg.norm(d.astype(np.float64))
+        # rays through points at lateral offset w from m: find the smallest w at which the kernel's u is >= +0
+        perp = np.cross(dhat, rng.normal(size=3)); perp /= np.linalg.norm(perp)
+        along = float(rng.uniform(-3.0, 3.0))
+
+        def origin(w):
+            return (m + perp * w + dhat * along).astype(f32)
+        lo, hi = 0.0, 6.0
+        if not _u_of(mh, r2h, C.astype(f32), origin(hi), d) >= 0.0:
+            continue
+        for _ in range(50):
+            mid = 0.5 * (lo + hi)
+            if _u_of(mh, r2h, C.astype(f32), origin(mid), d) >= 0.0:
+                hi = mid
+            else:
+                lo = mid
+        s = origin(hi).astype(np.float64)
+        h = s - m
+        W = float(np.linalg.norm(h - (h @ dhat) * dhat))
+        need = rho + 0.02 * (float(np.linalg.norm(h)) + 2.0 * rho)
+        assert W >= need, f"u >= 0 at W = {W}, the proof needs {need} (rho {rho}, |h| {np.linalg.norm(h)})"
+        tightest = min(tightest, W / need)
+        checked += 1
+    assert checked > 2500
+    assert tightest < 1.2                                   # the test sits close to what it has to imply
