@@ -170,7 +170,10 @@ ROVER_API int rover_get_collisions(rover_ctx *ctx, const float *positions, const
  *    cell ids cell [E,26+P] int32, distances dist [E,26+P] (each optional).
  *  rover_cast_rays: casts caller-supplied rays in the same layout (origins + record directions; slots 0..25 against the rocks map,
  *    the rest against the terrain map) through the step's sort + ray-cast kernels (variant / precision / cell index mode as set) and
- *    returns their distances dist [E,26+P].  Overwrites the ray workspace like rover_get_depths. */
+ *    returns their distances dist [E,26+P].  Overwrites the ray workspace like rover_get_depths.  The directions are used as they are:
+ *    with the culled / staged ray cast (variants 3, 4), whose rejection proofs assume what -normalize() produces, a finite direction
+ *    whose squared length is not within 1e-5 of 1 (4e-3 with ray_precision 2) is ROVER_E_INVALID — the call synchronises the stream to
+ *    find out; variants 1 and 2 evaluate every triangle and take any direction. */
 ROVER_API int rover_export_rays(rover_ctx *ctx, float *src, float *dir, int32_t *cell, float *dist, void *stream);
 ROVER_API int rover_cast_rays(rover_ctx *ctx, const float *src, const float *dir, float *dist, void *stream);
 /* reset_buf.nonzero() rover.py:356 without the host sync: ids ascending (+env_offset), count to n_reset[0] */

@@ -895,8 +895,21 @@ static int cast_rays(rover_ctx* c, const float* pos, const float* quat, const fl
         p.hist = c->d_bkt_table; p.hist_low_bits = c->low_bits; p.hist_buckets = bucket_count(c);
     }
     if (import_src) {
+        // caller-supplied directions: the culled / staged ray cast's proofs need them of unit length (what -normalize() gives)
+        uint32_t* const not_unit = variant >= 3 ? c->d_block_cnt + (size_t)c->cfg.num_envs / 256 + 1 : nullptr;      // (the spare word behind the block counts)
+        if (not_unit) HIP_TRY(c, hipMemsetAsync(not_unit, 0, sizeof(uint32_t), s));
         HIP_TRY(c, launch_import_rays(import_src, import_dir, E, c->R8, (uint32_t)c->P, c->map[0], c->map[1], p.rocks_bin_offset, c->precision,
-                                      c->cell_rcp, c->d_rays, sorts ? c->d_bins : nullptr, s));
+                                      c->cell_rcp, c->d_rays, sorts ? c->d_bins : nullptr, s, not_unit));
+        if (not_unit) {
+            uint32_t bad = 0;
+            HIP_TRY(c, hipMemcpyAsync(&bad, not_unit, sizeof bad, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            if (bad) {
+                c->rays_valid = false;
+                return fail(c, ROVER_E_INVALID, "cast_rays: %u directions are not of unit length (|d|^2 within %g of 1: pass -normalize(direction) as "
+                            "rover_export_rays returns it, or use raycast_variant 1 / 2, which evaluate every triangle)", bad, c->precision == 2 ? 4.0e-3 : 1.0e-5);
+            }
+        }
     } else {
         HIP_TRY(c, launch_prep(p, s));
     }

@@ -245,7 +245,8 @@ hipError_t launch_export_dist(const float* dist, const RayRec* rays, uint32_t E,
 hipError_t launch_export_rays(const RayRec* rays, const float* dist, uint32_t E, uint32_t R8, uint32_t P, float* src, float* dir, int32_t* cell,
                               float* out_dist, hipStream_t s);
 hipError_t launch_import_rays(const float* src, const float* dir, uint32_t E, uint32_t R8, uint32_t P, const KnnDev& terrain, const KnnDev& rocks,
-                              uint32_t rocks_bin_offset, int precision, int cell_rcp, RayRec* rays, uint32_t* bin_out, hipStream_t s);
+                              uint32_t rocks_bin_offset, int precision, int cell_rcp, RayRec* rays, uint32_t* bin_out, hipStream_t s,
+                              uint32_t* not_unit = nullptr /* optional: counts the finite directions whose length is not 1 */);
 hipError_t launch_obs_metrics(const ObsArgs& o, const MetricsArgs& m, hipStream_t s);     // both in one launch (rover_step)
 hipError_t launch_metrics_done(const MetricsArgs& a, hipStream_t s);
 hipError_t launch_compact(const int64_t* reset, uint32_t n, int64_t offset, uint32_t* block_cnt, bool counted, int64_t* ids,

@@ -562,7 +562,8 @@ __global__ void __launch_bounds__(256) export_rays_kernel(const RayRec* __restri
 // and bin key as prep_rays_kernel derives them from an origin / a direction (camera.py:233-264 for the cell).
 __global__ void __launch_bounds__(256) import_rays_kernel(const float* __restrict__ src, const float* __restrict__ dir, uint32_t E, uint32_t R8,
                                                           uint32_t n_real, KnnDev terrain, KnnDev rocks, uint32_t rocks_bin_offset,
-                                                          int precision, int cell_rcp, RayRec* __restrict__ rays, uint32_t* __restrict__ bin_out) {
+                                                          int precision, int cell_rcp, RayRec* __restrict__ rays, uint32_t* __restrict__ bin_out,
+                                                          uint32_t* __restrict__ not_unit) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)E * R8) return;
     const uint32_t e = (uint32_t)(i / R8), sl = (uint32_t)(i % R8);
@@ -575,6 +576,13 @@ __global__ void __launch_bounds__(256) import_rays_kernel(const float* __restric
         const KnnDev& m = rk ? rocks : terrain;
         rec.sx = src[o]; rec.sy = src[o + 1]; rec.sz = src[o + 2];
         rec.dx = dir[o]; rec.dy = dir[o + 1]; rec.dz = dir[o + 2];
+        // the rejection proofs of the culled / staged ray cast take |d|^2 <= 1.00001 (f32; as shipped, normalised in fp16: within 4e-3 of 1),
+        // what -normalize() gives: a finite direction of another length is counted, rover_cast_rays refuses the call (NaN compares false
+        // in every test: such a ray keeps all its candidates by itself)
+        if (not_unit) {
+            const float dd = rec.dx * rec.dx + rec.dy * rec.dy + rec.dz * rec.dz;
+            if (fabsf(dd - 1.0f) > (precision == 2 ? 4.0e-3f : 1.0e-5f)) atomicAdd(not_unit, 1u);
+        }
         const uint32_t ix = cell_coord(rec.sx, m.shift_x, m.cell, m.inv_cell, cell_rcp, m.X);
         uint32_t iy = cell_coord(rec.sy, m.shift_y, m.cell, m.inv_cell, cell_rcp, m.X);
         if (iy > (uint32_t)(m.Y - 1)) iy = (uint32_t)(m.Y - 1);
@@ -1832,9 +1840,10 @@ hipError_t launch_export_rays(const RayRec* rays, const float* dist, uint32_t E,
 }
 
 hipError_t launch_import_rays(const float* src, const float* dir, uint32_t E, uint32_t R8, uint32_t P, const KnnDev& terrain, const KnnDev& rocks,
-                              uint32_t rocks_bin_offset, int precision, int cell_rcp, RayRec* rays, uint32_t* bin_out, hipStream_t s) {
+                              uint32_t rocks_bin_offset, int precision, int cell_rcp, RayRec* rays, uint32_t* bin_out, hipStream_t s,
+                              uint32_t* not_unit) {
     hipLaunchKernelGGL(import_rays_kernel, dim3(blocks_for((uint64_t)E * R8, 256)), dim3(256), 0, s, src, dir, E, R8, 26u + P, terrain, rocks,
-                       rocks_bin_offset, precision, cell_rcp, rays, bin_out);
+                       rocks_bin_offset, precision, cell_rcp, rays, bin_out, not_unit);
     return hipGetLastError();
 }
 

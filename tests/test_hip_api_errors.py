@@ -113,6 +113,41 @@ def test_get_collisions_argument_checks_and_state():
     eng.close()
 
 
+def test_cast_rays_refuses_directions_that_are_not_unit_length_where_the_proofs_need_them():
+    """rover_cast_rays takes the directions as they are.  The culled / staged ray cast (variants 3, 4) prove their rejections for
+    |d|^2 <= 1.00001 — what -normalize() gives —: a finite direction of another length is ROVER_E_INVALID there, not a silent difference;
+    the every-triangle kernels (1, 2) take it; a NaN direction (keeps all its candidates by itself) is no error anywhere."""
+    from isaac_rover_amd import _lib
+    eng, scene = _engine(16)
+    dev = eng.device
+    pos = torch.zeros(16, 3, device=dev) + 1.5
+    eng.get_depths(pos, torch.zeros(16, 3, device=dev))
+    src, dirs, cell, dist = eng.export_rays()
+    torch.cuda.synchronize()
+    long = dirs.clone(); long[3, 30] *= 1.01
+    nan = dirs.clone(); nan[5, 7, 1] = float("nan")
+    results = {}
+    for variant in (1, 2, 3, 4):
+        eng.set_option("raycast_variant", variant)
+        base = eng.cast_rays(src, dirs).clone()
+        with_nan = eng.cast_rays(src, nan).clone()
+        results[variant] = (base, with_nan)
+        if variant >= 3:
+            with pytest.raises(_lib.RoverError, match="not of unit length"):
+                eng.cast_rays(src, long)
+            again = eng.cast_rays(src, dirs)                  # the ctx is usable after the refusal
+            torch.cuda.synchronize()
+            assert torch.equal(again, base)
+        else:
+            results[variant] += (eng.cast_rays(src, long).clone(),)
+    torch.cuda.synchronize()
+    for variant in (2, 3, 4):
+        assert torch.equal(results[variant][0], results[1][0])
+        assert torch.equal(results[variant][1].view(torch.int32), results[1][1].view(torch.int32))
+    assert torch.equal(results[2][2], results[1][2])
+    eng.close()
+
+
 def test_c_level_argument_checks():
     from isaac_rover_amd import _lib
     eng, _ = _engine(16)

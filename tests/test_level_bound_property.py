@@ -214,3 +214,51 @@ def test_test_a_on_cell_relative_fp16_records_implies_the_proofs_premise():
         checked += 1
     assert checked > 2500
     assert tightest < 1.2                                   # the test sits close to what it has to imply
+
+
+# ---------------------------------------------------------------------------------------------------
+# Test (B) for a whole set (last sentence): the ray record carries qm = 3.5e-3 |d_z| + |d_xy| (+ 2e-5, rounded UP to 16
+# bits: ray_cone_bound, rover_kernels.hip), a cell or a suffix q = min |N_z| / |N| over its triangles (rounded DOWN to 16 bits:
+# lane_build_kernel / idx4_build_kernel).  q16 >= rq must give |N . d| > 3.4e-3 |N| for every triangle of the set (3.5e-3 for an exactly unit
+# d) — more than the 3e-3 that (B) with the stored normal's 1e-3 error needs.
+# ---------------------------------------------------------------------------------------------------
+def _ray_q16(d):
+    dx, dy, dz = (f32(x) for x in d)
+    qm = f32(3.5e-3) * abs(dz) + np.sqrt(dx * dx + dy * dy, dtype=f32) + f32(2.0e-5)
+    return 0xffff if not qm < f32(0.9999) else int(math.ceil(float(qm * f32(65535.0))))
+
+
+def _set_q16(qn):
+    q16 = int(math.floor(float(f32(qn) * f32(65535.0)))) if qn > 0.0 else 0
+    return min(q16, 0xfffe)
+
+
+def test_a_set_cone_that_covers_the_ray_gives_test_b_for_every_triangle():
+    rng = np.random.default_rng(5)
+    covered = 0
+    tightest = math.inf
+    for _ in range(4000):
+        tilt = rng.uniform(0.0, 1.3) * rng.choice([1.0, 0.3])
+        az = rng.uniform(0.0, 2.0 * math.pi)
+        # (a record's direction is -normalize() in f32, or checked by rover_cast_rays: |d|^2 within 1e-5 of 1.  The bound leans on that: at a
+        #  tilt of 1.3 rad a direction 0.1 % short would leave 1e-5 of the 3.5e-3)
+        d = (np.array([math.sin(tilt) * math.cos(az), math.sin(tilt) * math.sin(az), -math.cos(tilt)]) * rng.uniform(1.0 - 4.0e-6, 1.0 + 4.0e-6)).astype(f32)
+        rq = _ray_q16(d)
+        # the set's cone JUST covers the ray; its triangles' normals lie anywhere on or inside that cone, worst azimuth included
+        q16 = rq
+        if q16 > 0xfffe:
+            continue
+        qn_min = q16 / 65535.0                               # every q that rounds down to q16 is >= this
+        n_t = 50
+        nz = np.concatenate([[qn_min], rng.uniform(qn_min, 1.0, n_t - 1)])
+        na = np.concatenate([[az, az + math.pi], rng.uniform(0.0, 2.0 * math.pi, n_t - 2)])      # towards / against the ray's tilt: the worst cases
+        nxy = np.sqrt(np.maximum(0.0, 1.0 - nz * nz))
+        N = np.stack([nxy * np.cos(na), nxy * np.sin(na), nz * rng.choice([1.0, -1.0], n_t)], axis=1)
+        assert _set_q16(qn_min) <= q16
+        dd = d.astype(np.float64)
+        c = np.abs(N @ dd)                                   # |N| = 1
+        assert (c > 3.4e-3).all(), f"cone {q16} >= ray bound {rq}, but |N.d| / |N| = {c.min()}"
+        tightest = min(tightest, float(c.min()))
+        covered += 1
+    assert covered > 2000
+    assert tightest < 0.02                                   # the worst-azimuth normal on the cone's rim sits close to the threshold
