@@ -943,7 +943,7 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are the wild rays: every pair a candidate.
 // ---------------------------------------------------------------------------------------------------
 #define LN_CH 8u                     // pairs per chunk: one 128-byte line of a cell's record row, one 8-bit candidate mask (with 16 pairs per chunk a
-                                     // terrain ray of configs[2] tested 2.4 chunks = 38 pairs on average, with 8 it tests 3.9 chunks = 31)
+                                     // terrain ray of configs[2] tested 2.4 chunks = 38 pairs on average, with 8 it tests 4.3 chunks = 34)
 #define LN_MAXCH 16u                 // chunks per row at most (K8 <= 256: 128 pairs)
 #define LN_LVL 11u                   // float4 per cell of the level table: header {Cx, Cy, z_c, q16}, 16 levels x 8 B {G, z0, z1, rho_out} as fp16 (G, z0
                                      // rounded down, z1, rho_out up), the levels' 16 x 16-bit cones
@@ -1268,7 +1268,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
     const bool in_run = lane < n_run;
     const uint64_t t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     // sorted == NULL: the ray slots in env order (small batches: a bin holds a ray or none, the sort's three launches buy nothing; a run is
-    // then 64 consecutive slots, padding slots — flags bit 1 clear — take no part)
+    // then `run` consecutive slots — 16, 32 or 64: run_raycast —, padding slots — flags bit 1 clear — take no part)
     const uint32_t gid = sorted ? sorted[i0 + (in_run ? lane : n_run - 1u)] : i0 + (in_run ? lane : n_run - 1u);
     const float4 rsa = reinterpret_cast<const float4*>(rays + gid)[0], rsb = reinterpret_cast<const float4*>(rays + gid)[1];
     const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w), map = rflags & 1u;
