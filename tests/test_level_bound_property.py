@@ -262,3 +262,58 @@ def test_a_set_cone_that_covers_the_ray_gives_test_b_for_every_triangle():
         covered += 1
     assert covered > 2000
     assert tightest < 0.02                                   # the worst-azimuth normal on the cone's rim sits close to the threshold
+
+
+# ---------------------------------------------------------------------------------------------------
+# The constants of test (A) themselves (rover_cull.hip: CullK<0>, cull_proof_h): c_a |h|^2 - (h.d)^2 > c_rho rho^2 has to
+# give W - rho >= eta (|h| + 2 rho) — f32 proof: c_a = 0.995, c_rho = 1.19, eta = 0.02, |d|^2 <= 1.00001; as-shipped fp16 proof: c_a, c_rho
+# derived from eta by cull_proof_h, |d|^2 within 4e-3 of 1 (the direction is normalised in fp16).
+# ---------------------------------------------------------------------------------------------------
+def _proof_h(eta):
+    """cull_proof_h (rover_cull.hip)."""
+    a = eta + 1.0e-3
+    b = 1.0 + 2.0 * a
+    c_rho = (b * b + 2.0 * a * b) * 1.004 + 0.005
+    c_a = float(f32(0.996 * (1.0 - (a * a + 0.5 * a * b)) - 0.0005))
+    return c_a, c_rho
+
+
+def _edge_of_test_a(rng, c_a, c_rho, eta, dd_lo, dd_hi, n):
+    """Rays at the edge of `c_a |h|^2 - (h.d)^2 > c_rho rho^2`: the smallest (W - rho) / (|h| + 2 rho) over them must stay >= eta."""
+    worst = math.inf
+    for _ in range(n):
+        rho = float(rng.uniform(1.0e-3, 0.5))
+        dlen = math.sqrt(float(rng.uniform(dd_lo, dd_hi)))
+        dv = rng.normal(size=3); dv *= dlen / np.linalg.norm(dv)
+        dhat = dv / np.linalg.norm(dv)
+        perp = np.cross(dhat, rng.normal(size=3)); perp /= np.linalg.norm(perp)
+        along = float(rng.uniform(-1.0, 1.0)) * float(rng.choice([0.1, 1.0, 10.0]))
+        lo, hi = 0.0, 50.0 + 50.0 * abs(along)
+
+        def passes(w):
+            h = perp * w + dhat * along
+            return c_a * float(h @ h) - float(h @ dv) ** 2 > c_rho * rho * rho
+        if not passes(hi):
+            continue
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            if passes(mid):
+                hi = mid
+            else:
+                lo = mid
+        h = perp * hi + dhat * along
+        W = hi                                                   # distance from the centre to the ray's line
+        worst = min(worst, (W - rho) / (float(np.linalg.norm(h)) + 2.0 * rho))
+    return worst
+
+
+def test_test_a_constants_give_the_margin_the_proofs_use():
+    rng = np.random.default_rng(11)
+    w32 = _edge_of_test_a(rng, 0.995, 1.19, 0.02, 0.99999, 1.00001, 3000)
+    assert w32 >= 0.02, w32
+    assert w32 < 0.03                                            # ... and not much more: the constants are not wasteful
+    for eta in (0.04, 0.06, 0.10):                               # 0.06: the library's choice (cull_eta_h)
+        c_a, c_rho = _proof_h(eta)
+        wh = _edge_of_test_a(rng, c_a, c_rho, eta, 0.996, 1.004, 3000)
+        assert wh >= eta, (eta, wh)
+        assert wh < eta + 0.02
