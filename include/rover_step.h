@@ -312,9 +312,11 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        4 = staged: the proof of 3 on per-cell record rows ordered by a distance bound (16 suffix levels per cell: a ray tests only the
  *        prefix it cannot clear as a group), one lane per (ray, chunk of 8 pairs), then the same exact phase.
  *        All give bit-identical results.  auto: fp32 arithmetic (ray_precision 0, 1) — 4 from 24 576 rays per step, 1 below;
- *        ray_precision = 2 — 3 from 24 576 rays per step, 2 below.
+ *        ray_precision = 2 — 2 up to 24 576 rays per step; above that 4 in env order below 98 304 rays per step, 4 behind the sort on dense
+ *        ray sets (ten or more heightmap rays per terrain cell), 3 otherwise.
  * name = "lane_env_order" (variant 4): 1 = no sort, the ray slots in env order; 0 = rays sorted by (map, cell); -1 (default) = auto: env
- *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 48 cells.
+ *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 48 cells (ray_precision
+ *        2: below 98 304 rays per step).
  * name = "lane_rocks" (variant 4, sorted): 1 = the rock rays through the staged kernel too, 0 = through the culled one (3); -1 (default)
  *        = auto: 1 when fewer than half of the rocks map's cells have a usable far bound (an irregular rocks mesh).
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.

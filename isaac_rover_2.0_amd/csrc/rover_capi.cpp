@@ -188,6 +188,7 @@ static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_env
 // 16 384: 19.2 / 72.2 / 79.7 / 66.9, 32 768: 19.3 / 98.4 / 113.6 / 71.1, 65 536: 19.2 / 121.7 / 142.1 / 73.5; 120 + 26 rays at 4 096 envs
 // 8.4 / 26.1 / 30.8 / 35.0, at 65 536 envs 8.5 / 56.2 / 69.9 / 45.4.
 #define ROVER_AUTO_LANE_RAYS 24576u
+#define ROVER_AUTO_LANE_ENV_RAYS_F16 98304u   // as shipped: below this many rays the staged kernel in env order (lane_env_order) is ahead of the culled one
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
@@ -200,8 +201,16 @@ static int effective_variant(const rover_ctx* c) {
     // variant 4 (staged, rover_cull.hip: lane = (ray, chunk of 8 pairs) over per-cell record rows): either arithmetic, each with its
     // proof's tables.  Auto: the table above; the native 1 634 + 26 rays at 512 envs on an irregular mesh 2.13 / 2.98 (culled / staged), the
     // irregular mesh at 65 536 envs 83.5 / 113.8.  As shipped (fp16 proof: a third of the rays lie off their cell's narrow cone and test
-    // every pair both ways) 91.2 / 87.1: stays on the culled kernel.
-    if (v4_ok && (c->variant == 4 || (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) >= ROVER_AUTO_LANE_RAYS))) return 4;
+    // every pair both ways) the culled kernel stays ahead at 37 + 26 rays from 2 048 envs on (23.1 / 22.2 there, 31.7 / 27.1 at 4 096, 54.2 / 46.8 at
+    // 16 384, 91.2 / 87.1 at 65 536) but not below (env order, no sort: 512 envs 9.7 / 13.4, 1 024: 15.4 / 18.5, 1 536: 20.0 / 21.8) and not on dense ray
+    // sets — ten or more heightmap rays per terrain cell (behind the sort: 120 + 26 rays at 65 536 envs 47.1 / 51.6, the native 1 634 + 26 rays at
+    // 4 096 envs 3.65 / 3.86, at 512 envs on the 24 m irregular mesh 1.47 / 1.62; below ten: native rays at 512 envs on the 60 m map 2.25 / 1.95).
+    if (v4_ok && c->variant == 4) return 4;
+    if (v4_ok && c->variant == 0 && c->have_dist) {
+        if (c->precision != 2) { if (valid_rays(c) >= ROVER_AUTO_LANE_RAYS) return 4; }
+        else if (valid_rays(c) < ROVER_AUTO_LANE_ENV_RAYS_F16 ||
+                 (uint64_t)c->cfg.num_envs * (uint64_t)c->P >= 10ull * (uint64_t)c->cull_cells[0]) return 4;
+    }
     return 3;
 }
 
@@ -785,6 +794,8 @@ static bool lane_env_order(const rover_ctx* c, int variant) {
     // what decides is the heightmap rays per terrain cell (rovers spread over the map): below ~1.5 the sort buys no sharing (4 096 envs x 120
     // rays: 1.37, env order 35.3 against 30.9 M env-steps/s behind the sort; 16 384 x 37: 1.68, 67.1 / 80.1) — and the rovers per cell: from one per
     // 48 cells a cell's rays come from several rovers and only the sort brings them together (8 192 x 37: 57.8 / 59.3; 4 096 x 37: 49.2 / 41.1)
+    // (as shipped the staged kernel is the auto choice for small batches in env order and for dense ray sets behind the sort: effective_variant)
+    if (c->precision == 2) return c->have_dist && valid_rays(c) < ROVER_AUTO_LANE_ENV_RAYS_F16;
     return c->have_dist && 2ull * (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 3ull * (uint64_t)c->cull_cells[0] &&
            48ull * (uint64_t)c->cfg.num_envs < (uint64_t)c->cull_cells[0];
 }

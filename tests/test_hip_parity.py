@@ -646,7 +646,8 @@ def test_rays_that_clear_their_cell_are_not_scanned():
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto), f32 arithmetic: the env-order kernel below 24 576 rays per step, the staged kernel (4) from there on —
     in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays and 48 cells or more hold one rover —; as shipped: the binned kernel up to 24 576 rays,
-    the culled one above; K8 > 256 always falls back to the env-order kernel."""
+    above that the staged kernel in env order below 98 304 rays and behind the sort on dense ray sets (ten or more heightmap rays per terrain
+    cell), the culled one otherwise; K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=16, n_stones=8)
@@ -655,11 +656,12 @@ def test_auto_variant_and_run_selection():
     assert small.info().raycast_variant == 1
     small.set_option("ray_precision", 2)
     assert small.info().raycast_variant == 2
-    for n, want32, want16 in ((384, 1, 2), (512, 4, 3), (1024, 4, 3)):   # 24 192 / 32 256 / 64 512 rays: either side of the f32 and of the fp16 switch
+    for n, want32, want16 in ((384, 1, 2), (512, 4, 4), (1024, 4, 4)):   # 24 192 / 32 256 / 64 512 rays: either side of the f32 and of the fp16 switch
         mid = make_engine(scene, distn, n, variant=None)
         assert mid.info().raycast_variant == want32, n
         mid.set_option("ray_precision", 2)
         assert mid.info().raycast_variant == want16, n
+        assert mid.info().raycast_sorted == 0 or want16 != 4, n           # (as shipped, small batches: the staged kernel in env order)
         mid.close()
     # the staged kernel without the sort: fewer than 1.5 heightmap rays per terrain cell AND fewer than one rover per 48 cells
     wide = synth.make_scene(n_cells=160, k=16, n_stones=8)
@@ -667,10 +669,14 @@ def test_auto_variant_and_run_selection():
         e = make_engine(wide, distn, n, variant=None)
         assert e.info().raycast_variant == 4 and e.info().raycast_sorted == want_sorted, n
         e.close()
+    sparse = make_engine(wide, distn, 4096, variant=None)   # as shipped, 258 048 rays, 5.9 heightmap rays per terrain cell: the culled kernel
+    sparse.set_option("ray_precision", 2)
+    assert sparse.info().raycast_variant == 3
+    sparse.close()
     big = make_engine(scene, distn, 4096, variant=None)
     assert big.info().raycast_variant == 4 and big.info().raycast_sorted == 1
     big.set_option("ray_precision", 2)
-    assert big.info().raycast_variant == 3            # as shipped: the culled kernel (its own proof tables)
+    assert big.info().raycast_variant == 4 and big.info().raycast_sorted == 1      # as shipped, 37 heightmap rays per terrain cell of this small map: staged, sorted
     big.set_option("ray_precision", 0)
     st = synth.make_states(4096, 6.4, seed=3)
     a = hip_step(big, st)                                   # auto run length
