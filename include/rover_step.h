@@ -313,7 +313,7 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        prefix it cannot clear as a group), one lane per (ray, chunk of 8 pairs), then the same exact phase.
  *        All give bit-identical results.  auto: fp32 arithmetic (ray_precision 0, 1) — 4 from 24 576 rays per step, 1 below;
  *        ray_precision = 2 — 2 up to 24 576 rays per step; above that 4 in env order below 98 304 rays per step, 4 behind the sort on dense
- *        ray sets (ten or more heightmap rays per terrain cell), 3 otherwise.
+ *        ray sets (ten or more heightmap rays per terrain cell; two or more on an irregular terrain mesh), 3 otherwise.
  * name = "lane_env_order" (variant 4): 1 = no sort, the ray slots in env order; 0 = rays sorted by (map, cell); -1 (default) = auto: env
  *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 48 cells (ray_precision
  *        2: below 98 304 rays per step).

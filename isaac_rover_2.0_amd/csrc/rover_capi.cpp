@@ -204,12 +204,14 @@ static int effective_variant(const rover_ctx* c) {
     // every pair both ways) the culled kernel stays ahead at 37 + 26 rays from 2 048 envs on (23.1 / 22.2 there, 31.7 / 27.1 at 4 096, 54.2 / 46.8 at
     // 16 384, 91.2 / 87.1 at 65 536) but not below (env order, no sort: 512 envs 9.7 / 13.4, 1 024: 15.4 / 18.5, 1 536: 20.0 / 21.8) and not on dense ray
     // sets — ten or more heightmap rays per terrain cell (behind the sort: 120 + 26 rays at 65 536 envs 47.1 / 51.6, the native 1 634 + 26 rays at
-    // 4 096 envs 3.65 / 3.86, at 512 envs on the 24 m irregular mesh 1.47 / 1.62; below ten: native rays at 512 envs on the 60 m map 2.25 / 1.95).
+    // 4 096 envs 3.65 / 3.86; below ten: native rays at 512 envs 2.25 / 1.95).  On an irregular terrain mesh — fewer than half of the cells
+    // with a usable far bound: the culled kernel then scans most cells whole — from two rays per cell: 37 + 26 rays at 4 096 / 16 384 / 65 536
+    // envs (0.4 / 1.7 / 6.7 rays per cell) 25.5 / 20.7, 36.1 / 34.3, 48.1 / 58.7; the native rays at 512 envs (2.3) 1.46 / 1.61.
     if (v4_ok && c->variant == 4) return 4;
     if (v4_ok && c->variant == 0 && c->have_dist) {
         if (c->precision != 2) { if (valid_rays(c) >= ROVER_AUTO_LANE_RAYS) return 4; }
         else if (valid_rays(c) < ROVER_AUTO_LANE_ENV_RAYS_F16 ||
-                 (uint64_t)c->cfg.num_envs * (uint64_t)c->P >= 10ull * (uint64_t)c->cull_cells[0]) return 4;
+                 (uint64_t)c->cfg.num_envs * (uint64_t)c->P >= (2 * c->cull_farok[0] >= c->cull_cells[0] ? 10ull : 2ull) * (uint64_t)c->cull_cells[0]) return 4;
     }
     return 3;
 }
