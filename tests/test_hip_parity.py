@@ -669,7 +669,8 @@ def test_auto_variant_and_run_selection():
         e = make_engine(wide, distn, n, variant=None)
         assert e.info().raycast_variant == 4 and e.info().raycast_sorted == want_sorted, n
         e.close()
-    sparse = make_engine(wide, distn, 4096, variant=None)   # as shipped, 258 048 rays, 5.9 heightmap rays per terrain cell: the culled kernel
+    wider = synth.make_scene(n_cells=256, k=16, n_stones=8)
+    sparse = make_engine(wider, distn, 2048, variant=None)   # as shipped, 129 024 rays, 1.2 heightmap rays per terrain cell: the culled kernel
     sparse.set_option("ray_precision", 2)
     assert sparse.info().raycast_variant == 3
     sparse.close()
