@@ -455,7 +455,11 @@ def measure_also(args, device, local_rank, **override):
         _SCENES.clear()                      # one scene resident at a time
         _SCENES[skey] = load_scene(a, device, local_rank)
     scene, zf = _SCENES[skey]
-    distn = synth.ray_distribution(a.rays)
+    if a.rays == "native":
+        from isaac_rover_amd.tasks.utils.heightmap_distribution import generate_native
+        distn = tuple(np.asarray(x) for x in generate_native())
+    else:
+        distn = synth.ray_distribution(a.rays)
     n_rays = int(distn[0].shape[0])
     eng = _make_engine(E, local_rank, E, 0)
     eng.set_scene(scene, distn)
@@ -540,12 +544,18 @@ def measure_also(args, device, local_rank, **override):
 def also_workloads(args, device, local_rank):
     """The other single-GPU workloads of BASELINE.json and the two representative variants of the headline, each under this run's
     clock (the driver times one command): configs[1], configs[4], one rank's shard of configs[3]; the geometry the reference's real
-    terrain has (a decimated mesh, utils/terrain_utils/terrain_generation.py:217-243) and its real arithmetic (fp16, camera.py:55)."""
+    terrain has (a decimated mesh, utils/terrain_utils/terrain_generation.py:217-243) and its real arithmetic (fp16, camera.py:55); and
+    the reference's own operating point — numEnvs 512 (cfg/task/Rover.yaml:11) x its native 1 634 + 26 rays on that mesh — in both
+    arithmetics (the irregular scene of the entry before them is still resident)."""
     return {"configs1": measure_also(args, device, local_rank, envs_per_gpu=4096, also_steps=max(200, args.also_steps)),
             "configs3_shard": measure_also(args, device, local_rank, envs_per_gpu=32768),
             "configs4": measure_also(args, device, local_rank, rays="120", validate_goals=True),
             "fp16_as_shipped": measure_also(args, device, local_rank, ray_precision="fp16_as_shipped"),
-            "mesh_irregular": measure_also(args, device, local_rank, mesh="irregular")}
+            "mesh_irregular": measure_also(args, device, local_rank, mesh="irregular"),
+            "ref_operating_point": measure_also(args, device, local_rank, mesh="irregular", rays="native", envs_per_gpu=512,
+                                                also_steps=max(500, args.also_steps)),
+            "ref_operating_point_as_shipped": measure_also(args, device, local_rank, mesh="irregular", rays="native", envs_per_gpu=512,
+                                                           ray_precision="fp16_as_shipped", also_steps=max(500, args.also_steps))}
 
 
 def run_rank(args):
