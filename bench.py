@@ -845,6 +845,7 @@ def run_rank(args):
 
 
 def main(argv=None):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (before anything touches HIP: a launcher's ranks need dmabuf IPC for RCCL on this host)
     args = parse(argv)
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and (world_env is None or (world_env == "1" and "RANK" not in os.environ)):
