@@ -91,6 +91,7 @@ def parse(argv=None):
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` object of the default N = 1 run: the same 65 536-env batch on the irregular (decimated-style) mesh "
                          "and in the reference's as-shipped fp16 arithmetic, timed in the same process after the headline pass")
+    ap.add_argument("--also-only", default="", help="comma-separated names of the `also` workloads to run (default: all)")
     ap.add_argument("--also-steps", type=int, default=50, help="timed steps per pass of each `also` workload (>= 20)")
     ap.add_argument("--passes", type=int, default=30,
                     help="back-to-back timed passes of --steps steps (each bracketed by barrier + device sync); value / ms_per_step are the MEDIAN "
@@ -259,6 +260,7 @@ def cpu_baseline(args, scene, distn, states):
     return {"value": n / best, "unit": "env-steps/s", "cores": threads, "kind": "port", "cpu_model": model, "torch_ref": torch_ref,
             "host": {"sockets": len(sockets) or None, "physical_cores": len(phys) or None, "logical_cpus": logical,
                      "omp_threads": threads},
+            "sample_short": f"{n} envs x {reps} reps, best rep (oracle/rover_oracle.c, OpenMP)",
             "sample": f"{n} envs x {reps} reps of the same workload (P={distn[0].shape[0]}, K={args.k}, "
                       f"{args.cells}x{args.cells} cells), best rep; oracle/rover_oracle.c, gcc -O2 -fopenmp on every logical CPU",
             "reference_pytorch": "the reference's own PyTorch path is not runnable on the GPU box (it cannot travel); measured in the "
@@ -427,6 +429,104 @@ def _median_pass(times):
     return t[len(t) // 2], t[0], t[-1]
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the record: ONE compact JSON line on stdout (the driver keeps the last ~8 KB of stdout: a longer line is lost — round 5's
+# 21 KB line was), everything else in a side file
+# ---------------------------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 4000         # bytes: tests/test_host_logic.py holds the line to this
+
+
+def _r(x, digits=5):
+    """A float at `digits` significant digits (the line is a record, not a checkpoint); anything else unchanged; NaN / inf -> None
+    (strict JSON has neither)."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _short_workload(w):
+    """"BASELINE configs[1]: 4096 envs x (37 + 26) rays, K=200, ..." -> label + what differs from the headline."""
+    head, _, rest = w.partition(": ")
+    if head.startswith("RoverTask"):                         # the task-level entries: "RoverTask.pre_physics_step + ... (<label>)"
+        head = "RoverTask pre+post_physics_step, " + head[head.find("(") + 1:head.rfind(")")]
+    head = head.replace(" (32 768 of its 262 144 envs, no gather)", "")
+    keep = [p for p in rest.split(", ") if p.startswith(("mesh=", "ray_precision=", "+ goal")) and p not in ("mesh=grid", "ray_precision=fp32")]
+    envs = rest.split(", ")[0] if rest else ""
+    return ", ".join([head if "BASELINE configs" in head else "custom", envs] + keep)
+
+
+def compact_line(full, full_path=None):
+    """The line the driver parses: the contract's keys, the roofline and cpu_baseline objects at their required fields, `also` at
+    five fields per workload.  `full` (every number this run measured) goes to `full_path`."""
+    rf = full.get("roofline") or {}
+    line = {k: full[k] for k in
+            ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "envs_total", "rays_per_env", "obs_dim", "algorithmic_bytes_per_env_step") if k in cfg}
+    ps = full.get("passes") or {}
+    line["passes"] = {k: ps.get(k) for k in ("n", "min_ms_per_step", "max_ms_per_step")}
+    line["passes"]["spread"] = _r(ps.get("spread"))
+    line["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+                                                   "stall_frac", "limited_by", "profile_key", "profile_stale")}
+    line["roofline"]["valu_frac"] = _r((rf.get("valu") or {}).get("frac"))
+    line["roofline"]["algorithmic_equiv_GBps"] = _r(rf.get("algorithmic_equiv_GBps"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "cpu_model": cb.get("cpu_model"),
+                                "sample": cb.get("sample_short") or cb.get("sample")}
+        tr = cb.get("torch_ref") or {}
+        for name in ("fp32", "fp16_as_shipped"):
+            if isinstance(tr.get(name), dict):
+                line["cpu_baseline"]["torch_ref_" + name] = _r(tr[name]["value"])
+    for k in ("rccl_ranks", "backend", "lib", "lib_built_from_tree", "gather_check", "gather_bytes_per_rank_per_step",
+              "gather_messages_per_peer_per_step"):
+        if k in full:
+            line[k] = full[k]
+    if full.get("per_rank"):
+        line["per_rank"] = {k: [_r(x) for x in v] for k, v in full["per_rank"].items()}
+    for k in ("alt_sync_gather", "alt_overlapped"):
+        if k in full:
+            a = full[k]
+            line[k] = {"value": _r(a["value"], 7), "ms_per_step": _r(a["ms_per_step"], 7), "gather_check": a.get("gather_check")}
+    if full.get("cull"):
+        line["cull"] = {k: _r(full["cull"].get(k)) for k in ("candidate_pairs_per_ray", "rays_not_scanned")}
+    if full.get("also"):
+        line["also"] = {}
+        for name, a in full["also"].items():
+            if "error" in a:
+                line["also"][name] = {"error": str(a["error"])[:120]}
+                continue
+            e = {"value": _r(a["value"]), "ms_per_step": _r(a["ms_per_step"]), "dtype": a.get("dtype"),
+                 "workload": _short_workload(a.get("workload", "")), "frac": _r((a.get("roofline") or {}).get("frac"))}
+            for k in ("host_enqueue_ms", "engine_step_ms"):          # the task-level entries
+                if k in a:
+                    e[k] = _r(a[k])
+            line["also"][name] = e
+    if full_path:
+        line["full_record"] = full_path
+    return line
+
+
+def write_full(full):
+    """The whole record as indented JSON: gpurun_out/bench_full.json when that directory exists (it is merged back from the GPU box),
+    else next to bench.py, else the temp dir; -> the path written (None if nowhere is writable)."""
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT, tempfile.gettempdir()):
+        if not os.path.isdir(d):
+            continue
+        path = os.path.join(d, "bench_full.json")
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1, default=str)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
+
+
 _SCENES = {}
 
 
@@ -541,21 +641,104 @@ def measure_also(args, device, local_rank, **override):
     return out
 
 
+
+def measure_task_api(args, device, local_rank, steps=200, graph=None, **override):
+    """The drop-in surface itself (N = 1): what the reference's caller invokes per env.step() — `RoverTask.pre_physics_step(actions)`
+    (rover.py:338-414: done compaction consumed, device-side reset_idx + set_targets, history, Ackermann) and
+    `RLTask.post_physics_step()` (rl_task.py:239-259: the fused rover_step) — on static poses (the pose feeder / physics stand-in is
+    skipped; envs the step flags done are reset to their spawn by the task itself, as in training).  Reports wall ms per step, the host's
+    enqueue time per step (the Python + ctypes cost of the task layer) and, next to them, `Engine.step` alone on the same buffers."""
+    import argparse as _ap
+    import numpy as np
+    import torch
+    from isaac_rover_amd import config as rcfg, synth, vec_env
+    from isaac_rover_amd.tasks.rover import RoverTask
+    a = _ap.Namespace(**vars(args))
+    for k, v in override.items():
+        setattr(a, k, v)
+    E = a.envs_per_gpu
+    skey = (a.mesh, a.cells, a.k, a.stones)
+    if skey not in _SCENES:
+        _SCENES.clear()
+        _SCENES[skey] = load_scene(a, device, local_rank)
+    scene, zf = _SCENES[skey]
+    distn = None if a.rays == "native" else synth.ray_distribution(a.rays)
+    cfg = rcfg.SimConfig(num_envs=E, device=f"cuda:{local_rank}")
+    kw = {} if graph is None else {"graph": graph}
+    task = RoverTask("Rover", cfg, vec_env.VecEnv(headless=True), scene=scene, distribution=distn, fused=True, device_reset=True,
+                     ray_precision=a.ray_precision, cell_index_mode=a.cell_index_mode, stone_mask_margin=0.0, **kw)
+    st = synth.make_states(E, a.cells * 0.1, seed=7, heightfn=zf)
+    task.set_up_scene(spawn_positions=st["pos"].to(device))
+    task.post_reset()
+    task._rover.feed(orientations=st["quat"].to(device), joint_positions=st["joints"].to(device))
+    task.reset()
+    g = torch.Generator().manual_seed(3)
+    acts = [(2 * torch.rand(E, 2, generator=g) - 1).to(device) for _ in range(8)]
+
+    def step(i):
+        task.pre_physics_step(acts[i % 8])
+        return task.post_physics_step()
+
+    for i in range(40):                      # past global step 10 (the curriculum switch, rover.py:344-353) and any graph capture
+        step(i)
+    _sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    t_enq = time.perf_counter() - t0
+    _sync()
+    t_all = time.perf_counter() - t0
+    n_done = int(task.reset_buf.sum().item())
+    eng = task._engine
+    for i in range(10):
+        eng.step(task._sin, task._sout, increment_progress=True, compact=True)
+    _sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.step(task._sin, task._sout, increment_progress=True, compact=True)
+    _sync()
+    t_eng = time.perf_counter() - t0
+    info = eng.info()
+    out = {"value": E * steps / t_all, "unit": "env-steps/s", "ms_per_step": 1e3 * t_all / steps, "steps": steps,
+           "host_enqueue_ms": 1e3 * t_enq / steps, "engine_step_ms": 1e3 * t_eng / steps,
+           "task_over_engine": t_all / t_eng, "graph": bool(getattr(task, "_use_graph", False)),
+           "envs_done_last_step": n_done, "dtype": "f16" if a.ray_precision == "fp16_as_shipped" else "f32",
+           "raycast_variant": int(info.raycast_variant),
+           "workload": f"RoverTask.pre_physics_step + post_physics_step ({config_label(a, E, 1, E)}): {E} envs x ({a.rays} + 26) rays, "
+                       f"K={a.k}, {a.cells}x{a.cells} cells, mesh={a.mesh}, ray_precision={a.ray_precision}, device reset + goal validation"}
+    task.close()
+    del task, acts
+    torch.cuda.empty_cache()
+    return out
+
+
 def also_workloads(args, device, local_rank):
     """The other single-GPU workloads of BASELINE.json and the two representative variants of the headline, each under this run's
     clock (the driver times one command): configs[1], configs[4], one rank's shard of configs[3]; the geometry the reference's real
     terrain has (a decimated mesh, utils/terrain_utils/terrain_generation.py:217-243) and its real arithmetic (fp16, camera.py:55); and
     the reference's own operating point — numEnvs 512 (cfg/task/Rover.yaml:11) x its native 1 634 + 26 rays on that mesh — in both
     arithmetics (the irregular scene of the entry before them is still resident)."""
-    return {"configs1": measure_also(args, device, local_rank, envs_per_gpu=4096, also_steps=max(200, args.also_steps)),
-            "configs3_shard": measure_also(args, device, local_rank, envs_per_gpu=32768),
-            "configs4": measure_also(args, device, local_rank, rays="120", validate_goals=True),
-            "fp16_as_shipped": measure_also(args, device, local_rank, ray_precision="fp16_as_shipped"),
-            "mesh_irregular": measure_also(args, device, local_rank, mesh="irregular"),
-            "ref_operating_point": measure_also(args, device, local_rank, mesh="irregular", rays="native", envs_per_gpu=512,
-                                                also_steps=max(500, args.also_steps)),
-            "ref_operating_point_as_shipped": measure_also(args, device, local_rank, mesh="irregular", rays="native", envs_per_gpu=512,
-                                                           ray_precision="fp16_as_shipped", also_steps=max(500, args.also_steps))}
+    todo = [("configs1", measure_also, dict(envs_per_gpu=4096, also_steps=max(200, args.also_steps))),
+            ("task_api_configs1", measure_task_api, dict(envs_per_gpu=4096, steps=300)),
+            ("task_api_configs2", measure_task_api, dict(steps=100)),
+            ("configs3_shard", measure_also, dict(envs_per_gpu=32768)),
+            ("configs4", measure_also, dict(rays="120", validate_goals=True)),
+            ("fp16_as_shipped", measure_also, dict(ray_precision="fp16_as_shipped")),
+            ("mesh_irregular", measure_also, dict(mesh="irregular")),
+            ("ref_operating_point", measure_also, dict(mesh="irregular", rays="native", envs_per_gpu=512, also_steps=max(500, args.also_steps))),
+            ("task_api_ref_operating_point", measure_task_api, dict(mesh="irregular", rays="native", envs_per_gpu=512, steps=300)),
+            ("ref_operating_point_as_shipped", measure_also, dict(mesh="irregular", rays="native", envs_per_gpu=512,
+                                                                  ray_precision="fp16_as_shipped", also_steps=max(500, args.also_steps)))]
+    out = {}
+    for name, fn, kw in todo:
+        if args.also_only and name not in args.also_only.split(","):
+            continue
+        try:
+            out[name] = fn(args, device, local_rank, **kw)
+        except Exception as e:           # one extra workload failing must not lose the headline (it is reported in its place)
+            print(f"bench.py: also[{name}] failed: {e!r}", file=sys.stderr)
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def run_rank(args):
@@ -809,7 +992,7 @@ def run_rank(args):
                             "triangles": ci["triangles"], "queue_bytes": ci["queue_bytes"],
                             "cells_with_far_bound": ci["cells_with_far_bound"], "far_records_on_demand": bool(ci["far_records_on_demand"])}
             if info.raycast_variant == 4:
-                line["cull"].update({"lane_items_per_ray": ci["lane_items"] / max(ci["rays"], 1), "lane_passes": ci["lane_passes"],
+                line["cull"].update({"lane_items_per_ray": ci["lane_items"] / max(ci["rays"], 1),
                                      "lane_flushes": ci["lane_flushes"]})
         if world > 1:
             line["gather_check"] = ok
@@ -832,7 +1015,11 @@ def run_rank(args):
             torch.cuda.empty_cache()
             _SCENES[(args.mesh, args.cells, args.k, args.stones)] = (scene, zf)
             line["also"] = also_workloads(args, device, local_rank)
-        print(json.dumps(line), flush=True)
+        out_line = json.dumps(compact_line(line, write_full(line)), allow_nan=False, separators=(",", ":"))
+        if len(out_line) > COMPACT_LIMIT:
+            print(f"bench.py: the record line is {len(out_line)} bytes (> {COMPACT_LIMIT}): a driver that keeps a bounded tail may lose it",
+                  file=sys.stderr)
+        print(out_line, flush=True)
         if line["lib_built_from_tree"] is False:
             # a number measured on a library built from OTHER sources than the ones next to it is not a number of this tree
             print("bench.py: librover_step.so was not built from the sources in the tree (run isaac_rover_2.0_amd/csrc/build.sh)",

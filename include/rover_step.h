@@ -341,6 +341,11 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        sorted rays: 712 MB at 65 536 envs x 63 rays.  Past the budget a step's ray cast is cut into several launches that
  *        re-use the regions (each extra launch costs ~25 us); an allocation failure is an error (ROVER_E_NOMEM), never a
  *        silent change of kernel.
+ * name = "staged_tables": which proofs' tables of the staged ray cast (variant 4) the NEXT rover_set_knn_map calls build — bit 0 the f32
+ *        proof (ray_precision 0 / 1), bit 1 the as-shipped fp16 proof (ray_precision 2); default 3.  About 4.3 KB per cell, map and proof
+ *        at K = 200 (1.56 GB at 600 x 600 cells).  Tables that are not asked for, or that do not fit (the allocation failure is absorbed:
+ *        the culled kernel, variant 3, then runs), leave variant 4 unavailable for that arithmetic: the auto choice never picks it, and
+ *        asking for it by name ("raycast_variant" 4) is an error (ROVER_E_STATE / ROVER_E_NOMEM), never a silent change of kernel.
  * name = "raycast_run": sorted rays per wave for variants 2 and 3 (default 0 = auto: 32 on full batches, down to 4 on small
  *        ones; variant 3 caps it at 64). */
 ROVER_API int rover_set_option(rover_ctx *ctx, const char *name, int64_t value);
@@ -375,7 +380,7 @@ typedef struct {
     int64_t cells_with_far_bound[2];  /* per map: cells whose far bound is wide enough to hold for a usual ray (f32 proof tables) */
     uint64_t far_records_on_demand;   /* 1: the scan kernel in use fetches a bin's far records only when one of its rays tests them, and does not scan rays that clear their whole cell (rays_not_scanned) */
     uint64_t rays_not_scanned;        /* rays that cleared BOTH halves of their cell's triangles as groups (no candidate: the distance is the miss value) */
-    uint64_t lane_items, lane_passes, lane_flushes;   /* staged ray cast (variant 4): (ray, chunk of 8 pairs) items tested, staging passes, exact-phase rounds of runs */
+    uint64_t lane_items, lane_flushes;   /* staged ray cast (variant 4): (ray, chunk of 8 pairs) items tested, exact-phase rounds of runs (saturating at 63 per wave) */
 } rover_cull_info;
 ROVER_API int rover_get_cull_info(rover_ctx *ctx, rover_cull_info *out);
 /* In-situ kernel timing: when enabled, rover_step / rover_get_observations bracket the ray-cast launch with

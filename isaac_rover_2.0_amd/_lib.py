@@ -65,7 +65,7 @@ class CullInfo(C.Structure):
                 ("rays", C.c_uint64), ("candidate_pairs", C.c_uint64), ("rays_both_tests", C.c_uint64), ("bins", C.c_uint64),
                 ("max_pairs_per_run", C.c_uint64), ("queue_bytes", C.c_uint64), ("launches_per_step", C.c_uint64), ("rays_far_skipped", C.c_uint64),
                 ("cells_with_far_bound", C.c_int64 * 2), ("far_records_on_demand", C.c_uint64), ("rays_not_scanned", C.c_uint64),
-                ("lane_items", C.c_uint64), ("lane_passes", C.c_uint64), ("lane_flushes", C.c_uint64)]
+                ("lane_items", C.c_uint64), ("lane_flushes", C.c_uint64)]
 
 
 class ChainDesc(C.Structure):

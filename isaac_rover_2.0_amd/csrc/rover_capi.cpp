@@ -41,6 +41,8 @@ struct rover_ctx {
     int lane_side_stream = 0;           // ROVER_LANE_SIDE_STREAM=1: side by side (measured: 125 against 127 M env-steps/s one after the other — the two launches
                                         // slow each other down by more than the rocks launch's ramp and tail cost; kept as a switch)
     int lane_env_order = -1;            // variant 4 without the sort (the ray slots in env order): -1 auto (mid-size batches), 0 / 1 (option "lane_env_order")
+    int staged_tables = 3;              // which proofs' staged-kernel tables rover_set_knn_map builds: bit 0 the f32 proof, bit 1 the as-shipped fp16 one (option
+                                        // "staged_tables", before the maps are set; ~4.3 KB per cell, K = 200, map and proof)
     int lane_rocks = -1;                // variant 4: the rocks part of the sorted list through the staged kernel too: -1 auto, 0 / 1 (option "lane_rocks", ROVER_LANE_ROCKS)
     uint2* d_cull_queue = nullptr;      // candidate queue of the culled ray cast: one region of 1 024 entries per wave of a launch
     uint64_t cull_entries = 0;
@@ -189,10 +191,14 @@ static uint64_t valid_rays(const rover_ctx* c) { return (uint64_t)c->cfg.num_env
 // 8.4 / 26.1 / 30.8 / 35.0, at 65 536 envs 8.5 / 56.2 / 69.9 / 45.4.
 #define ROVER_AUTO_LANE_RAYS 24576u
 #define ROVER_AUTO_LANE_ENV_RAYS_F16 98304u   // as shipped: below this many rays the staged kernel in env order (lane_env_order) is ahead of the culled one
+static bool lane_tables_ok(const rover_ctx* c) {
+    const LaneTables* t = c->precision == 2 ? c->lane_h : c->lane;
+    return t[0].lrec && t[1].lrec;
+}
 static int effective_variant(const rover_ctx* c) {
     const bool v2_ok = c->map[0].K8 <= 256 && c->map[1].K8 <= 256;      // 64 lanes x 4 triangles
     if (c->variant == 1 || !v2_ok) return 1;
-    const bool v4_ok = c->lane[0].lrec && c->lane[1].lrec && c->lane_h[0].lrec && c->lane_h[1].lrec;
+    const bool v4_ok = lane_tables_ok(c);     // the staged kernel's tables of the proof in force, on both maps
     if (c->variant == 0 && c->precision != 2 && c->have_dist && valid_rays(c) < (v4_ok ? ROVER_AUTO_LANE_RAYS : ROVER_AUTO_CULL_RAYS_F32 + 1u)) return 1;
     if (c->variant == 0 && c->precision == 2 && c->have_dist && valid_rays(c) <= ROVER_AUTO_CULL_RAYS_F16) return 2;      // small batches, as shipped: binned
     // variant 3 (culled): its exact phase runs either arithmetic (f32 / as shipped), each with its own proof tables
@@ -468,7 +474,10 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
-        c->side = nullptr;              // (no side stream: the launches run one after the other)
+        if (c->side) (void)hipStreamDestroy(c->side);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+        c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;      // (no side stream: the launches run one after the other)
     }
     *out = c;
     return ROVER_OK;
@@ -563,8 +572,32 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
         if (T_int >= 0x3ffffffu) { drop(); return fail(c, ROVER_E_INVALID, "set_knn_map: too many triangles for the culled ray cast's 26-bit ids"); }
         const uint64_t b_ct = (uint64_t)T_int * sizeof(uint4), b_rt = (uint64_t)T_int * 20u;
         const uint64_t b_lane = n_cells * ((uint64_t)lane_lvl_stride() * sizeof(float4) + (uint64_t)lane_pp * (2 * sizeof(uint4) + sizeof(uint2)));
-        const bool lane_fits = true;
-        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u + (lane_fits ? 2 * b_lane : 0);
+        // The staged kernel's tables are optional: which proofs get them is the "staged_tables" option, and an allocation that fails drops them
+        // (the culled kernel then runs, effective_variant) — unless variant 4 was asked for by name.
+        const bool want_f = (c->staged_tables & 1) != 0, want_h = (c->staged_tables & 2) != 0;
+        auto lane_alloc = [&](LaneTables& t) -> hipError_t {
+            hipError_t le;
+            if ((le = hipMalloc((void**)&t.lvl, n_cells * (uint64_t)lane_lvl_stride() * sizeof(float4))) != hipSuccess ||
+                (le = hipMalloc((void**)&t.lrec, n_cells * 2ull * lane_pp * sizeof(uint4))) != hipSuccess ||
+                (le = hipMalloc((void**)&t.lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess) {
+                dfree(t.lvl); dfree(t.lrec); dfree(t.lid);
+                t = LaneTables{};
+                (void)hipGetLastError();
+            }
+            return le;
+        };
+        hipError_t le = hipSuccess;
+        if (want_f) le = lane_alloc(lt);
+        if (want_h && le == hipSuccess) le = lane_alloc(lth);
+        if (le != hipSuccess) {
+            dfree(lt.lvl); dfree(lt.lrec); dfree(lt.lid); lt = LaneTables{};
+            if (c->variant == 4) {
+                drop();
+                return fail(c, ROVER_E_NOMEM, "set_knn_map: the staged ray cast's tables (%llu B per proof) do not fit and raycast_variant 4 was requested: %s",
+                            (unsigned long long)b_lane, hipGetErrorString(le));
+            }
+        }
+        cull_bytes = b_idx + 2 * b_ct + b_rt + 2 * n_cells * sizeof(uint32_t) + 2 * n_cells * 48u + ((lt.lrec ? 1 : 0) + (lth.lrec ? 1 : 0)) * b_lane;
         if ((e = hipMalloc((void**)&d_cidx, b_idx)) != hipSuccess || (e = hipMalloc((void**)&d_ctab, b_ct)) != hipSuccess ||
             (e = hipMalloc((void**)&d_ctab_h, b_ct)) != hipSuccess || (e = hipMalloc((void**)&d_qrow_h, n_cells * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void**)&d_rtab, b_rt)) != hipSuccess || (e = hipMalloc((void**)&d_qrow, n_cells * sizeof(uint32_t))) != hipSuccess ||
@@ -576,12 +609,6 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = hipMemcpy(d_order, order.data(), (uint64_t)T_int * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemset(d_cnt, 0, 8 * sizeof(uint32_t))) != hipSuccess ||
-            (lane_fits && ((e = hipMalloc((void**)&lt.lvl, n_cells * (uint64_t)lane_lvl_stride() * sizeof(float4))) != hipSuccess ||
-                           (e = hipMalloc((void**)&lt.lrec, n_cells * 2ull * lane_pp * sizeof(uint4))) != hipSuccess ||
-                           (e = hipMalloc((void**)&lt.lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess ||
-                           (e = hipMalloc((void**)&lth.lvl, n_cells * (uint64_t)lane_lvl_stride() * sizeof(float4))) != hipSuccess ||
-                           (e = hipMalloc((void**)&lth.lrec, n_cells * 2ull * lane_pp * sizeof(uint4))) != hipSuccess ||
-                           (e = hipMalloc((void**)&lth.lid, n_cells * (uint64_t)lane_pp * sizeof(uint2))) != hipSuccess)) ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
                                    d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
                                    shift_x, shift_y, lt, lth, nullptr)) != hipSuccess ||
@@ -735,6 +762,10 @@ static int effective_variant(const rover_ctx* c);
 static int check_precision(rover_ctx* c) {
     if (c->precision == 2 && effective_variant(c) < 2)
         return fail(c, ROVER_E_STATE, "ray_precision 2 (as shipped, fp16 maths) needs ray-cast variant 2 or 3 (K <= 256 on both maps)");
+    // a variant asked for by name is the one that runs, or the call fails: the staged kernel needs the tables of the arithmetic in force
+    if (c->variant == 4 && effective_variant(c) != 4)
+        return fail(c, ROVER_E_STATE, "raycast_variant 4 (staged) was requested but its tables for ray_precision %d are not there (K > 256, option "
+                                      "staged_tables, or they did not fit when the maps were set)", c->precision);
     return ROVER_OK;
 }
 
@@ -1267,7 +1298,7 @@ int rover_get_cull_info(rover_ctx* c, rover_cull_info* out) {
     HIP_TRY(c, hipMemcpy(h.data(), c->d_cull_stats, h.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (const uint4& v : h) {
         out->candidate_pairs += v.x; out->rays += v.y & 0xffu; out->rays_far_skipped += v.y >> 8; out->rays_both_tests += v.z & 0xffu; out->rays_not_scanned += v.z >> 8; out->bins += v.w & 0xffu;
-        out->lane_items += (v.w >> 8) & 0xfffu; out->lane_passes += (v.w >> 20) & 0x3fu; out->lane_flushes += v.w >> 26;
+        out->lane_items += (v.w >> 8) & 0x3ffffu; out->lane_flushes += v.w >> 26;      // (zero in the words the culled kernel's waves write)
         out->max_pairs_per_run = v.x > out->max_pairs_per_run ? v.x : out->max_pairs_per_run;
     }
     return ROVER_OK;
@@ -1499,8 +1530,16 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     USE_DEVICE(c);                                 // some options (re)allocate device workspace
     if (!strcmp(name, "raycast_variant")) {
         if (value < 0 || value > 4) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned), 3 (culled) or 4 (staged)");
+        if (value == 4 && c->have_map[0] && c->have_map[1] && !lane_tables_ok(c))
+            return fail(c, ROVER_E_STATE, "raycast_variant 4 (staged) needs its tables for the arithmetic in force: they were not built (option "
+                                          "staged_tables, or they did not fit when the maps were set)");
         c->variant = (int)value;
         return alloc_cull_queue(c);
+    }
+    if (!strcmp(name, "staged_tables")) {
+        if (value < 0 || value > 3) return fail(c, ROVER_E_INVALID, "staged_tables must be 0 (none), 1 (f32 proof), 2 (as-shipped fp16 proof) or 3 (both)");
+        c->staged_tables = (int)value;       // takes effect at the next rover_set_knn_map
+        return ROVER_OK;
     }
     if (!strcmp(name, "lane_env_order")) {
         if (value < -1 || value > 1) return fail(c, ROVER_E_INVALID, "lane_env_order must be -1 (auto), 0 or 1");
@@ -1516,6 +1555,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 2) return fail(c, ROVER_E_INVALID, "ray_precision must be 0 (fp32), 1 (fp16 sources) or 2 (as shipped)");
         c->precision = (int)value;
         c->rays_valid = false;
+        c->obs_valid = false;           // (what an observation means changed: rover_calculate_metrics wants a fresh rover_get_observations)
         return alloc_cull_queue(c);
     }
     if (!strcmp(name, "bin_low_bits")) {
@@ -1533,6 +1573,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
         c->cell_rcp = (int32_t)value;
         c->hf.rcp = c->cell_rcp;
         c->rays_valid = false;
+        c->obs_valid = false;
         return ROVER_OK;
     }
     if (!strcmp(name, "cull_queue_mb")) {

@@ -1492,7 +1492,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
         const uint32_t n_fskip = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && !allc && 2u * L <= nch) & am);
         const uint32_t n_bins = (uint32_t)__builtin_popcountll(heads);
         const uint32_t n_rays = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));          // (env order: without the padding slots)
-        if (lane == 0u) stats[wave] = make_uint4(ctot, n_rays | (n_fskip << 8), n_both | (n_askip << 8), n_bins | ((ia_tot + ib_tot) << 8) | (n_flush << 26));
+        if (lane == 0u) stats[wave] = make_uint4(ctot, n_rays | (n_fskip << 8), n_both | (n_askip << 8), n_bins | (min(ia_tot + ib_tot, 0x3ffffu) << 8) | (min(n_flush, 63u) << 26));
         if (DIAG && lane == 0u) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) diag[(size_t)wave * 8u + k] = dg[k];

@@ -133,8 +133,9 @@ def test_full_size_config4_dense_rays_and_goal_validation():
     distn = synth.ray_distribution("120")
     st = synth.make_states(E, CELLS * 0.1, seed=9)
     outs = {}
-    for variant in (3, 2, 1):
+    for variant in (4, 3, 2, 1):
         eng = make_engine(scene, distn, E, variant=variant)
+        assert eng.info().raycast_variant == variant
         outs[variant] = hip_step(eng, st)
         if variant != 3:
             eng.close()
@@ -144,6 +145,7 @@ def test_full_size_config4_dense_rays_and_goal_validation():
     for k in a:
         np.testing.assert_array_equal(a[k], outs[1][k], err_msg=k)
         np.testing.assert_array_equal(a[k], outs[2][k], err_msg=k)
+        np.testing.assert_array_equal(a[k], outs[4][k], err_msg=k)
     assert a["obs_buf"].shape == (E, 124)
     np.testing.assert_array_equal(a["obs_buf"][:, 4:], a["ray_dist"] / 2.0)
     idx = np.random.default_rng(2).choice(E, 128, replace=False)

@@ -20,13 +20,18 @@ def _oracle_maps(scene):
 
 @pytest.mark.parametrize("name", STEP_FIXTURES_FP32)
 @pytest.mark.parametrize("fused", [True, False])
-def test_step_matches_reference_golden(name, fused):
+@pytest.mark.parametrize("variant", [None, 4, 3])
+def test_step_matches_reference_golden(name, fused, variant):
+    """Every fp32 fixture captured from the reference, through the library's own choice of ray-cast kernel (None), the staged kernel
+    (4: the one full batches and bench.py run) and the culled kernel (3)."""
     from hip_helpers import hip_step, make_engine
     fx = load_golden(name)
     scene = scene_for(fx)
     st = states_of(fx)
-    eng = make_engine(scene, (fx["distribution"], fx["sparse_idx"], fx["dense_idx"]), st["pos"].shape[0],
+    eng = make_engine(scene, (fx["distribution"], fx["sparse_idx"], fx["dense_idx"]), st["pos"].shape[0], variant=variant,
                       curriculum_level=int(fx["curriculum_level"]), num_envs_global=int(fx["num_envs_global"]))
+    if variant is not None:
+        assert eng.info().raycast_variant == variant
     out = hip_step(eng, st, fused=fused)
     assert_step_close(out, fx, name)
     np.testing.assert_array_equal(out["reset_ids"], np.nonzero(out["reset_buf"])[0])
@@ -34,7 +39,7 @@ def test_step_matches_reference_golden(name, fused):
 
 
 @pytest.mark.parametrize("name,precision", [("step_lattice_fp32", "fp32"), ("step_lattice_fp16_as_shipped", "fp16_as_shipped")])
-@pytest.mark.parametrize("variant", [3, 2, 1])
+@pytest.mark.parametrize("variant", [4, 3, 2, 1])
 def test_exact_ties_follow_the_reference(name, precision, variant):
     """The lattice fixture (exact threshold / det-guard / degenerate-triangle hits, see tests/test_oracle_golden.py):
     on its rounding-free envs the HIP ray casts equal the reference bit for bit, in both kernels."""
@@ -46,6 +51,7 @@ def test_exact_ties_follow_the_reference(name, precision, variant):
     st = states_of(fx)
     eng = make_engine(scene, (fx["distribution"], fx["sparse_idx"], fx["dense_idx"]), st["pos"].shape[0], variant=variant)
     eng.set_option("ray_precision", {"fp32": 0, "fp16_as_shipped": 2}[precision])
+    assert eng.info().raycast_variant == variant
     out = hip_step(eng, st)
     n = int(fx["exact_envs"])
     for key in ("ray_dist", "wheel_dist", "body_dist", "rock_collision", "reset_buf"):
@@ -139,7 +145,7 @@ def test_fp16_source_option_matches_oracle_and_as_shipped_reference():
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [3, 2])
+@pytest.mark.parametrize("variant", [4, 3, 2])
 @pytest.mark.parametrize("name", STEP_FIXTURES_AS_SHIPPED)
 def test_as_shipped_fp16_mode_is_bit_identical_to_the_reference(name, variant):
     """ray_precision 2: the reference AS SHIPPED (Camera.dtype = float16).  Ray distances, wheel / body distances, the

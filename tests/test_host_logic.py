@@ -319,7 +319,12 @@ def _check_bench_line(out, extra):
     import json
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
-    d = json.loads(lines[0])
+    assert out.rstrip("\n").splitlines()[-1] == lines[0], "the record must be the LAST stdout line"
+    assert len(lines[0]) < 4000, "the driver keeps a bounded tail of stdout: the record line must stay compact"
+
+    def no_constants(x):
+        raise ValueError(f"not strict JSON: {x}")
+    d = json.loads(lines[0], parse_constant=no_constants)
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 3 and d["scaling"] == "weak" and d["config"]["envs_total"] == 128
     assert d["value"] > 0 and abs(d["value"] - 128 * 7 / (d["ms_per_step"] * 7e-3)) < 1e-6 * d["value"]
     assert ("overlapped" in d["config"]["workload"]) == (extra == "")
@@ -333,6 +338,47 @@ def _check_bench_line(out, extra):
     assert d["passes"]["n"] == 3 and d["passes"]["min_ms_per_step"] <= d["ms_per_step"] <= d["passes"]["max_ms_per_step"]
     assert "BASELINE configs" not in d["config"]["workload"]      # 64 envs per rank is none of BASELINE.json's configs
     return d
+
+
+def test_bench_record_line_stays_compact_and_strict():
+    """bench.compact_line: whatever the full record holds (seven `also` workloads with their own rooflines and 900-byte notes, NaN
+    from an empty profile, a failed workload), the line printed on stdout is strict JSON well under the ~8 KB of stdout the driver
+    keeps (round 5's 21 KB line was lost) and carries the contract's keys, roofline and cpu_baseline."""
+    import json
+    import bench
+    note = "x" * 900
+    roof = {"bound": "hbm", "achieved": 3161.8123456789, "peak": 8000.0, "unit": "GB/s", "frac": 0.395123456, "traffic": 1.1631e9, "kernel": "lane_scan_kernel",
+            "avg_launch_ms": 0.3678123, "stall_frac": float("nan"), "limited_by": "latency", "profile_key": "E65536_P37_K200_C600", "profile_stale": False,
+            "valu": {"frac": 0.62, "issue_rates": {"a": 4.1} , "unit": note}, "hbm": {"traffic": 1.0}, "note": note, "algorithmic_equiv_GBps": float("inf")}
+    also = {f"workload_{i}": {"value": 1.23456789e8, "unit": "env-steps/s", "ms_per_step": 0.4567891, "steps": 50, "passes": {"n": 5}, "dtype": "f32",
+                              "workload": "BASELINE configs[1]: 4096 envs x (37 + 26) rays, K=200, 600x600 cells, mesh=grid, ray_precision=fp32, cell_index_mode=cuda_rcp",
+                              "roofline": dict(roof), "cull": {"triangles": [1, 2]}} for i in range(9)}
+    also["task_api"] = {"value": 1e7, "ms_per_step": 0.2, "dtype": "f32", "host_enqueue_ms": 0.15, "engine_step_ms": 0.17,
+                        "workload": "RoverTask.pre_physics_step + post_physics_step (custom workload (no BASELINE config)): 512 envs x (native + 26) rays, K=200, mesh=irregular"}
+    also["broken"] = {"error": "RoverError('" + note + "')"}
+    full = {"metric": "env-steps/sec (obs+reward+done)", "value": 1.42e8, "unit": "env-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.46,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "passes": {"n": 30, "statistic": note, "min_ms_per_step": 0.45, "max_ms_per_step": 0.47, "spread": 0.02},
+            "config": {"workload": "BASELINE configs[2]: 65536 envs/GPU x 1 GPU, 37-point heightmap + 26 rock rays, K=200", "envs_total": 65536, "rays_per_env": 63,
+                       "obs_dim": 41, "algorithmic_bytes_per_env_step": 227148, "table_bytes": 1 << 32},
+            "rccl_ranks": 1, "backend": None, "roofline": roof, "lib": "rover_step 0.3 (gfx950) src-000000000000", "lib_built_from_tree": True,
+            "cull": {"candidate_pairs_per_ray": 3.6, "rays_not_scanned": 0.25, "triangles": [720000, 720000]},
+            "cpu_baseline": {"value": 374760.123, "unit": "env-steps/s", "cores": 256, "kind": "port", "cpu_model": "AMD EPYC", "sample": note,
+                             "sample_short": "2048 envs x 20 reps, best rep", "torch_ref": {"torch_threads": 8, "fp32": {"value": 374.0}, "fp16_as_shipped": {"value": 79.7}},
+                             "host": {"sockets": 2}, "reference_pytorch": note},
+            "also": also}
+    line = json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json"), allow_nan=False, separators=(",", ":"))
+    assert "\n" not in line and len(line) < bench.COMPACT_LIMIT, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert d[k] == full[k]
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and "model" not in d["config"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "stall_frac", "profile_key", "profile_stale"}
+    assert d["roofline"]["stall_frac"] is None and d["roofline"]["frac"] == 0.39512
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and len(d["cpu_baseline"]["sample"]) < 100
+    assert set(d["also"]) == set(also) and set(d["also"]["workload_0"]) == {"value", "ms_per_step", "dtype", "workload", "frac"}
+    assert d["also"]["task_api"]["host_enqueue_ms"] == 0.15 and "error" in d["also"]["broken"] and len(d["also"]["broken"]["error"]) <= 120
+    assert d["full_record"] == "gpurun_out/bench_full.json"
 
 
 def test_bench_labels_name_a_baseline_config_only_when_everything_matches():
