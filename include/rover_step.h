@@ -221,6 +221,8 @@ typedef struct {
     uint64_t seed;
     int32_t *n_draws_used;        /* optional [1]                                                                  */
     int32_t yaw_deg_len;          /* entries in yaw_deg: >= n_reset_host, or >= num_envs when n_reset_dev is used   */
+    const uint64_t *seed_dev;     /* optional [1] device word ADDED to `seed` (mod 2^64) when the kernels run: a caller that replays the
+                                   * call from a captured hipGraph keeps its step counter there, so that every replay draws anew   */
 } rover_reset_io;
 ROVER_API int rover_reset_envs(rover_ctx *ctx, const rover_reset_io *io, void *stream);
 
@@ -228,10 +230,11 @@ ROVER_API int rover_reset_envs(rover_ctx *ctx, const rover_reset_io *io, void *s
 /* pre_physics_step rover.py:338-414 minus the reset branch, one kernel: euler_pre = tensor_quat_to_eul(quat) (:343),
  * Memory.input_state for both histories (:379-380, in place, newest first), Ackermann (:391) and the scatter of
  * 4 steering angles / 6 wheel speeds into the [E,13] joint-target arrays at the indices of
- * robots/articulations/views/rover_view.py:45-46.  actions [E,2]; euler_pre / targets optional. */
+ * robots/articulations/views/rover_view.py:45-46.  actions [E,2]; euler_pre / targets optional; actions_nn optional [E,2,3]:
+ * self.actions_nn (:366: the newest action prepended, the oldest dropped), in place. */
 ROVER_API int rover_pre_physics_step(rover_ctx *ctx, const float *actions, const float *quat, float *lin_hist,
                                      float *ang_hist, float *euler_pre, float *joint_pos_targets13,
-                                     float *joint_vel_targets13, void *stream);
+                                     float *joint_vel_targets13, float *actions_nn, void *stream);
 /* Ackermann tasks/utils/kinematics.py:13-67 on its own:
  * lin, ang [n] -> steering [n][6], velocities [n][6] in wheel order FL,FR,ML,MR,RL,RR */
 ROVER_API int rover_ackermann(rover_ctx *ctx, const float *lin, const float *ang, int32_t n, float *steering,

@@ -78,7 +78,8 @@ class ResetIO(C.Structure):
                 ("initial_pos3", C.c_void_p), ("pos3", C.c_void_p), ("quat4", C.c_void_p), ("joint_pos13", C.c_void_p),
                 ("joint_vel13", C.c_void_p), ("base_pos3", C.c_void_p), ("reset", C.c_void_p), ("progress", C.c_void_p),
                 ("yaw_deg", C.c_void_p), ("target3", C.c_void_p), ("radius", C.c_float), ("draws", C.c_void_p),
-                ("max_draws", C.c_int32), ("seed", C.c_uint64), ("n_draws_used", C.c_void_p), ("yaw_deg_len", C.c_int32)]
+                ("max_draws", C.c_int32), ("seed", C.c_uint64), ("n_draws_used", C.c_void_p), ("yaw_deg_len", C.c_int32),
+                ("seed_dev", C.c_void_p)]
 
 
 class Profile(C.Structure):
@@ -113,7 +114,7 @@ SYMBOLS = {
     "rover_sample_height": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rover_generate_goals": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_float, _P, C.c_int32, C.c_uint64, _P, _P]),
     "rover_reset_envs": (C.c_int, [_P, C.POINTER(ResetIO), _P]),
-    "rover_pre_physics_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rover_pre_physics_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rover_ackermann": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "rover_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "rover_get_cull_info": (C.c_int, [_P, C.POINTER(CullInfo)]),
@@ -177,7 +178,14 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(device_index=None):
+    """The current stream of the device as the void* the C ABI takes.  torch.cuda.current_stream() costs ~3 us of Python per call —
+    a fifth of a small batch's step when a step makes three calls —, the raw accessor a tenth of that."""
+    if _raw_stream is not None and device_index is not None:
+        return C.c_void_p(_raw_stream(device_index))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -200,6 +208,7 @@ class Engine:
             device = device.index or 0
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", int(device))
+        self._dev_index = int(device)
         self.cfg = Cfg(self.num_envs, int(num_envs_global), int(env_offset), int(device), int(curriculum_level),
                        int(max_episode_length), rw["pos_reward"], rw["heading_contraint_reward"],
                        rw["motion_contraint_reward"], rw["goal_angle_reward"], rw["boogie_contraint_reward"])
@@ -352,18 +361,18 @@ class Engine:
 
     def step(self, sin: StepIn, sout: StepOut, increment_progress=True, compact=False):
         flags = (STEP_INCREMENT_PROGRESS if increment_progress else 0) | (STEP_COMPACT if compact else 0)
-        self._check(self.lib.rover_step(self._h, C.byref(sin), C.byref(sout), flags, _stream()), "rover_step")
+        self._check(self.lib.rover_step(self._h, C.byref(sin), C.byref(sout), flags, _stream(self._dev_index)), "rover_step")
 
     def get_observations(self, sin, sout):
-        self._check(self.lib.rover_get_observations(self._h, C.byref(sin), C.byref(sout), _stream()),
+        self._check(self.lib.rover_get_observations(self._h, C.byref(sin), C.byref(sout), _stream(self._dev_index)),
                     "rover_get_observations")
 
     def calculate_metrics(self, sin, sout):
-        self._check(self.lib.rover_calculate_metrics(self._h, C.byref(sin), C.byref(sout), _stream()),
+        self._check(self.lib.rover_calculate_metrics(self._h, C.byref(sin), C.byref(sout), _stream(self._dev_index)),
                     "rover_calculate_metrics")
 
     def is_done(self, sin, sout):
-        self._check(self.lib.rover_is_done(self._h, C.byref(sin), C.byref(sout), _stream()), "rover_is_done")
+        self._check(self.lib.rover_is_done(self._h, C.byref(sin), C.byref(sout), _stream(self._dev_index)), "rover_is_done")
 
     def get_depths(self, positions, rotations):
         """Camera.get_depths (camera.py:60-145): positions [E,3], rotations [E,3] euler angles -> (distances [E,P], points [E,P,3],
@@ -374,7 +383,7 @@ class Engine:
         dist = torch.empty(e, self.P, device=positions.device)
         pts = torch.empty(e, self.P, 3, device=positions.device)
         src = torch.empty(e, self.P, 3, device=positions.device)
-        self._check(self.lib.rover_get_depths(self._h, _ptr(positions), _ptr(rotations), _ptr(dist), _ptr(pts), _ptr(src), _stream()),
+        self._check(self.lib.rover_get_depths(self._h, _ptr(positions), _ptr(rotations), _ptr(dist), _ptr(pts), _ptr(src), _stream(self._dev_index)),
                     "rover_get_depths")
         return dist, pts, src
 
@@ -389,7 +398,7 @@ class Engine:
         wheel = torch.empty(e, 24, device=positions.device)
         body = torch.empty(e, 2, device=positions.device)
         self._check(self.lib.rover_get_collisions(self._h, _ptr(positions), _ptr(rotations), _ptr(joints), _ptr(wheel), _ptr(body),
-                                                  _stream()), "rover_get_collisions")
+                                                  _stream(self._dev_index)), "rover_get_collisions")
         return wheel, body
 
     def export_rays(self):
@@ -400,7 +409,7 @@ class Engine:
         dirs = torch.empty(e, r, 3, device=self.device)
         cell = torch.empty(e, r, dtype=torch.int32, device=self.device)
         dist = torch.empty(e, r, device=self.device)
-        self._check(self.lib.rover_export_rays(self._h, _ptr(src), _ptr(dirs), _ptr(cell), _ptr(dist), _stream()), "rover_export_rays")
+        self._check(self.lib.rover_export_rays(self._h, _ptr(src), _ptr(dirs), _ptr(cell), _ptr(dist), _stream(self._dev_index)), "rover_export_rays")
         return src, dirs, cell, dist
 
     def cast_rays(self, src, dirs):
@@ -409,14 +418,14 @@ class Engine:
         self._chk(src, (e, r, 3), f, "src")
         self._chk(dirs, (e, r, 3), f, "dir")
         dist = torch.empty(e, r, device=self.device)
-        self._check(self.lib.rover_cast_rays(self._h, _ptr(src), _ptr(dirs), _ptr(dist), _stream()), "rover_cast_rays")
+        self._check(self.lib.rover_cast_rays(self._h, _ptr(src), _ptr(dirs), _ptr(dist), _stream(self._dev_index)), "rover_cast_rays")
         return dist
 
     def compact_resets(self, reset, reset_ids, n_reset):
         self._chk(reset, (self.num_envs,), torch.int64, "reset")
         self._chk(reset_ids, (self.num_envs,), torch.int64, "reset_ids")
         self._chk(n_reset, (1,), torch.int32, "n_reset")
-        self._check(self.lib.rover_compact_resets(self._h, _ptr(reset), _ptr(reset_ids), _ptr(n_reset), _stream()),
+        self._check(self.lib.rover_compact_resets(self._h, _ptr(reset), _ptr(reset_ids), _ptr(n_reset), _stream(self._dev_index)),
                     "rover_compact_resets")
 
     def quat_to_euler(self, quat, out=None):
@@ -424,7 +433,7 @@ class Engine:
         self._chk(quat, (n, 4), torch.float32, "quat")
         out = torch.empty(n, 3, device=self.device) if out is None else out
         self._chk(out, (n, 3), torch.float32, "euler")
-        self._check(self.lib.rover_quat_to_euler(self._h, _ptr(quat), _ptr(out), n, _stream()), "rover_quat_to_euler")
+        self._check(self.lib.rover_quat_to_euler(self._h, _ptr(quat), _ptr(out), n, _stream(self._dev_index)), "rover_quat_to_euler")
         return out
 
     def build_knn_map(self, vertices, triangles, n_x, n_y, res=0.1, k=200, ranking="exact_f32", cell_x_f16=None, cell_y_f16=None):
@@ -472,7 +481,7 @@ class Engine:
         if out.shape[0] != m or out.shape[1] != n:
             raise RoverError(f"linear_forward: out must be [{m},{n}]")
         self._check(self.lib.rover_linear_forward(self._h, _ptr(x), max(x.stride(0), k), m, k, _ptr(weight), _ptr(bias), n,
-                                                  self.ACTIVATIONS[activation], _ptr(out), out.stride(0), _stream()),
+                                                  self.ACTIVATIONS[activation], _ptr(out), out.stride(0), _stream(self._dev_index)),
                     "rover_linear_forward")
         return out
 
@@ -505,7 +514,7 @@ class Engine:
         widths = (C.c_int32 * n)(*[l.weight.shape[0] for l in layers])
         acts = (C.c_int32 * n)(*[self.ACTIVATIONS[l.activation] for l in layers])
         self._check(self.lib.rover_mlp_chain_forward(self._h, _ptr(x), x.stride(0), m, k0, n, w, b, widths, acts, _ptr(out), out.stride(0),
-                                                     _stream()), "rover_mlp_chain_forward")
+                                                     _stream(self._dev_index)), "rover_mlp_chain_forward")
         return out
 
     def _chain_desc(self, x, layers, out, keep):
@@ -542,7 +551,7 @@ class Engine:
                     raise RoverError(f"chain_pair_forward: {name} must be a float32 GPU matrix of the same rows with >= copy_cols columns")
         self._check(self.lib.rover_mlp_chain_pair_forward(
             self._h, xa.shape[0], C.byref(da), C.byref(db), _ptr(copy_src) if copy_cols else None, copy_src.stride(0) if copy_cols else 0,
-            _ptr(copy_dst) if copy_cols else None, copy_dst.stride(0) if copy_cols else 0, int(copy_cols), _stream()),
+            _ptr(copy_dst) if copy_cols else None, copy_dst.stride(0) if copy_cols else 0, int(copy_cols), _stream(self._dev_index)),
             "rover_mlp_chain_pair_forward")
 
     def set_option(self, name, value):
@@ -558,7 +567,7 @@ class Engine:
         return p
 
     def replay_raycast(self, stream=None):
-        s = _stream() if stream is None else C.c_void_p(stream)
+        s = _stream(self._dev_index) if stream is None else C.c_void_p(stream)
         self._check(self.lib.rover_replay_raycast(self._h, s), "rover_replay_raycast")
 
     # ---- reset path ----------------------------------------------------------------------------
@@ -566,20 +575,20 @@ class Engine:
         n = xy.shape[0]
         self._chk(xy, (n, 2), torch.float32, "xy")
         out = torch.empty(n, device=self.device)
-        self._check(self.lib.rover_clearance(self._h, _ptr(xy), n, _ptr(out), _stream()), "rover_clearance")
+        self._check(self.lib.rover_clearance(self._h, _ptr(xy), n, _ptr(out), _stream(self._dev_index)), "rover_clearance")
         return out
 
     def shift_spawns(self, pos3, max_iter=100000):
         n = pos3.shape[0]
         self._chk(pos3, (n, 3), torch.float32, "pos3")
-        self._check(self.lib.rover_shift_spawns(self._h, _ptr(pos3), n, int(max_iter), _stream()), "rover_shift_spawns")
+        self._check(self.lib.rover_shift_spawns(self._h, _ptr(pos3), n, int(max_iter), _stream(self._dev_index)), "rover_shift_spawns")
         return pos3
 
     def sample_height(self, xy):
         n = xy.shape[0]
         self._chk(xy, (n, 2), torch.float32, "xy")
         out = torch.empty(n, device=self.device)
-        self._check(self.lib.rover_sample_height(self._h, _ptr(xy), n, _ptr(out), _stream()), "rover_sample_height")
+        self._check(self.lib.rover_sample_height(self._h, _ptr(xy), n, _ptr(out), _stream(self._dev_index)), "rover_sample_height")
         return out
 
     def generate_goals(self, env_ids, initial_pos3, target3, radius=8.0, draws=None, max_draws=64, seed=0,
@@ -594,12 +603,14 @@ class Engine:
         self._chk(n_draws_used, (1,), torch.int32, "n_draws_used")
         self._check(self.lib.rover_generate_goals(self._h, _ptr(env_ids), n, _ptr(initial_pos3), _ptr(target3),
                                                   float(radius), _ptr(draws), int(max_draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                                  _ptr(n_draws_used), _stream()), "rover_generate_goals")
+                                                  _ptr(n_draws_used), _stream(self._dev_index)), "rover_generate_goals")
 
-    def reset_envs(self, reset_ids, initial_pos3, pos3, quat4, reset, progress, n_reset_dev=None, n_reset_host=0,
-                   joint_pos13=None, joint_vel13=None, base_pos3=None, yaw_deg=None, target3=None, radius=8.0, draws=None,
-                   max_draws=256, seed=0, n_draws_used=None):
+    def _reset_io(self, reset_ids, initial_pos3, pos3, quat4, reset, progress, n_reset_dev=None, n_reset_host=0,
+                  joint_pos13=None, joint_vel13=None, base_pos3=None, yaw_deg=None, target3=None, radius=8.0, draws=None,
+                  max_draws=256, seed=0, n_draws_used=None, seed_dev=None):
+        """Validates the arguments of rover_reset_envs and packs them (the struct keeps its tensors alive)."""
         e, f, i64 = self.num_envs, torch.float32, torch.int64
+        self._chk(seed_dev, (1,), i64, "seed_dev")
         self._chk(reset_ids, (e,), i64, "reset_ids")
         for t, sh, n in ((initial_pos3, (e, 3), "initial_pos3"), (pos3, (e, 3), "pos3"), (quat4, (e, 4), "quat4"),
                          (joint_pos13, (e, 13), "joint_pos13"), (joint_vel13, (e, 13), "joint_vel13"),
@@ -620,17 +631,51 @@ class Engine:
         io = ResetIO(_ptr(reset_ids), _ptr(n_reset_dev), int(n_reset_host), _ptr(initial_pos3), _ptr(pos3), _ptr(quat4),
                      _ptr(joint_pos13), _ptr(joint_vel13), _ptr(base_pos3), _ptr(reset), _ptr(progress), _ptr(yaw_deg),
                      _ptr(target3), float(radius), _ptr(draws), int(max_draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                     _ptr(n_draws_used), 0 if yaw_deg is None else int(yaw_deg.shape[0]))
-        self._check(self.lib.rover_reset_envs(self._h, C.byref(io), _stream()), "rover_reset_envs")
+                     _ptr(n_draws_used), 0 if yaw_deg is None else int(yaw_deg.shape[0]), _ptr(seed_dev))
+        io._keep = (reset_ids, initial_pos3, pos3, quat4, reset, progress, n_reset_dev, joint_pos13, joint_vel13, base_pos3, yaw_deg,
+                    target3, draws, n_draws_used, seed_dev)
+        return io
 
-    def pre_physics_step(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None):
+    def reset_envs(self, *args, **kw):
+        """rover_reset_envs (reset_idx + set_targets for the compacted ids, rover.py:416-453,566-584); arguments: `_reset_io`."""
+        io = self._reset_io(*args, **kw)
+        self._check(self.lib.rover_reset_envs(self._h, C.byref(io), _stream(self._dev_index)), "rover_reset_envs")
+
+    def bind_reset_envs(self, *args, **kw):
+        """reset_envs with everything but the seed validated and packed ONCE: returns call(seed) (for a task whose buffers persist)."""
+        io = self._reset_io(*args, **kw)
+        fn, check, idx, h = self.lib.rover_reset_envs, self._check, self._dev_index, self._h
+
+        def call(seed):
+            io.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            check(fn(h, C.byref(io), _stream(idx)), "rover_reset_envs")
+        return call
+
+    def bind_pre_physics(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None, actions_nn=None):
+        """Validates the tensors ONCE and returns a callable that enqueues rover_pre_physics_step on them (for a task whose buffers
+        are persistent: the per-call checks are most of a small batch's host cost).  The callable keeps the tensors alive."""
         e, f = self.num_envs, torch.float32
+        for t, sh, n in ((actions, (e, 2), "actions"), (quat, (e, 4), "quat"), (lin_hist, (e, 3), "lin_hist"),
+                         (ang_hist, (e, 3), "ang_hist"), (euler_pre, (e, 3), "euler_pre"), (pos_targets13, (e, 13), "pos_targets13"),
+                         (vel_targets13, (e, 13), "vel_targets13"), (actions_nn, (e, 2, 3), "actions_nn")):
+            self._chk(t, sh, f, n)
+        keep = (actions, quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13, actions_nn)
+        args = [self._h] + [_ptr(t) for t in keep]
+        fn, check, idx = self.lib.rover_pre_physics_step, self._check, self._dev_index
+
+        def call(_keep=keep):
+            check(fn(*args, _stream(idx)), "rover_pre_physics_step")
+        return call
+
+    def pre_physics_step(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None, actions_nn=None):
+        e, f = self.num_envs, torch.float32
+        self._chk(actions_nn, (e, 2, 3), f, "actions_nn")
         for t, sh, n in ((actions, (e, 2), "actions"), (quat, (e, 4), "quat"), (lin_hist, (e, 3), "lin_hist"),
                          (ang_hist, (e, 3), "ang_hist"), (euler_pre, (e, 3), "euler_pre"),
                          (pos_targets13, (e, 13), "pos_targets13"), (vel_targets13, (e, 13), "vel_targets13")):
             self._chk(t, sh, f, n)
         self._check(self.lib.rover_pre_physics_step(self._h, _ptr(actions), _ptr(quat), _ptr(lin_hist), _ptr(ang_hist),
-                                                    _ptr(euler_pre), _ptr(pos_targets13), _ptr(vel_targets13), _stream()),
+                                                    _ptr(euler_pre), _ptr(pos_targets13), _ptr(vel_targets13), _ptr(actions_nn), _stream(self._dev_index)),
                     "rover_pre_physics_step")
 
     def ackermann(self, lin, ang):
@@ -639,6 +684,6 @@ class Engine:
         self._chk(ang, (n,), torch.float32, "ang")
         steer = torch.empty(n, 6, device=self.device)
         vel = torch.empty(n, 6, device=self.device)
-        self._check(self.lib.rover_ackermann(self._h, _ptr(lin), _ptr(ang), n, _ptr(steer), _ptr(vel), _stream()),
+        self._check(self.lib.rover_ackermann(self._h, _ptr(lin), _ptr(ang), n, _ptr(steer), _ptr(vel), _stream(self._dev_index)),
                     "rover_ackermann")
         return steer, vel

@@ -763,8 +763,9 @@ static int check_precision(rover_ctx* c) {
     if (c->precision == 2 && effective_variant(c) < 2)
         return fail(c, ROVER_E_STATE, "ray_precision 2 (as shipped, fp16 maths) needs ray-cast variant 2 or 3 (K <= 256 on both maps)");
     // a variant asked for by name is the one that runs, or the call fails: the staged kernel needs the tables of the arithmetic in force
-    if (c->variant == 4 && effective_variant(c) != 4)
-        return fail(c, ROVER_E_STATE, "raycast_variant 4 (staged) was requested but its tables for ray_precision %d are not there (K > 256, option "
+    // (K > 256 on a map is the documented exception: every variant then runs as the streaming kernel 1, and rover_get_info says so)
+    if (c->variant == 4 && c->map[0].K8 <= 256 && c->map[1].K8 <= 256 && !lane_tables_ok(c))
+        return fail(c, ROVER_E_STATE, "raycast_variant 4 (staged) was requested but its tables for ray_precision %d are not there (option "
                                       "staged_tables, or they did not fit when the maps were set)", c->precision);
     return ROVER_OK;
 }
@@ -1203,7 +1204,7 @@ int rover_generate_goals(rover_ctx* c, const int64_t* env_ids, int32_t n, const 
     if (n == 0) return ROVER_OK;
     USE_DEVICE(c);
     GoalArgs g{c->d_stones, (uint32_t)c->S, c->hf, c->sgrid, env_ids, 0, (uint32_t)n, nullptr, initial_pos3, target3, radius, draws,
-               max_draws, seed, (int32_t*)c->d_goal_work, n_draws_used};
+               max_draws, seed, nullptr, (int32_t*)c->d_goal_work, n_draws_used};
     HIP_TRY(c, launch_generate_goals(g, (uint32_t)n, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -1229,25 +1230,25 @@ int rover_reset_envs(rover_ctx* c, const rover_reset_io* io, void* stream) {
     a.ids = io->reset_ids; a.id_offset = c->cfg.env_offset; a.n_host = (uint32_t)io->n_reset_host; a.n_dev = io->n_reset_dev;
     a.initial_pos3 = io->initial_pos3; a.pos3 = io->pos3; a.quat4 = io->quat4; a.joint_pos13 = io->joint_pos13;
     a.joint_vel13 = io->joint_vel13; a.base_pos3 = io->base_pos3; a.reset = io->reset; a.progress = io->progress;
-    a.yaw_deg = io->yaw_deg; a.seed = io->seed;
+    a.yaw_deg = io->yaw_deg; a.seed = io->seed; a.seed_dev = io->seed_dev;
     const uint32_t n_max = io->n_reset_dev ? (uint32_t)c->cfg.num_envs : (uint32_t)io->n_reset_host;
     HIP_TRY(c, launch_reset_envs(a, n_max, s));
     if (io->target3) {
         GoalArgs g{c->d_stones, (uint32_t)c->S, c->hf, c->sgrid, io->reset_ids, (int64_t)c->cfg.env_offset, (uint32_t)io->n_reset_host,
                    io->n_reset_dev, io->initial_pos3, io->target3, io->radius > 0.f ? io->radius : 8.0f, io->draws,
-                   io->max_draws > 0 ? io->max_draws : 256, io->seed, (int32_t*)c->d_goal_work, io->n_draws_used};
+                   io->max_draws > 0 ? io->max_draws : 256, io->seed, io->seed_dev, (int32_t*)c->d_goal_work, io->n_draws_used};
         HIP_TRY(c, launch_generate_goals(g, n_max, s));
     }
     return ROVER_OK;
 }
 
 int rover_pre_physics_step(rover_ctx* c, const float* actions, const float* quat, float* lin_hist, float* ang_hist,
-                           float* euler_pre, float* pos_targets13, float* vel_targets13, void* stream) {
+                           float* euler_pre, float* pos_targets13, float* vel_targets13, float* actions_nn, void* stream) {
     if (!c) return ROVER_E_INVALID;
     if (!actions || !lin_hist || !ang_hist) return fail(c, ROVER_E_INVALID, "pre_physics_step: actions and both histories are required");
     if (euler_pre && !quat) return fail(c, ROVER_E_INVALID, "pre_physics_step: euler_pre needs quat");
     USE_DEVICE(c);
-    PrePhysicsArgs a{(uint32_t)c->cfg.num_envs, actions, quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13};
+    PrePhysicsArgs a{(uint32_t)c->cfg.num_envs, actions, quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13, actions_nn};
     HIP_TRY(c, launch_pre_physics(a, (hipStream_t)stream));
     return ROVER_OK;
 }
@@ -1530,7 +1531,7 @@ int rover_set_option(rover_ctx* c, const char* name, int64_t value) {
     USE_DEVICE(c);                                 // some options (re)allocate device workspace
     if (!strcmp(name, "raycast_variant")) {
         if (value < 0 || value > 4) return fail(c, ROVER_E_INVALID, "raycast_variant must be 0 (auto), 1 (env order), 2 (binned), 3 (culled) or 4 (staged)");
-        if (value == 4 && c->have_map[0] && c->have_map[1] && !lane_tables_ok(c))
+        if (value == 4 && c->have_map[0] && c->have_map[1] && c->map[0].K8 <= 256 && c->map[1].K8 <= 256 && !lane_tables_ok(c))
             return fail(c, ROVER_E_STATE, "raycast_variant 4 (staged) needs its tables for the arithmetic in force: they were not built (option "
                                           "staged_tables, or they did not fit when the maps were set)");
         c->variant = (int)value;

@@ -166,6 +166,7 @@ struct ResetArgs {
     int64_t *reset, *progress;
     const int32_t* yaw_deg;      // optional [n]
     uint64_t seed;
+    const uint64_t* seed_dev;    // optional [1]: added to seed on the device (a captured graph's step counter)
 };
 
 struct GoalArgs {
@@ -174,6 +175,7 @@ struct GoalArgs {
     uint32_t n_host; const int32_t* n_dev;
     const float* initial_pos3; float* target3; float radius;
     const float* draws; int32_t max_draws; uint64_t seed;
+    const uint64_t* seed_dev;    // optional [1]: added to seed on the device
     int32_t* t_acc;              // [n] scratch: iteration at which entry i was accepted (-1: id 0 from the start)
     int32_t* n_draws_used;
 };
@@ -182,6 +184,7 @@ struct PrePhysicsArgs {
     uint32_t E;
     const float *actions, *quat;
     float *lin_hist, *ang_hist, *euler_pre, *pos_targets13, *vel_targets13;
+    float* actions_nn;           // optional [E,2,3]: self.actions_nn (rover.py:366), newest first
 };
 
 struct LinearArgs {

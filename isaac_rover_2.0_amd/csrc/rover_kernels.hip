@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(256) goals_draw_kernel(GoalArgs a) {
         float x = 0.0f, y = 0.0f;
         if (active && t < a.max_draws) {
             // library RNG: keyed by the entry's GLOBAL env id, so that the shards of a multi-GPU run draw different streams
-            float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed, (uint32_t)t, (uint32_t)a.env_ids[i]);
+            float u = a.draws ? a.draws[(uint64_t)t * n + i] : philox_uniform(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), (uint32_t)t, (uint32_t)a.env_ids[i]);
             goal_from_draw(u, a.radius, a.initial_pos3, id, x, y);
             clear = !collides_grid(a.grid, a.info7, x, y, 1.0f);               // :539: redraw while nearest_rock <= 1.0
         }
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(1024) goals_env0_kernel(GoalArgs a) {
             bool clear = false;
             float cx = 0.0f, cy = 0.0f;
             if (t < a.max_draws) {
-                float u = a.draws ? a.draws[(uint64_t)t * n + src] : philox_uniform(a.seed, (uint32_t)t, (uint32_t)a.env_ids[src]);
+                float u = a.draws ? a.draws[(uint64_t)t * n + src] : philox_uniform(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), (uint32_t)t, (uint32_t)a.env_ids[src]);
                 goal_from_draw(u, a.radius, a.initial_pos3, 0, cx, cy);
                 clear = !collides_grid(a.grid, a.info7, cx, cy, 1.0f);
             }
@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(256) reset_envs_kernel(ResetArgs a) {
     if (i >= n) return;
     const int64_t id = a.ids[i] - a.id_offset;
     float deg = a.yaw_deg ? (float)a.yaw_deg[i]
-                          : floorf(philox_uniform(a.seed ^ 0x9E3779B97F4A7C15ull, 0u, (uint32_t)a.ids[i]) * 361.0f);   // global id
+                          : floorf(philox_uniform((a.seed + (a.seed_dev ? *a.seed_dev : 0ull)) ^ 0x9E3779B97F4A7C15ull, 0u, (uint32_t)a.ids[i]) * 361.0f);   // global id
     float half = (deg * (3.14159265358979323846f / 180.0f)) / 2.0f;
     a.quat4[4ull * id] = sinf(half); a.quat4[4ull * id + 1] = 0.0f; a.quat4[4ull * id + 2] = 0.0f; a.quat4[4ull * id + 3] = cosf(half);
 #pragma unroll
@@ -1042,6 +1042,11 @@ __global__ void __launch_bounds__(256) pre_physics_kernel(PrePhysicsArgs a) {
     a.lin_hist[3ull * e] = lin; a.lin_hist[3ull * e + 1] = l0; a.lin_hist[3ull * e + 2] = l1;
     float g0 = a.ang_hist[3ull * e], g1 = a.ang_hist[3ull * e + 1];
     a.ang_hist[3ull * e] = ang; a.ang_hist[3ull * e + 1] = g0; a.ang_hist[3ull * e + 2] = g1;
+    if (a.actions_nn) {                         // rover.py:366: cat((actions[:, :, None], actions_nn), 2)[:, :, 0:3]
+        float* n = a.actions_nn + 6ull * e;
+        const float n0 = n[0], n1 = n[1], n3 = n[3], n4 = n[4];
+        n[0] = lin; n[1] = n0; n[2] = n1; n[3] = ang; n[4] = n3; n[5] = n4;
+    }
     if (!a.pos_targets13 && !a.vel_targets13) return;
     // Ackermann, tasks/utils/kinematics.py:13-67 (same operation order as ackermann_kernel)
     const float wl[6][2] = {{-0.385, 0.438}, {0.385, 0.438}, {-0.447, 0.0}, {0.447, 0.0}, {-0.385, -0.411}, {0.385, -0.411}};

@@ -18,6 +18,10 @@ Deviations from the reference, all deliberate and tested:
   * ``reset_idx`` draws its yaw on the device RNG instead of Python's ``random`` (RNG streams cannot match).
   * ``pre_physics_step`` defaults to the device-side reset orchestration (``rover_reset_envs``): same state
     transitions as ``reset_idx`` + ``set_targets``, but the reset count never travels to the host.
+  * ``graph=True``: from global step 11 on (the curriculum switch of :344-353 is behind it) the launches of
+    ``pre_physics_step`` and of ``post_physics_step`` are each replayed from a captured hipGraph — same kernels, same
+    arguments, same results (``test_task_graph_replay_equals_eager``); the host then pays two graph launches per step
+    instead of ~14 kernel launches, which is what bounds small batches (the reference's default is 512 envs).
 """
 from __future__ import annotations
 
@@ -30,6 +34,15 @@ from ..config import SimConfig
 from ..views import RigidPrimView, RoverView
 from .base.rl_task import RLTask
 from .utils.heightmap_distribution import Heightmap
+
+
+_STEP_KEY = 0xD1B54A32D192ED03          # the global step's multiplier in the device RNG's key
+
+
+def _to_i64(x):
+    """x mod 2^64 as the int64 with the same bits (torch has no uint64 arithmetic)."""
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >= (1 << 63) else x
 
 
 class Memory:
@@ -88,7 +101,7 @@ class _RockDetector:
 class RoverTask(RLTask):
     def __init__(self, name, sim_config, env, offset=None, *, scene=None, distribution=None, fused=True,
                  device_reset=True, ray_precision="fp32", num_envs_global=None, env_offset=0, stone_mask_margin=None,
-                 cell_index_mode="cuda_rcp") -> None:
+                 cell_index_mode="cuda_rcp", graph=False) -> None:
         """``scene``: a ``synth.Scene`` (or ``assets.load_reference_assets(root)``) with the terrain / rocks KNN maps,
         stone list and heightfield the reference loads from disk (:92-94,:144,:210).  ``distribution``: optional
         (points [P,3] f64, sparse_idx, dense_idx); default = the reference's native 1634-point set.
@@ -136,12 +149,15 @@ class RoverTask(RLTask):
         self.linear_velocity = Memory(self._num_envs, 1, 3, self._device)                 # :154-155
         self.angular_velocity = Memory(self._num_envs, 1, 3, self._device)
         self.rew_scales = self._task_cfg["rewards"]                                       # :158
-        self.actions_nn = torch.zeros((self._num_envs, self._num_actions, 3), device=self._device)   # :183
+        self.actions_nn = torch.zeros((self._num_envs, self._num_actions, 3), device=self._device)   # :183 (the kernels keep it: :366)
         self.horizontal_scale = scene.horizontal_scale                                    # :212
         self.vertical_scale = scene.vertical_scale                                        # :213
         self.heightmap = scene.heightmap.to(self._device)                                 # :210
         self._fused = bool(fused)
         self._device_reset = bool(device_reset)
+        self._use_graph = bool(graph)
+        if self._use_graph and not (self._fused and self._device_reset):
+            raise ValueError("graph=True replays the fused, device-reset step: it needs fused=True and device_reset=True")
         RLTask.__init__(self, name, env)                                                  # :184
 
         dev_index = torch.device(self._device).index or 0
@@ -175,6 +191,12 @@ class RoverTask(RLTask):
         self._rover = None
         self._balls = None
         self._sin = self._sout = None
+        # graph replay (graph=True): the actions land in a persistent buffer, the step counter of the device RNG lives on the device
+        self._actions_buf = torch.zeros(e, self._num_actions, device=dev)
+        self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._pre_graph = self._post_graph = None
+        self._graph_level = self._graph_key = None
+        self._bound_key = self._bound_pre = self._bound_reset = None
 
     # ------------------------------------------------------------------------------------------------
     # scene / views (rover.py:196-230, 455-458) — USD is out of scope; views are host pose feeders
@@ -199,6 +221,7 @@ class RoverTask(RLTask):
         positions[:, 2] = height + self.position_z_offset                                 # :218
         self.initial_pos = positions
         self._rover.set_world_poses(self.initial_pos, self._rover.get_world_poses()[1])  # :220
+        self._balls._pos = self.target_positions       # the target balls ARE the goals (:584 moves them there): one tensor, no per-step copy
         self._bind()
 
     def _bind(self):
@@ -213,6 +236,7 @@ class RoverTask(RLTask):
                                   euler=self.rover_rotation, heading_diff=self.heading_diff,
                                   stone_collision=self.stone_collision, stone_margin=self._stone_margin or 0.0)
         self.rover_positions = pos
+        self._bound_key = None
 
     def reset(self):
         RLTask.reset(self)
@@ -246,7 +270,10 @@ class RoverTask(RLTask):
             return RLTask.post_physics_step(self)
         if self._is_playing():
             self.rover_positions = self._rover.get_world_poses()[0]
-            self._engine.step(self._sin, self._sout, increment_progress=True, compact=True)
+            if self._use_graph and self._post_graph is not None and self._graph_level == self.curriculum_level:
+                self._post_graph.replay()
+            else:
+                self._engine.step(self._sin, self._sout, increment_progress=True, compact=True)
             self._compaction_fresh = True
         else:
             self.progress_buf[:] += 1
@@ -277,20 +304,21 @@ class RoverTask(RLTask):
         if not self._compaction_fresh:
             self._engine.compact_resets(self.reset_buf, self.reset_env_ids_buf, self._n_reset)
         self._compaction_fresh = False
-        _actions = actions.to(self._device).float().contiguous()
-        self.actions_nn = torch.cat((torch.reshape(_actions, (self.num_envs, self._num_actions, 1)), self.actions_nn), 2)[:, :, 0:3]
         rv = self._rover
         if self._device_reset:
-            # euler_pre must see the PRE-reset orientation (:343 runs before :359), so this kernel goes first
-            self._engine.pre_physics_step(_actions, rv._quat, self.linear_velocity.tracker, self.angular_velocity.tracker,
-                                          euler_pre=self.rover_rot, pos_targets13=rv._joint_pos_targets,
-                                          vel_targets13=rv._joint_vel_targets)
-            self._engine.reset_envs(self.reset_env_ids_buf, self.initial_pos, rv._pos, rv._quat, self.reset_buf,
-                                    self.progress_buf, n_reset_dev=self._n_reset, joint_pos13=rv._joint_pos,
-                                    joint_vel13=rv._joint_vel, base_pos3=self.base_pos, yaw_deg=reset_yaw_deg,
-                                    target3=self.target_positions, radius=8.0, seed=self._rng_seed())
-            self._balls._pos.copy_(self.target_positions)                                        # :584 (visual only)
+            if self._use_graph and reset_yaw_deg is None and self.global_step > 10:
+                self._actions_buf.copy_(actions)            # (device, dtype and layout conversions included)
+                key = self._ptr_key(self._actions_buf, self._actions_nn_buf())
+                if self._pre_graph is None or self._graph_level != self.curriculum_level or self._graph_key != key:
+                    self._capture_graphs()
+                    self._graph_key = key
+                self._pre_graph.replay()
+                return
+            _actions = actions.to(self._device).float().contiguous()
+            self._launch_pre_physics(_actions, reset_yaw_deg, seed=self._rng_seed(), seed_dev=None)
             return
+        _actions = actions.to(self._device).float().contiguous()
+        self.actions_nn = torch.cat((torch.reshape(_actions, (self.num_envs, self._num_actions, 1)), self.actions_nn), 2)[:, :, 0:3]   # :366
         self._engine.quat_to_euler(rv.get_world_poses()[1], out=self.rover_rot)                  # :343
         n = int(self._n_reset.item())                      # the reference's len(reset_env_ids) is the same host sync
         if n > 0:
@@ -314,6 +342,61 @@ class RoverTask(RLTask):
         velocities[:, 5] = motor_velocities[:, 4]          # RL
         self._rover.set_joint_position_targets(positions, indices=None, joint_indices=self._rover.actuated_pos_indices)
         self._rover.set_joint_velocity_targets(velocities, indices=None, joint_indices=self._rover.actuated_vel_indices)
+
+    def _launch_pre_physics(self, _actions, reset_yaw_deg, seed, seed_dev):
+        """The device-reset form of :338-414 as launches on the current stream (eager, or while a graph is being captured)."""
+        rv = self._rover
+        ann = self._actions_nn_buf()
+        # The task's buffers persist: their checks and the argument structs are made once per (actions tensor, actions_nn tensor) and
+        # reused while the same tensors come back (a learner's action buffer usually does) — the per-call validation was a third of a
+        # 512-env step's host time.  Caller-supplied yaws (tests) and a captured graph's device seed take the plain path.
+        key = self._ptr_key(_actions, ann)
+        if reset_yaw_deg is None and seed_dev is None and self._bound_key == key:
+            self._bound_pre()
+            self._bound_reset(seed)
+        else:
+            # euler_pre must see the PRE-reset orientation (:343 runs before :359), so this kernel goes first
+            pre_kw = dict(euler_pre=self.rover_rot, pos_targets13=rv._joint_pos_targets, vel_targets13=rv._joint_vel_targets, actions_nn=ann)
+            reset_kw = dict(n_reset_dev=self._n_reset, joint_pos13=rv._joint_pos, joint_vel13=rv._joint_vel, base_pos3=self.base_pos,
+                            target3=self.target_positions, radius=8.0)
+            reset_args = (self.reset_env_ids_buf, self.initial_pos, rv._pos, rv._quat, self.reset_buf, self.progress_buf)
+            self._engine.pre_physics_step(_actions, rv._quat, self.linear_velocity.tracker, self.angular_velocity.tracker, **pre_kw)
+            self._engine.reset_envs(*reset_args, yaw_deg=reset_yaw_deg, seed=seed, seed_dev=seed_dev, **reset_kw)
+            if reset_yaw_deg is None and seed_dev is None:
+                self._bound_pre = self._engine.bind_pre_physics(_actions, rv._quat, self.linear_velocity.tracker,
+                                                                self.angular_velocity.tracker, **pre_kw)
+                self._bound_reset = self._engine.bind_reset_envs(*reset_args, **reset_kw)
+                self._bound_key = key
+        if self._balls._pos.data_ptr() != self.target_positions.data_ptr():                      # :584 (visual only)
+            self._balls._pos.copy_(self.target_positions)
+
+    def _ptr_key(self, _actions, ann):
+        """Addresses of every tensor a cached argument struct / captured graph holds that an assignment could have replaced since."""
+        rv = self._rover
+        return (_actions.data_ptr(), ann.data_ptr(), self.initial_pos.data_ptr(), self.base_pos.data_ptr(), self.reset_buf.data_ptr(),
+                self.progress_buf.data_ptr(), self.target_positions.data_ptr(), rv._pos.data_ptr(), rv._quat.data_ptr(),
+                rv._joint_pos.data_ptr())
+
+    def _actions_nn_buf(self):
+        """self.actions_nn as the contiguous float32 [E, 2, 3] device tensor the kernel shifts in place (a caller may have rebound it)."""
+        a = self.actions_nn
+        if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and tuple(a.shape) == (self._num_envs, self._num_actions, 3)):
+            a = self.actions_nn = a.to(self._device).float().contiguous()
+        return a
+
+    def _capture_graphs(self):
+        """Captures the two halves of a step as hipGraphs over the task's persistent tensors.  The device RNG's step counter is a
+        device word the captured graph advances itself (`_rng_seed` is additive in the step for that), so a replay draws what the
+        eager call of the same global step would."""
+        torch.cuda.synchronize()
+        self._seed_dev.fill_(_to_i64((self.global_step - 1) * _STEP_KEY))       # the captured add_ makes it this step's
+        pre, post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(pre):
+            self._seed_dev.add_(_to_i64(_STEP_KEY))
+            self._launch_pre_physics(self._actions_buf, None, seed=self._rng_seed(step=0), seed_dev=self._seed_dev)
+        with torch.cuda.graph(post):
+            self._engine.step(self._sin, self._sout, increment_progress=True, compact=True)
+        self._pre_graph, self._post_graph, self._graph_level = pre, post, self.curriculum_level
 
     def reset_idx(self, env_ids, yaw_deg=None):
         """rover.py:416-453.  The reference builds scipy's (x,y,z,w) quaternion of a rotation about x and feeds
@@ -345,11 +428,12 @@ class RoverTask(RLTask):
         self._engine.generate_goals(env_ids.long().contiguous(), self.initial_pos, self.target_positions, radius=radius,
                                     draws=draws, max_draws=256, seed=self._rng_seed())
 
-    def _rng_seed(self):
+    def _rng_seed(self, step=None):
         """Philox key of this step's device-side draws: (run seed, global step); the counter is the GLOBAL env id, so every
         shard of a multi-GPU run and every run seed draws its own stream (the reference's torch.rand / random follow the
-        run seed the same way)."""
-        return ((self._seed * 0x9E3779B97F4A7C15) ^ (self.global_step * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+        run seed the same way).  Additive in the step, so that a captured graph can keep the step part on the device."""
+        step = self.global_step if step is None else step
+        return (self._seed * 0x9E3779B97F4A7C15 + step * _STEP_KEY) & 0xFFFFFFFFFFFFFFFF
 
     def check_goal_collision(self, env_ids):
         """rover.py:533-542."""

@@ -250,3 +250,48 @@ def test_mlp_chain_forward_shapes_and_errors():
     with pytest.raises(_lib.RoverError, match="out must be"):
         eng.chain_forward(x, ok2, torch.empty(301, 34, device="cuda"))
     eng.close()
+
+
+def test_staged_tables_option_and_explicit_variant_4():
+    """"staged_tables": which proofs' tables of the staged ray cast rover_set_knn_map builds.  Without them the auto choice never picks
+    variant 4, asking for it by name is an error (never a silent change of kernel), and results do not change."""
+    from hip_helpers import hip_step
+    from isaac_rover_amd import _lib, synth
+    scene = synth.make_scene(n_cells=96, k=40, n_stones=16)
+    distn = synth.ray_distribution("37")
+    e = 1024                                          # 64 512 rays per step: the staged kernel's range in f32 arithmetic
+    st = synth.make_states(e, 9.6, seed=3)
+    outs = {}
+    for tables in (3, 0, 1, 2):
+        eng = _lib.Engine(e, device=0)
+        eng.set_option("staged_tables", tables)
+        eng.set_scene(scene, distn)
+        assert eng.info().raycast_variant == (4 if tables & 1 else 3), tables
+        outs[tables] = hip_step(eng, st)
+        if tables & 1:
+            eng.set_option("raycast_variant", 4)
+        else:
+            with pytest.raises(_lib.RoverError, match="staged"):
+                eng.set_option("raycast_variant", 4)
+        eng.set_option("raycast_variant", 0)
+        eng.set_option("ray_precision", 2)            # as shipped: needs the fp16 proof's tables
+        if tables & 2:
+            eng.set_option("raycast_variant", 4)
+            hip_step(eng, st)
+        else:
+            with pytest.raises(_lib.RoverError, match="staged"):
+                eng.set_option("raycast_variant", 4)
+        eng.close()
+    # a variant requested BEFORE the maps are set is checked when the step runs
+    eng = _lib.Engine(e, device=0)
+    eng.set_option("staged_tables", 0)
+    eng.set_option("raycast_variant", 4)
+    eng.set_scene(scene, distn)
+    with pytest.raises(_lib.RoverError, match="staged"):
+        hip_step(eng, st)
+    eng.close()
+    with pytest.raises(_lib.RoverError, match="staged_tables"):
+        _lib.Engine(8, device=0).set_option("staged_tables", 4)
+    for tables in (0, 1, 2):
+        for k in outs[3]:
+            np.testing.assert_array_equal(outs[3][k], outs[tables][k], err_msg=f"staged_tables {tables}: {k}")

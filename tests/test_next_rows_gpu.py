@@ -34,8 +34,10 @@ def test_pre_physics_step_matches_reference():
     euler = torch.full((e, 3), 7.0, device=dev)
     jpt = torch.full((e, 13), -5.0, device=dev)
     jvt = torch.full((e, 13), -6.0, device=dev)
-    eng.pre_physics_step(actions, quat, lin, ang, euler_pre=euler, pos_targets13=jpt, vel_targets13=jvt)
+    ann = torch.from_numpy(fx["in_actions_nn"]).to(dev).contiguous().clone()
+    eng.pre_physics_step(actions, quat, lin, ang, euler_pre=euler, pos_targets13=jpt, vel_targets13=jvt, actions_nn=ann)
     torch.cuda.synchronize()
+    np.testing.assert_array_equal(ann.cpu().numpy(), fx["out_actions_nn"])                           # :366 (bitwise, NaN included)
     np.testing.assert_allclose(euler.cpu().numpy(), fx["out_rover_rot"], rtol=1e-5, atol=1e-5)       # :343
     np.testing.assert_array_equal(lin.cpu().numpy(), fx["out_lin_tracker"])                         # :379-380 (bitwise, NaN included)
     np.testing.assert_array_equal(ang.cpu().numpy(), fx["out_ang_tracker"])

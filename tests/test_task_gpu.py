@@ -165,6 +165,61 @@ def test_device_reset_equals_host_reset():
             np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=k)
 
 
+def test_task_graph_replay_equals_eager():
+    """graph=True: from global step 11 on `pre_physics_step` and `post_physics_step` replay captured hipGraphs.  Two tasks — one eager, one
+    replaying — driven through VecEnv.step() by the same actions over the curriculum switch, a reset() in the middle and 60 steps leave
+    identical buffers at every step: obs, reward, done, progress, extras, poses, targets (the device RNG's step counter lives on the
+    device in graph mode and must draw what the eager call of the same step draws), histories, joint targets."""
+    from isaac_rover_amd import synth
+    from isaac_rover_amd.config import SimConfig
+    from isaac_rover_amd.vec_env import VecEnv, initialize_task
+    scene = synth.make_scene(n_cells=128, k=16, n_stones=24)
+    e = 192
+    envs, tasks = [], []
+    for graph in (False, True):
+        env = VecEnv(headless=True)
+        tasks.append(initialize_task(SimConfig(num_envs=e, device="cuda:0"), env, scene, distribution=synth.ray_distribution("37"),
+                                     graph=graph, stone_mask_margin=0.0))
+        envs.append(env)
+    obs = [env.reset() for env in envs]
+    g = torch.Generator().manual_seed(11)
+    n_resets, redrawn = 0, 0
+    for i in range(60):
+        actions = (2 * torch.rand(e, 2, generator=g) - 1).cuda()
+        if i == 30:
+            for t in tasks:
+                t.reset()                     # every env flagged: the next pre_physics_step re-spawns all of them
+        if i == 40:
+            for t in tasks:
+                t.progress_buf[::3] = 2995    # a third of the envs time out a few steps later (rover.py:614): partial resets
+        prev_target = tasks[1].target_positions.clone()
+        outs = [env.step(actions.clone()) for env in envs]
+        torch.cuda.synchronize()
+        a, b = tasks
+        for name in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "target_positions", "rover_rot", "rover_rotation", "heading_diff",
+                     "rock_collison", "stone_collision", "actions_nn", "reset_env_ids_buf", "_n_reset", "base_pos"):
+            x, y = getattr(a, name), getattr(b, name)
+            if name == "reset_env_ids_buf":
+                n = int(a._n_reset.item())
+                x, y = x[:n], y[:n]
+            assert torch.equal(x, y), f"step {i}: {name}"
+        for k in a.extras:
+            assert torch.equal(a.extras[k], b.extras[k]), f"step {i}: extras.{k}"
+        for x, y in zip(a._rover.get_world_poses() + (a._rover._joint_pos_targets, a._rover._joint_vel_targets, a.linear_velocity.tracker),
+                        b._rover.get_world_poses() + (b._rover._joint_pos_targets, b._rover._joint_vel_targets, b.linear_velocity.tracker)):
+            assert torch.equal(x, y), f"step {i}: rover state"
+        for x, y in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(x, y)
+        n_resets += int(a._n_reset.item())
+        if i > 12:
+            redrawn += int((b.target_positions != prev_target).any(dim=1).sum().item())
+    assert tasks[1]._pre_graph is not None and tasks[1]._post_graph is not None and tasks[0]._pre_graph is None
+    # the replayed graph did reset envs and draw new goals: all of them after reset(), then the timed-out third
+    assert n_resets >= e // 3 and redrawn >= e + e // 3 - 8, (n_resets, redrawn)
+    for env in envs:
+        env.close()
+
+
 def test_vec_env_rollout():
     """train.py-style loop: reset, then env.step(actions) for a while; curriculum flips at global step 10."""
     from isaac_rover_amd import synth
