@@ -956,6 +956,20 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 #define LN_PAD 5.0e-5                // added to a triangle's radius: what pays for the relative coordinates' rounding (header comment: >= 1e-6 would do)
 #define LN_AB 8u                     // pairs an item keeps in flight: test (A) only (a record per pair) ...
 #define LN_ABB 4u                    // ... tests (A) and (B) (two records per pair)
+// Test (B) of the f32 proof on 4-byte records ("B4", the second half of a cell's row: 8 B per pair instead of 16).  A record holds the
+// triangle's unit normal as three signed 10-bit integers n4 = round(511 n^) (bits 0-9, 10-19, 20-29), n^ the direction of the ctab record's
+// fp16 normal (within 5e-4 of N / |N|: fp16 components of a vector of length r / tau >= 1); the builder decodes its own code and keeps it only
+// if n4 / |n4| lies within LN_B4_ERR - 5e-4 of n^ and |n4| <= 512 — else, like slivers and overflows, the triangle is stored as n4 = 0, "always
+// a candidate".  A lane computes t = fl(n4 . d) (|t| <= 512 |d|, absolute error < 1e-4) and culls iff fl(t^2 - LN_B4_C) >= +0 with
+// LN_B4_C = (512 LN_B4_TAU)^2 (1 + 1e-4): then |n4 . d| >= LN_B4_TAU 512 (1 + 4e-5) >= LN_B4_TAU |n4|, i.e. the decoded unit normal — within
+// LN_B4_ERR of N / |N| — has |cos| > LN_B4_TAU, which is test (B) of the header comment with (tau, 1e-3) replaced by (LN_B4_TAU, LN_B4_ERR):
+// |N . d| / |N| > LN_B4_TAU - LN_B4_ERR.  n4 = 0 gives t = 0, u = -LN_B4_C < 0: a candidate.  (An empty slot decodes to a candidate too; its id
+// is CULL_NOID and the exact phase returns a miss for it: the row's last chunk only.)  The band of directions a triangle stays a candidate
+// for widens from 0.23 to 0.46 degrees about its plane: for a horizontal ray over 200 triangles one more exact evaluation in two rays.
+#define LN_B4_TAU 8.0e-3
+#define LN_B4_ERR 3.0e-3
+#define LN_B4_C ((float)((512.0 * LN_B4_TAU) * (512.0 * LN_B4_TAU) * 1.0001))
+static_assert(0.999 * (LN_B4_TAU - LN_B4_ERR) * CullK<0>::sigma > 2.0 * 1.0e-6 / 0.02, "f32 cull proof on B4 records: (B) must contradict (A)");
 #define LN_WAVES 5                   // waves per SIMD the kernel is compiled for (95 VGPRs, 7.4 KB LDS): 3 / 4 / 5 -> 317 / 253 / 235 us; 6 spills
 
 __device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v >= 0, finite or +inf)
@@ -1006,6 +1020,7 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
     __syncthreads();
     // the pair's record
     uint16_t hb[2][4], nb[2][4];
+    uint32_t b4[2] = {0u, 0u};                                                 // f32 proof: test (B)'s 4-byte records (0 = always a candidate)
     float G = __builtin_inff(), pz0 = __builtin_inff(), pz1 = -__builtin_inff(), pro = 0.0f, pq = 2.0f;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1040,6 +1055,16 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
             const float Fb = half ? 1.0f + (float)((rec[e].x & 63u) | ((rec[e].y & 63u) << 6)) * (1.0f / 512.0f) : 1.0f;
             nb[e][3] = half_bits_up(r2c * Fb * 1.000001f);
             pq = fminf(pq, nz_abs[id[e]]);                                     // |N_z| / |N| (rounded down) of the exact normal
+            if (!half) {    // B4: the normal's direction as 3 x 10 bits, kept only if it decodes to within the allowance of what was encoded
+                const double nx = (double)zn.y, ny = (double)w.x, nz = (double)w.y, nn = sqrt(nx * nx + ny * ny + nz * nz);
+                if (nn > 0.0 && nn < 1.0e30) {
+                    const int qx = (int)rint(nx / nn * 511.0), qy = (int)rint(ny / nn * 511.0), qz = (int)rint(nz / nn * 511.0);
+                    const double ql = sqrt((double)(qx * qx + qy * qy + qz * qz));
+                    const double ex = qx / ql - nx / nn, ey = qy / ql - ny / nn, ez = qz / ql - nz / nn;
+                    if (ql > 0.0 && ql <= 512.0 && sqrt(ex * ex + ey * ey + ez * ez) <= LN_B4_ERR - 5.0e-4 - 1.0e-6 && abs(qx) <= 511 && abs(qy) <= 511 && abs(qz) <= 511)
+                        b4[e] = ((uint32_t)qx & 0x3ffu) | (((uint32_t)qy & 0x3ffu) << 10) | (((uint32_t)qz & 0x3ffu) << 20);
+                }
+            }
         }
         if (r2b != 0x7c00u) {
             const float dxy = sqrtf((float)hx * (float)hx + (float)hy * (float)hy);
@@ -1059,8 +1084,9 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
     s_src[p] = (uint8_t)p;
     s_rec[p] = make_uint4((uint32_t)hb[0][0] | ((uint32_t)hb[0][1] << 16), (uint32_t)hb[0][2] | ((uint32_t)hb[0][3] << 16),
                           (uint32_t)hb[1][0] | ((uint32_t)hb[1][1] << 16), (uint32_t)hb[1][2] | ((uint32_t)hb[1][3] << 16));
-    s_nrec[p] = make_uint4((uint32_t)nb[0][0] | ((uint32_t)nb[0][1] << 16), (uint32_t)nb[0][2] | ((uint32_t)nb[0][3] << 16),
-                           (uint32_t)nb[1][0] | ((uint32_t)nb[1][1] << 16), (uint32_t)nb[1][2] | ((uint32_t)nb[1][3] << 16));
+    s_nrec[p] = half ? make_uint4((uint32_t)nb[0][0] | ((uint32_t)nb[0][1] << 16), (uint32_t)nb[0][2] | ((uint32_t)nb[0][3] << 16),
+                                  (uint32_t)nb[1][0] | ((uint32_t)nb[1][1] << 16), (uint32_t)nb[1][2] | ((uint32_t)nb[1][3] << 16))
+                     : make_uint4(b4[0], b4[1], 0u, 0u);
     s_id[p] = make_uint2(id[0] >= 0 ? (uint32_t)id[0] : CULL_NOID, id[1] >= 0 ? (uint32_t)id[1] : CULL_NOID);
     s_g[p] = G; s_z0[p] = pz0; s_z1[p] = pz1; s_ro[p] = pro; s_qn[p] = pq;
     __syncthreads();
@@ -1079,7 +1105,9 @@ __global__ void __launch_bounds__(128) lane_build_kernel(const int4* __restrict_
     if (p < pp) {       // a cell's row: the pp records of test (A), then the pp records of test (B)
         const uint32_t src = s_src[p];
         lrec[(uint64_t)cell * 2u * pp + p] = s_rec[src];
-        lrec[(uint64_t)cell * 2u * pp + pp + p] = s_nrec[src];
+        // test (B)'s records behind them: fp16 proof 16 B per pair {n, r2B} x 2; f32 proof 8 B per pair (B4 x 2: the row's last quarter stays unused)
+        if (half) lrec[(uint64_t)cell * 2u * pp + pp + p] = s_nrec[src];
+        else reinterpret_cast<uint2*>(lrec + (uint64_t)cell * 2u * pp + pp)[p] = make_uint2(s_nrec[src].x, s_nrec[src].y);
         lid[(uint64_t)cell * pp + p] = s_id[src];
     }
     // levels: the bound of the suffix behind the first 16 j pairs
@@ -1317,7 +1345,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
     const bool ab = act && tame && !cone;                     // off the cell's cone: the prefix runs tests (A) and (B)
     if (allc) L = nch;
     if (!act) L = 0u;
+#ifdef ROVER_DIAG_AB_MAXCH      // diagnostic builds only (wrong results, right timing): the (A) + (B) items of a ray stop after this many chunks
+    const uint32_t n_a = (act && !allc && !ab) ? L : 0u, n_b = ab ? min(L, (uint32_t)(ROVER_DIAG_AB_MAXCH)) : 0u;
+#else
     const uint32_t n_a = (act && !allc && !ab) ? L : 0u, n_b = ab ? L : 0u;
+#endif
     // (diagnostic of the library's own: ROVER_LANE_DIAG=1 prints where a wave's time goes — launch_raycast_lane)
     uint64_t tq = 0;
     uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1391,7 +1423,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
 #pragma unroll
                 for (uint32_t i = 0; i < NB; ++i) {
                     { const U4 v = cp[hf * NB + i]; rec[i] = make_uint4(v.x, v.y, v.z, v.w); }
-                    if (kAB) { const U4 v = cp[ppi + hf * NB + i]; nrc[i] = make_uint4(v.x, v.y, v.z, v.w); }
+                    if (kAB && H) { const U4 v = cp[ppi + hf * NB + i]; nrc[i] = make_uint4(v.x, v.y, v.z, v.w); }
+                }
+                if (kAB && !H) {      // B4 records, 8 B per pair: two pairs per 16-byte load (the pair's chunk starts ch * 64 bytes into the B4 rows)
+                    const GRow bp = (GRow)((uintptr_t)((uint64_t)__float_as_uint(rb.z) | ((uint64_t)__float_as_uint(rb.w) << 32))) + ppi + ch * (LN_CH / 2u);
+#pragma unroll
+                    for (uint32_t i = 0; i < NB; i += 2) {
+                        const U4 v = bp[(hf * NB + i) >> 1];
+                        nrc[i] = make_uint4(v.x, v.y, 0u, 0u); nrc[i + 1u] = make_uint4(v.z, v.w, 0u, 0u);
+                    }
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < NB; ++i) {
@@ -1413,7 +1453,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
                         u = __builtin_fmaf(-t, t, u);
                         sg |= __float_as_uint(u);
                     }
-                    if (kAB) {      // (B): (n . d)^2 - r2B >= +0 for both triangles, or the pair stays a candidate
+                    if (kAB && !H) {      // (B) on B4 records: (n4 . d)^2 - LN_B4_C >= +0 for both triangles, or the pair stays a candidate
+                        const uint4 n = nrc[i];
+                        auto b4t = [&](uint32_t c) {
+                            const float nx = (float)__builtin_amdgcn_sbfe((int)c, 0, 10), ny = (float)__builtin_amdgcn_sbfe((int)c, 10, 10),
+                                        nz = (float)__builtin_amdgcn_sbfe((int)c, 20, 10);
+                            float t = nx * ra.w; t = __builtin_fmaf(ny, rb.x, t); t = __builtin_fmaf(nz, rb.y, t);
+                            return __builtin_fmaf(t, t, -LN_B4_C);
+                        };
+                        sg |= __float_as_uint(b4t(n.x)) | __float_as_uint(b4t(n.y));
+                    } else if (kAB) {      // (B): (n . d)^2 - r2B >= +0 for both triangles, or the pair stays a candidate
                         const uint4 n = nrc[i];
                         float t0 = mix_mul<0>(n.x, ra.w); t0 = mix_fma<1>(n.x, rb.x, t0); t0 = mix_fma<0>(n.y, rb.y, t0);
                         float t1 = mix_mul<0>(n.z, ra.w); t1 = mix_fma<1>(n.z, rb.x, t1); t1 = mix_fma<0>(n.w, rb.y, t1);

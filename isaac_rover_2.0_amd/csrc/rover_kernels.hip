@@ -324,7 +324,11 @@ __global__ void __launch_bounds__(64 * PREP_SLOTS) prep_rays_kernel(PrepArgs a, 
         RayRec rec;
         rec.sx = rec.sy = rec.sz = 0.0f; rec.cell = 0u; rec.dx = rec.dy = 0.0f; rec.dz = 1.0f; rec.flags = 0u;
         uint32_t bin = 0xffffffffu;
+#ifdef ROVER_DIAG_SKIP_LO       // diagnostic builds only (wrong results, right timing): ray slots [LO, HI) are left out of the cast
+        const bool real = live && slot < n_real && !(slot >= (ROVER_DIAG_SKIP_LO) && slot < (ROVER_DIAG_SKIP_HI));
+#else
         const bool real = live && slot < n_real;
+#endif
         uint32_t kind = 0u;
         if (real) {
             float sx, sy, sz;                  // origin
