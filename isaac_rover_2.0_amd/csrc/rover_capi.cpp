@@ -834,7 +834,12 @@ static bool lane_env_order(const rover_ctx* c, int variant) {
            48ull * (uint64_t)c->cfg.num_envs < (uint64_t)c->cull_cells[0];
 }
 
-static bool lane_rocks_too(const rover_ctx* c) { return c->lane_rocks < 0 ? 2 * c->cull_farok[1] < c->cull_cells[1] : c->lane_rocks != 0; }
+// variant 4 behind the sort: the rocks part of the sorted list through the staged kernel too?  f32 arithmetic: yes (round 6: 4-byte test-(B)
+// records and test (A) by heading for the flat body rays — one launch 0.33 ms against 0.23 + 0.14).  As shipped: on an irregular rocks mesh only.
+static bool lane_rocks_too(const rover_ctx* c) {
+    if (c->lane_rocks >= 0) return c->lane_rocks != 0;
+    return c->precision != 2 || 2 * c->cull_farok[1] < c->cull_cells[1];
+}
 
 // the ray-cast launch(es) of a step for the variant in force, on the ray records / sorted list in the workspace
 static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
