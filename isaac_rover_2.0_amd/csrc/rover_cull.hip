@@ -956,6 +956,9 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 #define LN_PAD 5.0e-5                // added to a triangle's radius: what pays for the relative coordinates' rounding (header comment: >= 1e-6 would do)
 #define LN_AB 8u                     // pairs an item keeps in flight: test (A) only (a record per pair) ...
 #define LN_ABB 4u                    // ... tests (A) and (B) (two records per pair)
+#ifndef LN_ABB4
+#define LN_ABB4 4u                   // ... tests (A) and (B4) (f32 proof: 16 + 8 bytes per pair)
+#endif
 // Test (B) of the f32 proof on 4-byte records ("B4", the second half of a cell's row: 8 B per pair instead of 16).  A record holds the
 // triangle's unit normal as three signed 10-bit integers n4 = round(511 n^) (bits 0-9, 10-19, 20-29), n^ the direction of the ctab record's
 // fp16 normal (within 5e-4 of N / |N|: fp16 components of a vector of length r / tau >= 1); the builder decodes its own code and keeps it only
@@ -1266,6 +1269,17 @@ __device__ __forceinline__ void lane_exact(const RayRec* __restrict__ rays, cons
         uint32_t n_blocks, uint32_t split, uint32_t t8, uint32_t r8, uint32_t chsr, uint32_t run_r, float *__restrict__ out,                  \
         uint4 *__restrict__ stats, float k2_far, float c_a, uint32_t *__restrict__ diag
 
+#ifdef ROVER_DIAG_SORTED_RECS       // diagnostic builds only: the ray records copied into sorted order first (not timed with the kernel), read coalesced
+__device__ const RayRec* g_diag_recs = nullptr;
+__global__ void diag_gather_recs(const RayRec* __restrict__ rays, const uint32_t* __restrict__ sorted, uint32_t n, RayRec* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4* src = reinterpret_cast<const float4*>(rays + sorted[i]);
+    float4* dst = reinterpret_cast<float4*>(out + i);
+    dst[0] = src[0]; dst[1] = src[1];
+}
+#endif
+
 template <int H, int DIAG>
 __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bounds__(64) lane_scan_kernel(LANE_SCAN_ARGS) {
     __shared__ float4 s_ray[128];                         // per ray {s'x, s'y, s'z, dx}, {dy, dz, the cell's record row (64-bit address)}
@@ -1298,7 +1312,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
     // sorted == NULL: the ray slots in env order (small batches: a bin holds a ray or none, the sort's three launches buy nothing; a run is
     // then `run` consecutive slots — 16, 32 or 64: run_raycast —, padding slots — flags bit 1 clear — take no part)
     const uint32_t gid = sorted ? sorted[i0 + (in_run ? lane : n_run - 1u)] : i0 + (in_run ? lane : n_run - 1u);
-    const float4 rsa = reinterpret_cast<const float4*>(rays + gid)[0], rsb = reinterpret_cast<const float4*>(rays + gid)[1];
+#ifdef ROVER_DIAG_SORTED_RECS
+    const RayRec* const rrec = (sorted && g_diag_recs) ? g_diag_recs + (i0 + (in_run ? lane : n_run - 1u)) : rays + gid;
+#else
+    const RayRec* const rrec = rays + gid;
+#endif
+    const float4 rsa = reinterpret_cast<const float4*>(rrec)[0], rsb = reinterpret_cast<const float4*>(rrec)[1];
     const uint32_t cell = __float_as_uint(rsa.w), rflags = __float_as_uint(rsb.w), map = rflags & 1u;
     const bool act = in_run && (rflags & 2u) != 0u;
     const uint32_t pp = map ? pp01 >> 16 : pp01 & 0xffffu, nch = pp / LN_CH;
@@ -1416,7 +1435,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LN_WAVES, 8))) __launch_bound
             // (the (B) records of the row lie pp records behind the (A) records; pp by the map of the item's ray)
             const uint32_t ppi = kAB ? ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(rl << 2), (int)map) ? pp01 >> 16 : pp01 & 0xffffu) : 0u;
             uint32_t mask = 0;
-            constexpr uint32_t NB = kAB ? LN_ABB : LN_AB;            // records in flight per batch
+            constexpr uint32_t NB = kAB ? (H ? LN_ABB : LN_ABB4) : LN_AB;            // records in flight per batch
 #pragma unroll 1                                                // (one batch of LN_AB pairs at a time: with 16-pair chunks fully unrolled the compiler kept all in flight, 128 VGPRs and spills)
             for (uint32_t hf = 0; hf < LN_CH / NB; ++hf) {
                 uint4 rec[NB], nrc[kAB ? NB : 1u];
@@ -1716,6 +1735,14 @@ hipError_t launch_raycast_lane(LaneArgs a, hipStream_t s) {
         static const bool want_hist = atoi(getenv("ROVER_LANE_DIAG")) >= 2;      // the level histogram too
         if (want_hist) (void)hipMemsetAsync(d_diag + (size_t)waves * 8u + 39u, 1, 1, s);
     }
+#ifdef ROVER_DIAG_SORTED_RECS
+    if (a.sorted) {
+        static RayRec* d_recs = nullptr; static uint32_t cap = 0;
+        if (cap < a.n_sorted) { if (d_recs) (void)hipFree(d_recs); (void)hipMalloc((void**)&d_recs, (size_t)a.n_sorted * sizeof(RayRec)); cap = a.n_sorted;
+                                const RayRec* p = d_recs; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_recs), &p, sizeof p); }
+        hipLaunchKernelGGL(diag_gather_recs, dim3((a.n_sorted + 255u) / 256u), dim3(256), 0, s, a.rays, a.sorted, a.n_sorted, d_recs);
+    }
+#endif
     auto kern = a.half ? lane_scan_kernel<1, 0> : (want_diag && d_diag ? lane_scan_kernel<0, 1> : lane_scan_kernel<0, 0>);
     hipLaunchKernelGGL(kern, dim3((g.t8 + g.r8) * 8u * 4u), dim3(64), 0, s, a.rays, a.sorted,
                        a.n_sorted, a.lvl[0], a.lvl[1], a.lrec[0], a.lrec[1], a.lid[0], a.lid[1], reinterpret_cast<const RawTri*>(a.rtab[0]),
