@@ -381,13 +381,19 @@ def roofline(args, E, n_rays, prof, info, lib_version=""):
     else:
         head = {"bound": "hbm", "achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"]}
     head["stall_frac"] = stall
-    # (the staged kernel's plain and mixed / packed f32 instructions share the kind counters: its VALU figure is a bracket — the lower bound
-    #  prices every f32 instruction at the plain rate — and the verdict uses the bracket's middle)
-    v_est = valu_obj["frac"]
-    if v_est is not None and valu_obj.get("frac_lower_bound") is not None and info.raycast_variant == 4:
-        v_est = 0.5 * (v_est + valu_obj["frac_lower_bound"])
-    head["limited_by"] = (None if head["frac"] is None else
-                          ("hbm" if head["frac"] >= 0.7 else ("valu issue" if (v_est or 0) >= 0.7 else "latency (neither roof reached)")))
+    # `bound` names the roofline the contract asks for on this path (HBM: the north star's "rocprof HBM GB/s against the 8 TB/s roofline";
+    # there is no dense contraction, so never "mfma").  Which of the two measured resources lies nearer its roof is `nearest_roof`, from the
+    # HBM fraction and the VALU issue BRACKET [frac_lower_bound, frac] (the staged kernel's plain and mixed / packed f32 instructions share the
+    # kind counters: the lower end prices every f32 instruction at the plain rate) — reported as a bracket, no midpoint is taken.
+    v_hi, v_lo = valu_obj["frac"], valu_obj.get("frac_lower_bound")
+    head["valu_frac_bracket"] = None if v_hi is None else [v_lo if v_lo is not None else v_hi, v_hi]
+    if head["frac"] is None:
+        head["nearest_roof"] = head["limited_by"] = None
+    else:
+        lo = v_lo if v_lo is not None else (v_hi or 0.0)
+        head["nearest_roof"] = "hbm" if head["frac"] >= (v_hi or 0.0) else ("valu issue" if lo > head["frac"] else "hbm or valu issue (inside the bracket)")
+        top = max(head["frac"], v_hi or 0.0)
+        head["limited_by"] = head["nearest_roof"] if top >= 0.7 else "latency (neither roof reached)"
     head.update({"kernel": {4: "lane_scan_kernel", 3: "cull_scan_kernel", 2: "raycast_binned_kernel"}.get(info.raycast_variant, "raycast_kernel"),
                  "traffic": traffic, "avg_launch_ms": ray_ms, "launches": int(prof.launches), "launches_timed_every": int(getattr(args, "event_every", 1)), "rays_per_launch": rays,
                  "hbm": hbm, "valu": valu_obj, "algorithmic_bytes_per_launch": algo, "algorithmic_equiv_GBps": algo_gbs,
@@ -470,8 +476,8 @@ def compact_line(full, full_path=None):
     line["passes"] = {k: ps.get(k) for k in ("n", "min_ms_per_step", "max_ms_per_step")}
     line["passes"]["spread"] = _r(ps.get("spread"))
     line["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
-                                                   "stall_frac", "limited_by", "profile_key", "profile_stale")}
-    line["roofline"]["valu_frac"] = _r((rf.get("valu") or {}).get("frac"))
+                                                   "stall_frac", "limited_by", "nearest_roof", "profile_key", "profile_stale")}
+    line["roofline"]["valu_frac"] = [_r(x) for x in rf["valu_frac_bracket"]] if rf.get("valu_frac_bracket") else None
     line["roofline"]["algorithmic_equiv_GBps"] = _r(rf.get("algorithmic_equiv_GBps"))
     cb = full.get("cpu_baseline")
     if cb:

@@ -318,7 +318,7 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        ray_precision = 2 — 2 up to 24 576 rays per step; above that 4 in env order below 98 304 rays per step, 4 behind the sort on dense
  *        ray sets (ten or more heightmap rays per terrain cell; two or more on an irregular terrain mesh), 3 otherwise.
  * name = "lane_env_order" (variant 4): 1 = no sort, the ray slots in env order; 0 = rays sorted by (map, cell); -1 (default) = auto: env
- *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 48 cells (ray_precision
+ *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 64 cells (ray_precision
  *        2: below 98 304 rays per step).
  * name = "lane_rocks" (variant 4, sorted): 1 = the rock rays through the staged kernel too, 0 = through the culled one (3); -1 (default)
  *        = auto: 1 when fewer than half of the rocks map's cells have a usable far bound (an irregular rocks mesh).

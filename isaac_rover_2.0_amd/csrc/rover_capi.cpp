@@ -828,10 +828,12 @@ static bool lane_env_order(const rover_ctx* c, int variant) {
     // what decides is the heightmap rays per terrain cell (rovers spread over the map): below ~1.5 the sort buys no sharing (4 096 envs x 120
     // rays: 1.37, env order 35.3 against 30.9 M env-steps/s behind the sort; 16 384 x 37: 1.68, 67.1 / 80.1) — and the rovers per cell: from one per
     // 48 cells a cell's rays come from several rovers and only the sort brings them together (8 192 x 37: 57.8 / 59.3; 4 096 x 37: 49.2 / 41.1)
+    // (round 6, the rocks part in the staged launch too: behind the sort / env order 4 096 envs 48.9 / 49.9, 8 192 envs 68.6 / 58.3, 120 + 26 rays at
+    //  4 096 envs 35.3 / 36.4 — the sort pays from one rover per ~64 cells)
     // (as shipped the staged kernel is the auto choice for small batches in env order and for dense ray sets behind the sort: effective_variant)
     if (c->precision == 2) return c->have_dist && valid_rays(c) < ROVER_AUTO_LANE_ENV_RAYS_F16;
     return c->have_dist && 2ull * (uint64_t)c->cfg.num_envs * (uint64_t)c->P < 3ull * (uint64_t)c->cull_cells[0] &&
-           48ull * (uint64_t)c->cfg.num_envs < (uint64_t)c->cull_cells[0];
+           64ull * (uint64_t)c->cfg.num_envs < (uint64_t)c->cull_cells[0];
 }
 
 // variant 4 behind the sort: the rocks part of the sorted list through the staged kernel too?  f32 arithmetic: yes (round 6: 4-byte test-(B)

@@ -63,7 +63,8 @@ class StepGather:
             for k in range(n_shards):
                 self._views(buf, k)[2].fill_(1)              # done flags start at 1 (reset_buf, rl_task.py:105)
         self._pending = [None] * depth
-        # depth-1 interface (kept): the local views of set 0
+        self._flat = [None] * depth                          # flat_views(): allocated on first use, root only
+        # the local views of set 0 (what a single-set caller hands to the step)
         self.obs, self.rew, self.reset = self.local_views(0)
 
     def _views(self, buf, k):
@@ -90,6 +91,27 @@ class StepGather:
         rew = torch.as_strided(f, (n, e), (sb // 4, 1), storage_offset=e * w)
         done = torch.as_strided(buf, (n, e), (sb, 1), storage_offset=4 * e * w + 4 * e)
         return obs, rew, done
+
+    def flat_views(self, d: int = 0):
+        """The learner's batch of set ``d`` on the root (None elsewhere): obs f32 [N * E, W], rew f32 [N * E], done u8 [N * E] in global env
+        order (rank r's envs are rows [r * E, (r + 1) * E)); valid after ``wait(d)``.  With one rank these ARE the local views (no copy).  With
+        N > 1 a rank's three outputs travel as one packed message, so the shards' obs blocks are not adjacent in the receive buffer: this
+        accessor copies them into persistent flat tensors (three strided device copies: at 262 144 envs x 41 floats 43 MB, tens of
+        microseconds) — a learner that can index [rank, env] takes ``global_views`` and pays nothing."""
+        if not self.is_root:
+            return None
+        if self.world == 1:
+            return self.local_views(d)
+        og, rg, dg = self.global_views(d)
+        if self._flat[d] is None:
+            n = self.world * self.E
+            self._flat[d] = (torch.empty(n, self.W, dtype=torch.float32, device=og.device), torch.empty(n, dtype=torch.float32, device=og.device),
+                             torch.empty(n, dtype=torch.uint8, device=og.device))
+        fo, fr, fd = self._flat[d]
+        fo.view(self.world, self.E, self.W).copy_(og)
+        fr.view(self.world, self.E).copy_(rg)
+        fd.view(self.world, self.E).copy_(dg)
+        return fo, fr, fd
 
     def wait(self, d: int = 0):
         """Order the current stream behind the outstanding transfer of set ``d`` (no-op if there is none)."""

@@ -173,6 +173,8 @@ for step in range(5):
     g2.wait(d)
     if rank == 0 and step >= 2:                      # the learner reads step - 2 before the set is overwritten
         O, R, D = (t.reshape(E * world, *t.shape[2:]) for t in g2.global_views(d))
+        FO, FR, FD = g2.flat_views(d)                # the documented flat accessor: one batch in global env order
+        assert FO.shape == (E * world, W) and FO.is_contiguous() and torch.equal(FO, O) and torch.equal(FR, R) and torch.equal(FD, D)
         allids = torch.arange(E * world, dtype=torch.float32)
         assert torch.equal(O, allids[:, None] * 10 + torch.arange(W) + (step - 2))
         assert torch.equal(D.long(), (torch.arange(E * world) + step - 2) % 2)

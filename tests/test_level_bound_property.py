@@ -317,3 +317,80 @@ def test_test_a_constants_give_the_margin_the_proofs_use():
         wh = _edge_of_test_a(rng, c_a, c_rho, eta, 0.996, 1.004, 3000)
         assert wh >= eta, (eta, wh)
         assert wh < eta + 0.02
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: test (B) on 4-byte records (B4, rover_cull.hip: LN_B4_*)
+# ---------------------------------------------------------------------------------------------------------------------
+LN_B4_TAU, LN_B4_ERR = 8.0e-3, 3.0e-3
+LN_B4_C = f32((512.0 * LN_B4_TAU) * (512.0 * LN_B4_TAU) * 1.0001)
+
+
+def _b4_encode(n_fp16):
+    """lane_build_kernel: the ctab record's fp16 normal (any length) -> the three signed 10-bit integers, or None ("always a candidate")."""
+    n = n_fp16.astype(np.float64)
+    nn = math.sqrt(float(n @ n))
+    if not (0.0 < nn < 1.0e30):
+        return None
+    q = np.rint(n / nn * 511.0)
+    ql = math.sqrt(float(q @ q))
+    err = float(np.linalg.norm(q / ql - n / nn))
+    if ql <= 0.0 or ql > 512.0 or err > LN_B4_ERR - 5.0e-4 - 1.0e-6 or np.abs(q).max() > 511:
+        return None
+    return q.astype(np.int32)
+
+
+def _b4_culls(q, d):
+    """lane_scan_kernel's test on the decoded integers and the ray's direction, in float32: culled iff fl(t * t - C) >= +0."""
+    t = f32(q[0]) * f32(d[0])
+    t = f32(f32(q[1]) * f32(d[1]) + t)      # (the kernel's fma rounds once where this rounds twice: an ulp of |t| <= 512, covered below)
+    t = f32(f32(q[2]) * f32(d[2]) + t)
+    u = f32(t * t - LN_B4_C)
+    return not np.signbit(u)
+
+
+def test_b4_records_decode_within_their_allowance_and_cull_only_off_plane_rays():
+    """Test (B) on 4-byte records.  For random triangle normals — stored the way ctab_build_kernel stores them, as fp16 components of a vector of
+    length r / tau — the code lane_build_kernel keeps decodes to a direction within LN_B4_ERR of the TRUE unit normal, |n4| <= 512; and whenever
+    the kernel's float32 test culls a ray, the true normal has |cos(N, d)| > LN_B4_TAU - LN_B4_ERR, with the slack the proof's static_assert uses
+    (0.999 (LN_B4_TAU - LN_B4_ERR) sigma > 1e-4).  Rays are drawn near each triangle's plane, where the test decides, and at random."""
+    rng = np.random.default_rng(5)
+    n_codes = n_culled = n_kept_near = 0
+    worst_err, worst_cos = 0.0, 1.0
+    for _ in range(4000):
+        N = rng.normal(size=3)
+        if rng.random() < 0.3:
+            N[rng.integers(3)] *= 1.0e-3                       # normals near a coordinate plane / axis: where the quantisation is coarsest
+        N /= np.linalg.norm(N)
+        length = 10.0 ** rng.uniform(0.0, 3.0)                # |stored normal| = r / tau: 1 ... 1000
+        n16 = (N * length).astype(np.float16)
+        q = _b4_encode(n16)
+        if q is None:
+            continue
+        n_codes += 1
+        assert float(np.sqrt((q.astype(np.float64) ** 2).sum())) <= 512.0
+        err = float(np.linalg.norm(q / np.linalg.norm(q) - N))
+        worst_err = max(worst_err, err)
+        assert err <= LN_B4_ERR, err
+        # directions: in the triangle's plane tilted out of it by a small angle around the threshold, and anywhere
+        a = np.cross(N, rng.normal(size=3)); a /= np.linalg.norm(a)
+        for k in range(24):
+            if k < 16:
+                ang = rng.uniform(0.0, 2.5) * LN_B4_TAU * (1 if rng.random() < 0.5 else -1)
+                d = math.cos(ang) * a + math.sin(ang) * N
+            else:
+                d = rng.normal(size=3); d /= np.linalg.norm(d)
+            d = (d * rng.uniform(0.999995, 1.000005)).astype(np.float32)      # |d|^2 within 1e-5 of 1, as the proofs assume
+            cos_true = abs(float(N @ d.astype(np.float64))) / float(np.linalg.norm(d.astype(np.float64)))
+            if _b4_culls(q, d):
+                n_culled += 1
+                worst_cos = min(worst_cos, cos_true)
+                assert cos_true > LN_B4_TAU - LN_B4_ERR, (cos_true, q, d)
+            elif k < 16:
+                n_kept_near += 1
+    assert n_codes > 3500 and n_culled > 20000 and n_kept_near > 5000       # both outcomes were exercised near the threshold
+    assert 0.999 * (LN_B4_TAU - LN_B4_ERR) * 0.05 > 2.0 * 1.0e-6 / 0.02      # the static_assert of rover_cull.hip
+    print(f"B4: {n_codes} codes, worst decoded-normal error {worst_err:.2e} (allowance {LN_B4_ERR}), smallest |cos| of a culled ray {worst_cos:.2e} "
+          f"(needs > {LN_B4_TAU - LN_B4_ERR})")
+    # the "always a candidate" code: n4 = 0 gives u = -C < 0 for every direction
+    assert not _b4_culls(np.zeros(3, np.int32), np.array([0.3, -0.5, 0.8], np.float32))
