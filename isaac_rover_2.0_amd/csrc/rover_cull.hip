@@ -15,22 +15,30 @@
 //
 // ---- why a culled triangle is rejected by the reference (the proof behind phase 1) -----------------------------------
 // Per triangle the cull table holds a sphere centre m (any point) and, folded into the length of a scaled unit normal,
-// r2 >= 1.19 (rho + 1e-4)^2, where rho = max distance from m to the corners of the PADDED triangle
+// r2 >= 1.06 (rho + 1e-4)^2, where rho = max distance from m to the corners of the PADDED triangle
 // {a + n b + m c : n, m >= -0.101, n + m <= 1.101} (b = fl(v1 - a), c = fl(v0 - a) as ray_casting.py:35-36 computes them).
 // With h = s - m, W = distance from m to the ray's line, phase 1 culls iff
-//     (A)  0.995 |h|^2 - (h.d)^2 > r2          [ => W >= rho + 0.02 (|h| + 2 rho), rounding slack included ]
-//     (B)  |n_dec . d| > 4e-3                   [ n_dec = the stored fp16 unit normal, within 1e-3 of N / |N|, N = b x c ]
+//     (A)  0.99925 |h|^2 - (h.d)^2 > r2        [ => W >= rho + 0.005 (|h| + 2 rho), rounding slack included ]
+//     (B)  |n_dec . d| > 1.3e-2                 [ n_dec = the stored fp16 unit normal, within 1e-3 of N / |N|, N = b x c ]
 // and the triangle is no sliver (|N| >= 0.05 |b| |c|; slivers, overflows and NaNs are stored as "always a candidate").
 // The reference accepts iff fl(nn/det) >= -fp16(0.1), fl(mn/det) >= -fp16(0.1), fl(n + m) <= fp16(1.1)  (ray_casting.py:59),
 // i.e. the point a + (nn/det) b + (mn/det) c lies in the padded triangle, hence within rho of m.  Multiplying by det and
 // using the Cramer identity  nn* b + mn* c = det* g - kn* d  (exact triple products, g = s - a):
 //     |det*| W - err  <=  rho (|det*| + err'),   err, err' <= 1e-6 |b||c| (2|g| + rho)   [f32 rounding of nn, mn, det: 16 eps]
-// so with (A):  |det*| <= 2e-6 |b||c| / 0.02 = 1e-4 |b||c|.  But (B) and the sliver bound give
-// |det*| = |N . d| >= (4e-3 - 1e-3) * 0.05 |b||c| = 1.5e-4 |b||c|  — a contradiction: the reference rejects.
+// so with (A):  |det*| <= 2e-6 |b||c| / 0.005 = 4e-4 |b||c|.  But (B) and the sliver bound give
+// |det*| = |N . d| >= (1.3e-2 - 1e-3) * 0.05 |b||c| = 6e-4 |b||c|  — a contradiction: the reference rejects.
+// (err: the f32 rounding of the three triple products, each a sum of three products of a cross-product component — two products and a
+//  subtraction — with a component of d or g: <= 6 eps of the product of the three lengths, eps = 2^-24, against the 16 eps allowed here.)
+// (Rounds 2-5 ran (A) with the margin 0.02 (c_a = 0.995, c_rho = 1.19) against tau = 4e-3: the same factor 1.5 between the two sides.  Round 6
+//  quartered the margin and paid with tau: a steep ray's candidates are decided by (A) — its sphere about a 0.1 m grid triangle shrinks from
+//  0.116 to 0.098 m at |h| = 0.8 m, a quarter fewer pairs reach the exact arithmetic: one launch 338 -> 320 (margin 0.01) -> 308 us —, while (B)
+//  matters for rays within 0.75 degrees of a triangle's plane.  (A)'s constants: W^2 >= lambda1 |h|^2 + lambda2 rho^2 gives W >= a |h| + b rho
+//  for every a^2 / lambda1 + b^2 / lambda2 <= 1 (Cauchy-Schwarz); lambda1 = 1 - c_a / |d|^2 - 3e-6 >= 0.000737, lambda2 = 1.05999, b = 1.0102:
+//  a = 0.00524 >= 0.005 — the static_assert below.)
 // NaN / inf anywhere makes (A) or (B) compare false, i.e. keeps the triangle a candidate.  DESIGN.md §5 has the long form.
 // (B) for a whole cell at once: with q = min over the cell's triangles of |N_z| / |N| (0 if any is a sliver) and beta the
-// ray's angle from the vertical, every triangle has |N . d| / |N| >= cos(acos q + beta), which exceeds 3.5e-3 iff
-// q > 3.5e-3 |d_z| + sqrt(1 - 3.5e-3^2) |d_xy|.  prep_rays_kernel stores the right-hand side (rounded up to 16 bits) in the
+// ray's angle from the vertical, every triangle has |N . d| / |N| >= cos(acos q + beta), which exceeds 1.25e-2 iff
+// q > 1.25e-2 |d_z| + sqrt(1 - 1.25e-2^2) |d_xy| (ROVER_CONE_TAU: 1.25e-2 x sigma = 6.25e-4 against (A)'s 4e-4).  prep_rays_kernel stores the right-hand side (rounded up to 16 bits) in the
 // ray record, the id row carries q (rounded down): where q wins, phase 1 runs test (A) only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,8 +57,9 @@ namespace rover {
 // |b x c| < sigma |b||c| (or |b||c| < min_bc) is stored as "always a candidate".
 template <int H> struct CullK;
 template <> struct CullK<0> {
-    static constexpr double pad = 0.101, c_rho = 1.19, tau = 4.0e-3, sigma = 0.05, min_bc = 0.0;
-    static constexpr float c_a = 0.995f, tau2 = 1.6e-5f;
+    static constexpr double pad = 0.101, c_rho = 1.06, tau = 1.3e-2, sigma = 0.05, min_bc = 0.0;
+    static constexpr double alpha = 0.005;                   // (A)'s margin: W >= rho + alpha (|h| + 2 rho)
+    static constexpr float c_a = 0.99925f, tau2 = 1.6901e-4f;
 };
 // ---- as-shipped fp16 arithmetic (ray_casting.py:31-59 on Half tensors; u = 2^-11) ------------------------------------------
 // The exact phase then works on b = fl16(v1 - a), c = fl16(v0 - a), g' = fl16(s - a) (|g' - g| <= sqrt(3) u |g|: the ray as if
@@ -96,7 +105,13 @@ CullProofH cull_proof_h(double eta) {
     k.tau2 = (float)(k.kappa * k.kappa);
     return k;
 }
-static_assert(0.999 * (CullK<0>::tau - 1.0e-3) * CullK<0>::sigma > 2.0 * 1.0e-6 / 0.02, "f32 cull proof: (B) must contradict (A)");
+static_assert(0.999 * (CullK<0>::tau - 1.0e-3) * CullK<0>::sigma > 1.45 * 2.0 * 1.0e-6 / CullK<0>::alpha, "f32 cull proof: (B) must contradict (A), with the factor 1.5 of rounds 2-5");
+static_assert((double)CullK<0>::tau2 >= CullK<0>::tau * CullK<0>::tau && (double)CullK<0>::tau2 < 1.001 * CullK<0>::tau * CullK<0>::tau, "tau2 = tau^2");
+static_assert(ROVER_CONE_TAU * CullK<0>::sigma > 1.45 * 2.0 * 1.0e-6 / CullK<0>::alpha, "f32 cull proof: the set cone's (B) must contradict (A)");
+// (A) gives the margin alpha: lambda1 = 1 - c_a / 0.99999 - 3e-6, lambda2 = c_rho 0.99999 (1 - 3e-7), b = 1 + 2 alpha + 2e-4 (what the staged
+// kernel's relative records need on top): a^2 = lambda1 (1 - b^2 / lambda2) >= (1.04 alpha)^2
+static_assert((1.0 - (double)CullK<0>::c_a / 0.99999 - 3.0e-6) * (1.0 - (1.0 + 2.0 * CullK<0>::alpha + 2.0e-4) * (1.0 + 2.0 * CullK<0>::alpha + 2.0e-4) / (CullK<0>::c_rho * 0.99999 * (1.0 - 3.0e-7)))
+              >= (1.04 * CullK<0>::alpha) * (1.04 * CullK<0>::alpha), "f32 cull proof: test (A)'s constants must give W >= rho + alpha (|h| + 2 rho)");
 #define CULL_RUNMAX 64               // sorted rays per wave (one result slot per lane)
 #define CULL_RING   2                // id rows (one bin each) in flight per wave: global -> LDS loads issued this many bins ahead
 
@@ -931,14 +946,14 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // to cull_scan_kernel instead (rover_capi.cpp, run_raycast).  Measured history: EXPERIMENTS.md 8.2, 8.2b.
 //
 // Test (A) on these records.  A pair record holds, per triangle, m' = fp16(m - C) (m: ctab's sphere centre, C = (cell centre, z_c) in
-// f32) and r2' (fp16, rounded up) >= 1.19 (rho~ + e + p)^2 (p = LN_PAD = 5e-5) with rho~ >= the radius of the padded triangle about m (from ctab's own r2)
+// f32) and r2' (fp16, rounded up) >= c_rho (rho~ + e + p)^2 (c_rho = 1.06, p = LN_PAD = 5e-5) with rho~ >= the radius of the padded triangle about m (from ctab's own r2)
 // and e = |C + m' - m| the encoding's displacement, computed in double from the decoded values: the sphere about M = C + m' of radius
 // rho' = rho~ + e contains the padded triangle.  A lane computes s' = fl(s - C), h^ = fl(s' - m') (each component within 2.4e-7 |h| +
 // 5e-7 of the true h = s - M: two roundings of magnitudes <= |h| + |m'|, |m'| <= 4 m enforced by the builder), q = |h^|^2, t = h^ . d,
-// u = fl(fl(0.995 q - r2') - t^2) and culls iff u >= +0.  Rounding of q, t, u moves the inequality by < 3e-6 |h^|^2 + 3e-7 r2', so
-// u >= 0 gives W^ ^2 >= 0.004997 |h^|^2 + 1.19 (1 - 3e-7) (rho' + p)^2 for the distance W^ from M to the line through M + h^; by
-// Cauchy-Schwarz W^ >= 0.02126 |h^| + 1.0404 (rho' + p), and the true line is within |h - h^| <= 4.2e-7 |h| + 8.7e-7 of that one:
-// W >= 0.02125 |h| + 1.0404 rho' + 1.04 p - 9e-7 > rho' + 0.02 (|h| + 2 rho') for every p >= 1e-6, which is all the rejection proof at the
+// u = fl(fl(c_a q - r2') - t^2) (c_a = 0.99925) and culls iff u >= +0.  Rounding of q, t, u moves the inequality by < 3e-6 |h^|^2 + 3e-7 r2', so
+// u >= 0 gives W^ ^2 >= 0.000737 |h^|^2 + 1.05999 (rho' + p)^2 (|d|^2 within 1e-5 of 1) for the distance W^ from M to the line through M + h^; by
+// Cauchy-Schwarz W^ >= 0.00524 |h^| + 1.0102 (rho' + p), and the true line is within |h - h^| <= 4.2e-7 |h| + 8.7e-7 of that one:
+// W >= 0.00523 |h| + 1.0102 rho' + 1.01 p - 9e-7 > rho' + 0.005 (|h| + 2 rho') for every p >= 1e-6, which is all the rejection proof at the
 // top of this file uses of test (A).  (p = 1e-3 cost a tenth more candidates: 3.95 pairs per ray against 3.6 with 5e-5.)
 // Rays with a non-finite or far-away origin (|s'| >= 1e4: nothing overflows below that) are the wild rays: every pair a candidate.
 // ---------------------------------------------------------------------------------------------------
@@ -968,11 +983,11 @@ __global__ void __launch_bounds__(64 * CULL_WPB) cull_scan_kernel(CULL_SCAN_ARGS
 // LN_B4_ERR of N / |N| — has |cos| > LN_B4_TAU, which is test (B) of the header comment with (tau, 1e-3) replaced by (LN_B4_TAU, LN_B4_ERR):
 // |N . d| / |N| > LN_B4_TAU - LN_B4_ERR.  n4 = 0 gives t = 0, u = -LN_B4_C < 0: a candidate.  (An empty slot decodes to a candidate too; its id
 // is CULL_NOID and the exact phase returns a miss for it: the row's last chunk only.)  The band of directions a triangle stays a candidate
-// for widens from 0.23 to 0.46 degrees about its plane: for a horizontal ray over 200 triangles one more exact evaluation in two rays.
-#define LN_B4_TAU 8.0e-3
+// for is 0.89 degrees about its plane (0.75 with the 8-byte records): for a horizontal ray over 200 triangles two exact evaluations by orientation instead of one and a half.
+#define LN_B4_TAU 1.55e-2
 #define LN_B4_ERR 3.0e-3
 #define LN_B4_C ((float)((512.0 * LN_B4_TAU) * (512.0 * LN_B4_TAU) * 1.0001))
-static_assert(0.999 * (LN_B4_TAU - LN_B4_ERR) * CullK<0>::sigma > 2.0 * 1.0e-6 / 0.02, "f32 cull proof on B4 records: (B) must contradict (A)");
+static_assert(0.999 * (LN_B4_TAU - LN_B4_ERR) * CullK<0>::sigma > 1.45 * 2.0 * 1.0e-6 / CullK<0>::alpha, "f32 cull proof on B4 records: (B) must contradict (A)");
 #define LN_WAVES 5                   // waves per SIMD the kernel is compiled for (95 VGPRs, 7.4 KB LDS): 3 / 4 / 5 -> 317 / 253 / 235 us; 6 spills
 
 __device__ __forceinline__ uint16_t half_bits_up(float v) {      // fp16 >= v (v >= 0, finite or +inf)

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Test (B) for a whole set of triangles by its normal cone (rover_cull.hip, header comment): the ray-side constant of the f32 proof.
+#define ROVER_CONE_TAU 1.25e-2
+
 namespace rover {
 
 // One ray as the ray-cast kernel consumes it (32 B, two 16-byte loads).

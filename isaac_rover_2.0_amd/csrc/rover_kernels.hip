@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t cell_coord(float v, float shift, float cell,
 }
 
 // The ray's normal-cone bound for the culled ray cast (rover_cull.hip), a 16-bit fraction rounded up, 0xffff = none; (dx, dy, dz) = the
-// ray record's direction.  f32 proof: a cell whose triangles all have |N_z| / |N| above 3.5e-3 |d_z| + |d_xy| meets test (B) as a whole.
+// ray record's direction.  f32 proof: a cell whose triangles all have |N_z| / |N| above ROVER_CONE_TAU |d_z| + |d_xy| meets test (B) as a whole.
 // As-shipped fp16 arithmetic (precision 2): (B)'s threshold is per triangle, the cell stores the largest angle from the vertical a ray
 // may have (as a fraction of pi / 2) and the ray its angle beta (d is normalised in fp16 there: re-normalised here).
 __device__ __forceinline__ uint32_t ray_cone_bound(float dx, float dy, float dz, int precision) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t ray_cone_bound(float dx, float dy, float dz,
         const float beta = acosf(fminf(1.0f, fabsf(dz) * inv)) * 0.63661977f + 4.0e-5f;      // / (pi / 2), rounded up
         if (beta < 0.9999f) qq = (uint32_t)ceilf(beta * 65535.0f);                            // NaN -> 0xffff
     } else {
-        const float qm = 3.5e-3f * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
+        const float qm = (float)ROVER_CONE_TAU * fabsf(dz) + sqrtf(dx * dx + dy * dy) + 2.0e-5f;
         if (qm < 0.9999f) qq = (uint32_t)ceilf(qm * 65535.0f);                                // NaN -> 0xffff
     }
     return qq;

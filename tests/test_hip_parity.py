@@ -651,7 +651,7 @@ def test_rays_that_clear_their_cell_are_not_scanned():
 
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto), f32 arithmetic: the env-order kernel below 24 576 rays per step, the staged kernel (4) from there on —
-    in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays and 48 cells or more hold one rover —; as shipped: the binned kernel up to 24 576 rays,
+    in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays and more than 64 cells hold one rover —; as shipped: the binned kernel up to 24 576 rays,
     above that the staged kernel in env order below 98 304 rays and behind the sort on dense ray sets (ten or more heightmap rays per terrain
     cell), the culled one otherwise; K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
@@ -669,9 +669,9 @@ def test_auto_variant_and_run_selection():
         assert mid.info().raycast_variant == want16, n
         assert mid.info().raycast_sorted == 0 or want16 != 4, n           # (as shipped, small batches: the staged kernel in env order)
         mid.close()
-    # the staged kernel without the sort: fewer than 1.5 heightmap rays per terrain cell AND fewer than one rover per 48 cells
+    # the staged kernel without the sort: fewer than 1.5 heightmap rays per terrain cell AND fewer than one rover per 64 cells
     wide = synth.make_scene(n_cells=160, k=16, n_stones=8)
-    for n, want_sorted in ((400, 0), (1024, 1)):            # 25 600 cells: 64 / 25 cells per rover
+    for n, want_sorted in ((392, 0), (400, 1), (1024, 1)):  # 25 600 cells: 65.3 / 64 / 25 cells per rover
         e = make_engine(wide, distn, n, variant=None)
         assert e.info().raycast_variant == 4 and e.info().raycast_sorted == want_sorted, n
         e.close()

@@ -16,10 +16,13 @@ import math
 import numpy as np
 
 f32 = np.float32
-C_A = f32(0.995)                       # CullK<0>::c_a
+C_A = f32(0.99925)                      # CullK<0>::c_a
+C_RHO = 1.06                           # CullK<0>::c_rho
+ALPHA = 0.005                          # CullK<0>::alpha: test (A) must give W >= rho + ALPHA (|h| + 2 rho)
+CONE_TAU = 1.25e-2                     # ROVER_CONE_TAU
 
 
-def _far_consts(c_a=0.995, dd=1.00001):
+def _far_consts(c_a=0.99925, dd=1.00001):
     """cull_far_consts (rover_cull.hip)."""
     ca = c_a - 1.0e-5
     k1 = f32(1.00001 / (0.9 * math.sqrt(ca)))
@@ -102,7 +105,7 @@ def _records(D, ang, spread, hz, r):
     if dist.max() > 3.9:
         return None
     hx = np.float16(dist * np.cos(ang)); hy = np.float16(dist * np.sin(ang)); hzh = np.float16(hz)
-    r2h = np.array([_h_up(f32(1.19) * f32(x) * f32(x)) for x in r], dtype=np.float16)
+    r2h = np.array([_h_up(f32(C_RHO) * f32(x) * f32(x)) for x in r], dtype=np.float16)
     return hx, hy, hzh, r2h
 
 
@@ -147,20 +150,20 @@ def test_a_ray_that_is_not_steep_clears_nothing():
 
 # ---------------------------------------------------------------------------------------------------
 # Test (A) on the row's cell-relative fp16 records: u >= +0 as lane_scan_kernel computes it must give what
-# the rejection proof uses of test (A): W >= rho + 0.02 (|h| + 2 rho) for the TRUE sphere (centre m, padded radius rho) and the true ray.
+# the rejection proof uses of test (A): W >= rho + ALPHA (|h| + 2 rho) for the TRUE sphere (centre m, padded radius rho) and the true ray.
 # ---------------------------------------------------------------------------------------------------
 def _fma32(a, b, c):
     return f32(np.float64(a) * np.float64(b) + np.float64(c))          # one rounding (the products of two f32 are exact in f64)
 
 
 def _record_of(m, C, rho_true):
-    """lane_build_kernel's (A) record of a triangle whose ctab entry has centre m and r2 = 1.19 (rho + 1e-4)^2: m' (fp16), r2' (fp16)."""
-    r2c = f32(1.19 * (rho_true + 1.0e-4) ** 2 * (1.0 + 1.0e-6))
+    """lane_build_kernel's (A) record of a triangle whose ctab entry has centre m and r2 = C_RHO (rho + 1e-4)^2: m' (fp16), r2' (fp16)."""
+    r2c = f32(C_RHO * (rho_true + 1.0e-4) ** 2 * (1.0 + 1.0e-6))
     rel = (np.asarray(m, dtype=np.float64) - np.asarray(C, dtype=np.float64)).astype(f32)
     mh = rel.astype(np.float16)
     enc = float(np.linalg.norm(np.asarray(C, dtype=np.float64) + mh.astype(np.float64) - np.asarray(m, dtype=np.float64)))
-    rho = math.sqrt(float(r2c) / 1.19)
-    need = 1.19 * (rho + enc + 5.0e-5) ** 2 * 1.000001
+    rho = math.sqrt(float(r2c) / C_RHO)
+    need = C_RHO * (rho + enc + 5.0e-5) ** 2 * 1.000001
     r2h = _h_up(f32(need * 1.0000001))
     if float(r2h) < 2.0 ** -14:
         r2h = np.float16(2.0 ** -14)
@@ -208,7 +211,7 @@ def test_test_a_on_cell_relative_fp16_records_implies_the_proofs_premise():
         s = origin(hi).astype(np.float64)
         h = s - m
         W = float(np.linalg.norm(h - (h @ dhat) * dhat))
-        need = rho + 0.02 * (float(np.linalg.norm(h)) + 2.0 * rho)
+        need = rho + ALPHA * (float(np.linalg.norm(h)) + 2.0 * rho)
         assert W >= need, f"u >= 0 at W = {W}, the proof needs {need} (rho {rho}, |h| {np.linalg.norm(h)})"
         tightest = min(tightest, W / need)
         checked += 1
@@ -217,14 +220,14 @@ def test_test_a_on_cell_relative_fp16_records_implies_the_proofs_premise():
 
 
 # ---------------------------------------------------------------------------------------------------
-# Test (B) for a whole set (last sentence): the ray record carries qm = 3.5e-3 |d_z| + |d_xy| (+ 2e-5, rounded UP to 16
+# Test (B) for a whole set (last sentence): the ray record carries qm = CONE_TAU |d_z| + |d_xy| (+ 2e-5, rounded UP to 16
 # bits: ray_cone_bound, rover_kernels.hip), a cell or a suffix q = min |N_z| / |N| over its triangles (rounded DOWN to 16 bits:
-# lane_build_kernel / idx4_build_kernel).  q16 >= rq must give |N . d| > 3.4e-3 |N| for every triangle of the set (3.5e-3 for an exactly unit
+# lane_build_kernel / idx4_build_kernel).  q16 >= rq must give |N . d| > (CONE_TAU - 1e-4) |N| for every triangle of the set (CONE_TAU for an exactly unit
 # d) — more than the 3e-3 that (B) with the stored normal's 1e-3 error needs.
 # ---------------------------------------------------------------------------------------------------
 def _ray_q16(d):
     dx, dy, dz = (f32(x) for x in d)
-    qm = f32(3.5e-3) * abs(dz) + np.sqrt(dx * dx + dy * dy, dtype=f32) + f32(2.0e-5)
+    qm = f32(CONE_TAU) * abs(dz) + np.sqrt(dx * dx + dy * dy, dtype=f32) + f32(2.0e-5)
     return 0xffff if not qm < f32(0.9999) else int(math.ceil(float(qm * f32(65535.0))))
 
 
@@ -241,7 +244,7 @@ def test_a_set_cone_that_covers_the_ray_gives_test_b_for_every_triangle():
         tilt = rng.uniform(0.0, 1.3) * rng.choice([1.0, 0.3])
         az = rng.uniform(0.0, 2.0 * math.pi)
         # (a record's direction is -normalize() in f32, or checked by rover_cast_rays: |d|^2 within 1e-5 of 1.  The bound leans on that: at a
-        #  tilt of 1.3 rad a direction 0.1 % short would leave 1e-5 of the 3.5e-3)
+        #  tilt of 1.3 rad a direction 0.1 % short would leave 1e-5 of the threshold)
         d = (np.array([math.sin(tilt) * math.cos(az), math.sin(tilt) * math.sin(az), -math.cos(tilt)]) * rng.uniform(1.0 - 4.0e-6, 1.0 + 4.0e-6)).astype(f32)
         rq = _ray_q16(d)
         # the set's cone JUST covers the ray; its triangles' normals lie anywhere on or inside that cone, worst azimuth included
@@ -257,7 +260,7 @@ def test_a_set_cone_that_covers_the_ray_gives_test_b_for_every_triangle():
         assert _set_q16(qn_min) <= q16
         dd = d.astype(np.float64)
         c = np.abs(N @ dd)                                   # |N| = 1
-        assert (c > 3.4e-3).all(), f"cone {q16} >= ray bound {rq}, but |N.d| / |N| = {c.min()}"
+        assert (c > CONE_TAU - 1.0e-4).all(), f"cone {q16} >= ray bound {rq}, but |N.d| / |N| = {c.min()}"
         tightest = min(tightest, float(c.min()))
         covered += 1
     assert covered > 2000
@@ -266,7 +269,7 @@ def test_a_set_cone_that_covers_the_ray_gives_test_b_for_every_triangle():
 
 # ---------------------------------------------------------------------------------------------------
 # The constants of test (A) themselves (rover_cull.hip: CullK<0>, cull_proof_h): c_a |h|^2 - (h.d)^2 > c_rho rho^2 has to
-# give W - rho >= eta (|h| + 2 rho) — f32 proof: c_a = 0.995, c_rho = 1.19, eta = 0.02, |d|^2 <= 1.00001; as-shipped fp16 proof: c_a, c_rho
+# give W - rho >= eta (|h| + 2 rho) — f32 proof: c_a = 0.9984, c_rho = 1.12, eta = ALPHA = 0.005(rounds 2-5: 0.995, 1.19, 0.02), |d|^2 <= 1.00001; as-shipped fp16 proof: c_a, c_rho
 # derived from eta by cull_proof_h, |d|^2 within 4e-3 of 1 (the direction is normalised in fp16).
 # ---------------------------------------------------------------------------------------------------
 def _proof_h(eta):
@@ -309,8 +312,8 @@ def _edge_of_test_a(rng, c_a, c_rho, eta, dd_lo, dd_hi, n):
 
 def test_test_a_constants_give_the_margin_the_proofs_use():
     rng = np.random.default_rng(11)
-    w32 = _edge_of_test_a(rng, 0.995, 1.19, 0.02, 0.99999, 1.00001, 3000)
-    assert w32 >= 0.02, w32
+    w32 = _edge_of_test_a(rng, float(C_A), C_RHO, ALPHA, 0.99999, 1.00001, 3000)
+    assert w32 >= ALPHA, w32
     assert w32 < 0.03                                            # ... and not much more: the constants are not wasteful
     for eta in (0.04, 0.06, 0.10):                               # 0.06: the library's choice (cull_eta_h)
         c_a, c_rho = _proof_h(eta)
@@ -322,7 +325,7 @@ def test_test_a_constants_give_the_margin_the_proofs_use():
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 6: test (B) on 4-byte records (B4, rover_cull.hip: LN_B4_*)
 # ---------------------------------------------------------------------------------------------------------------------
-LN_B4_TAU, LN_B4_ERR = 8.0e-3, 3.0e-3
+LN_B4_TAU, LN_B4_ERR = 1.55e-2, 3.0e-3
 LN_B4_C = f32((512.0 * LN_B4_TAU) * (512.0 * LN_B4_TAU) * 1.0001)
 
 
@@ -389,7 +392,7 @@ def test_b4_records_decode_within_their_allowance_and_cull_only_off_plane_rays()
             elif k < 16:
                 n_kept_near += 1
     assert n_codes > 3500 and n_culled > 20000 and n_kept_near > 5000       # both outcomes were exercised near the threshold
-    assert 0.999 * (LN_B4_TAU - LN_B4_ERR) * 0.05 > 2.0 * 1.0e-6 / 0.02      # the static_assert of rover_cull.hip
+    assert 0.999 * (LN_B4_TAU - LN_B4_ERR) * 0.05 > 1.45 * 2.0 * 1.0e-6 / ALPHA      # the static_assert of rover_cull.hip
     print(f"B4: {n_codes} codes, worst decoded-normal error {worst_err:.2e} (allowance {LN_B4_ERR}), smallest |cos| of a culled ray {worst_cos:.2e} "
           f"(needs > {LN_B4_TAU - LN_B4_ERR})")
     # the "always a candidate" code: n4 = 0 gives u = -C < 0 for every direction
