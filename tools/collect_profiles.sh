@@ -41,15 +41,17 @@ pmc_passes E65536_P37_K200_C600_fp16_as_shipped "${TAG}_fp16" --ray-precision fp
 pmc_passes E65536_P37_K200_C600_irregular "${TAG}_irregular" --mesh irregular
 # un-profiled bench lines (valu.json / traffic.json of this run are in place: the lines carry their roofline fractions)
 cp "$OUT"/valu.json "$OUT"/traffic.json profiles/
-python3 bench.py > "$OUT/${TAG}_bench.json" 2> /dev/null          # the driver's command: headline + also{} + cpu_baseline
-python3 bench.py --envs-per-gpu 4096 --steps 200 --warmup 100 --no-cpu-baseline > "$OUT/${TAG}_bench_4096envs.json" 2> /dev/null
-python3 bench.py --envs-per-gpu 32768 --no-cpu-baseline > "$OUT/${TAG}_bench_32768envs.json" 2> /dev/null
-python3 bench.py --rays 120 --validate-goals --no-cpu-baseline > "$OUT/${TAG}_bench_cfg5_120rays_goalvalidation.json" 2> /dev/null
-python3 bench.py --ray-precision fp16_as_shipped --no-cpu-baseline > "$OUT/${TAG}_bench_fp16_as_shipped.json" 2> /dev/null
-python3 bench.py --mesh shuffled --no-cpu-baseline > "$OUT/${TAG}_bench_mesh_shuffled.json" 2> /dev/null
-python3 bench.py --mesh irregular --no-cpu-baseline > "$OUT/${TAG}_bench_mesh_irregular.json" 2> /dev/null
-python3 bench.py --rays native --envs-per-gpu 4096 --no-cpu-baseline > "$OUT/${TAG}_bench_native_4096envs.json" 2> /dev/null
+# (bench.py prints the compact record line on stdout and writes everything it measured to gpurun_out/bench_full.json: both are kept)
+b() { local name=$1; shift; python3 bench.py "$@" > "$OUT/${name}.json" 2> /dev/null; cp gpurun_out/bench_full.json "$OUT/${name}_full.json" 2> /dev/null; }
+b "${TAG}_bench"                                                  # the driver's command: headline + also{} + cpu_baseline
+b "${TAG}_bench_4096envs" --envs-per-gpu 4096 --steps 200 --warmup 100 --no-cpu-baseline --no-also
+b "${TAG}_bench_32768envs" --envs-per-gpu 32768 --no-cpu-baseline --no-also
+b "${TAG}_bench_cfg5_120rays_goalvalidation" --rays 120 --validate-goals --no-cpu-baseline --no-also
+b "${TAG}_bench_fp16_as_shipped" --ray-precision fp16_as_shipped --no-cpu-baseline --no-also
+b "${TAG}_bench_mesh_shuffled" --mesh shuffled --no-cpu-baseline --no-also
+b "${TAG}_bench_mesh_irregular" --mesh irregular --no-cpu-baseline --no-also
+b "${TAG}_bench_native_4096envs" --rays native --envs-per-gpu 4096 --no-cpu-baseline --no-also
 # the reference's own operating point: numEnvs 512 (cfg/task/Rover.yaml:11) x its native 1 634 + 26 rays, on the decimated-style mesh
-python3 bench.py --rays native --envs-per-gpu 512 --mesh irregular --steps 200 --warmup 100 --no-cpu-baseline > "$OUT/${TAG}_bench_native_512envs_irregular.json" 2> /dev/null
-python3 bench.py --rays native --envs-per-gpu 512 --mesh irregular --ray-precision fp16_as_shipped --steps 200 --warmup 100 --no-cpu-baseline > "$OUT/${TAG}_bench_native_512envs_irregular_fp16.json" 2> /dev/null
+b "${TAG}_bench_native_512envs_irregular" --rays native --envs-per-gpu 512 --mesh irregular --steps 200 --warmup 100 --no-cpu-baseline --no-also
+b "${TAG}_bench_native_512envs_irregular_fp16" --rays native --envs-per-gpu 512 --mesh irregular --ray-precision fp16_as_shipped --steps 200 --warmup 100 --no-cpu-baseline --no-also
 ls -la "$OUT"
