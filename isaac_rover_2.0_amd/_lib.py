@@ -651,20 +651,22 @@ class Engine:
             check(fn(h, C.byref(io), _stream(idx)), "rover_reset_envs")
         return call
 
-    def bind_pre_physics(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None, actions_nn=None):
-        """Validates the tensors ONCE and returns a callable that enqueues rover_pre_physics_step on them (for a task whose buffers
-        are persistent: the per-call checks are most of a small batch's host cost).  The callable keeps the tensors alive."""
+    def bind_pre_physics(self, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None, actions_nn=None):
+        """Validates the persistent tensors ONCE and returns call(actions), which enqueues rover_pre_physics_step on them (for a task whose
+        buffers are persistent: the per-call checks are a sizeable part of a small batch's host cost).  Only the actions tensor — usually a
+        fresh policy output every step — is checked per call.  The callable keeps the bound tensors alive."""
         e, f = self.num_envs, torch.float32
-        for t, sh, n in ((actions, (e, 2), "actions"), (quat, (e, 4), "quat"), (lin_hist, (e, 3), "lin_hist"),
+        for t, sh, n in ((quat, (e, 4), "quat"), (lin_hist, (e, 3), "lin_hist"),
                          (ang_hist, (e, 3), "ang_hist"), (euler_pre, (e, 3), "euler_pre"), (pos_targets13, (e, 13), "pos_targets13"),
                          (vel_targets13, (e, 13), "vel_targets13"), (actions_nn, (e, 2, 3), "actions_nn")):
             self._chk(t, sh, f, n)
-        keep = (actions, quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13, actions_nn)
-        args = [self._h] + [_ptr(t) for t in keep]
-        fn, check, idx = self.lib.rover_pre_physics_step, self._check, self._dev_index
+        keep = (quat, lin_hist, ang_hist, euler_pre, pos_targets13, vel_targets13, actions_nn)
+        rest = [_ptr(t) for t in keep]
+        fn, check, idx, h, chk = self.lib.rover_pre_physics_step, self._check, self._dev_index, self._h, self._chk
 
-        def call(_keep=keep):
-            check(fn(*args, _stream(idx)), "rover_pre_physics_step")
+        def call(actions, _keep=keep):
+            chk(actions, (e, 2), f, "actions")
+            check(fn(h, C.c_void_p(actions.data_ptr()), *rest, _stream(idx)), "rover_pre_physics_step")
         return call
 
     def pre_physics_step(self, actions, quat, lin_hist, ang_hist, euler_pre=None, pos_targets13=None, vel_targets13=None, actions_nn=None):

@@ -308,7 +308,7 @@ class RoverTask(RLTask):
         if self._device_reset:
             if self._use_graph and reset_yaw_deg is None and self.global_step > 10:
                 self._actions_buf.copy_(actions)            # (device, dtype and layout conversions included)
-                key = self._ptr_key(self._actions_buf, self._actions_nn_buf())
+                key = self._ptr_key(self._actions_nn_buf())
                 if self._pre_graph is None or self._graph_level != self.curriculum_level or self._graph_key != key:
                     self._capture_graphs()
                     self._graph_key = key
@@ -347,12 +347,11 @@ class RoverTask(RLTask):
         """The device-reset form of :338-414 as launches on the current stream (eager, or while a graph is being captured)."""
         rv = self._rover
         ann = self._actions_nn_buf()
-        # The task's buffers persist: their checks and the argument structs are made once per (actions tensor, actions_nn tensor) and
-        # reused while the same tensors come back (a learner's action buffer usually does) — the per-call validation was a third of a
-        # 512-env step's host time.  Caller-supplied yaws (tests) and a captured graph's device seed take the plain path.
-        key = self._ptr_key(_actions, ann)
+        # The task's buffers persist: their checks and the argument structs are made once and reused while the same tensors are in place
+        # (the actions — usually a fresh policy output — are passed and checked per call).  Caller-supplied yaws (tests) and a captured graph's device seed take the plain path.
+        key = self._ptr_key(ann)
         if reset_yaw_deg is None and seed_dev is None and self._bound_key == key:
-            self._bound_pre()
+            self._bound_pre(_actions)
             self._bound_reset(seed)
         else:
             # euler_pre must see the PRE-reset orientation (:343 runs before :359), so this kernel goes first
@@ -363,17 +362,18 @@ class RoverTask(RLTask):
             self._engine.pre_physics_step(_actions, rv._quat, self.linear_velocity.tracker, self.angular_velocity.tracker, **pre_kw)
             self._engine.reset_envs(*reset_args, yaw_deg=reset_yaw_deg, seed=seed, seed_dev=seed_dev, **reset_kw)
             if reset_yaw_deg is None and seed_dev is None:
-                self._bound_pre = self._engine.bind_pre_physics(_actions, rv._quat, self.linear_velocity.tracker,
+                self._bound_pre = self._engine.bind_pre_physics(rv._quat, self.linear_velocity.tracker,
                                                                 self.angular_velocity.tracker, **pre_kw)
                 self._bound_reset = self._engine.bind_reset_envs(*reset_args, **reset_kw)
                 self._bound_key = key
         if self._balls._pos.data_ptr() != self.target_positions.data_ptr():                      # :584 (visual only)
             self._balls._pos.copy_(self.target_positions)
 
-    def _ptr_key(self, _actions, ann):
-        """Addresses of every tensor a cached argument struct / captured graph holds that an assignment could have replaced since."""
+    def _ptr_key(self, ann):
+        """Addresses of every tensor a cached argument struct / captured graph holds that an assignment could have replaced since (the
+        actions are not among them: a bound call takes them per step, a captured graph reads the task's own actions buffer)."""
         rv = self._rover
-        return (_actions.data_ptr(), ann.data_ptr(), self.initial_pos.data_ptr(), self.base_pos.data_ptr(), self.reset_buf.data_ptr(),
+        return (ann.data_ptr(), self.initial_pos.data_ptr(), self.base_pos.data_ptr(), self.reset_buf.data_ptr(),
                 self.progress_buf.data_ptr(), self.target_positions.data_ptr(), rv._pos.data_ptr(), rv._quat.data_ptr(),
                 rv._joint_pos.data_ptr())
 
