@@ -456,12 +456,14 @@ def _r(x, digits=5):
 def _short_workload(w):
     """"BASELINE configs[1]: 4096 envs x (37 + 26) rays, K=200, ..." -> label + what differs from the headline."""
     head, _, rest = w.partition(": ")
-    if head.startswith("RoverTask"):                         # the task-level entries: "RoverTask.pre_physics_step + ... (<label>)"
-        head = "RoverTask pre+post_physics_step, " + head[head.find("(") + 1:head.rfind(")")]
+    task = head.startswith("RoverTask")                      # the task-level entries: "RoverTask.pre_physics_step + ... (<label>)"
+    if task:
+        head = head[head.find("(") + 1:head.rfind(")")]
     head = head.replace(" (32 768 of its 262 144 envs, no gather)", "")
     keep = [p for p in rest.split(", ") if p.startswith(("mesh=", "ray_precision=", "+ goal")) and p not in ("mesh=grid", "ray_precision=fp32")]
     envs = rest.split(", ")[0] if rest else ""
-    return ", ".join([head if "BASELINE configs" in head else "custom", envs] + keep)
+    label = head if "BASELINE configs" in head else "custom"
+    return ", ".join((["RoverTask pre+post_physics_step"] if task else []) + [label, envs] + keep)
 
 
 def compact_line(full, full_path=None):
