@@ -316,14 +316,13 @@ ROVER_API int rover_mlp_chain_pair_forward(rover_ctx *ctx, int32_t M, const rove
  *        prefix it cannot clear as a group; 16 B per pair for the sphere test, 8 B per pair — f32 proof — for the normal test), one lane
  *        per (ray, chunk of 8 pairs), then the same exact phase.
  *        All give bit-identical results.  auto: fp32 arithmetic (ray_precision 0, 1) — 4 from 24 576 rays per step, 1 below;
- *        ray_precision = 2 — 2 up to 24 576 rays per step; above that 4 in env order below 98 304 rays per step, 4 behind the sort on dense
- *        ray sets (ten or more heightmap rays per terrain cell; two or more on an irregular terrain mesh), 3 otherwise.
+ *        ray_precision = 2 — 2 up to 24 576 rays per step; above that 4: in env order below 98 304 rays per step, behind the sort beyond
+ *        (on an irregular terrain mesh — fewer than half of its cells with a usable far bound — 4 from two heightmap rays per terrain cell, 3 below).
  * name = "lane_env_order" (variant 4): 1 = no sort, the ray slots in env order; 0 = rays sorted by (map, cell); -1 (default) = auto: env
  *        order while a step's heightmap rays are fewer than 1.5 per terrain cell and the rovers fewer than one per 64 cells (ray_precision
  *        2: below 98 304 rays per step).
  * name = "lane_rocks" (variant 4, sorted): 1 = the rock rays through the staged kernel too (one ray-cast launch), 0 = through the culled one
- *        (3); -1 (default) = auto: 1 in f32 arithmetic; as shipped (ray_precision 2) 1 when fewer than half of the rocks map's cells have a
- *        usable far bound (an irregular rocks mesh).
+ *        (3); -1 (default) = auto: 1.
  * name = "ray_precision": 0 (default) = the reference's fp32 mode, which the parity tests pin.
  *        1 = every ray origin / direction rounded to fp16 before the cell lookup and the ray maths, like the reference AS
  *        SHIPPED (Camera.dtype = float16: camera.py:55,212; rock_detect.py:319,371); f32 arithmetic after that.

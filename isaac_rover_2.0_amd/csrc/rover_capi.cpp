@@ -52,7 +52,8 @@ struct rover_ctx {
     int64_t cull_always[2]{0, 0}, cull_nocone[2]{0, 0}, cull_tris[2]{0, 0};      // per map, counted when its tables were built
     int64_t cull_always_h[2]{0, 0}, cull_nocone_h[2]{0, 0};
     int64_t cull_farok[2]{0, 0}, cull_cells[2]{0, 0};      // cells whose far bound can hold for a usual ray (far_build_kernel) / cells
-    double cull_eta_h = 0.06;           // free parameter of the fp16 proof (rover_cull.hip, cull_proof_h); ROVER_CULLH_ETA for experiments
+    double cull_eta_h = 0.08;           // free parameter of the fp16 proof (rover_cull.hip, cull_proof_h); ROVER_CULLH_ETA for experiments
+    double cull_split_h = 8.0;          // how test (A)'s cross term is split between its |h|^2 and rho^2 parts (cull_proof_h); ROVER_CULLH_SPLIT
     uint64_t cull_budget = 1536ull << 20;  // option "cull_queue_mb": most bytes the queue may take (a step is cast in several launches beyond it)
     uint32_t cull_launches = 1;
     int cull_lazy = -1;                 // ROVER_CULL_LAZY: -1 auto, 0 / 1 force (experiments)
@@ -216,8 +217,14 @@ static int effective_variant(const rover_ctx* c) {
     if (v4_ok && c->variant == 4) return 4;
     if (v4_ok && c->variant == 0 && c->have_dist) {
         if (c->precision != 2) { if (valid_rays(c) >= ROVER_AUTO_LANE_RAYS) return 4; }
-        else if (valid_rays(c) < ROVER_AUTO_LANE_ENV_RAYS_F16 ||
-                 (uint64_t)c->cfg.num_envs * (uint64_t)c->P >= (2 * c->cull_farok[0] >= c->cull_cells[0] ? 10ull : 2ull) * (uint64_t)c->cull_cells[0]) return 4;
+        // (round 6 — the rocks part in the staged launch, eta = 0.08, cross-term split 8 —, binned / culled / staged behind the sort / staged in env order,
+        //  M env-steps/s at 37 + 26 rays: 512 envs 8.7 / 9.9 / 9.2 / 14.3; 1 536: 15.1 / 20.6 / 21.1 / 23.9; 2 048: 17.5 / 23.7 / 24.3 / 24.8; 4 096: 21.9 / 32.6 / 33.7 /
+        //  30.3; 16 384: 39.8 / 55.9 / 57.6 / 41.0; 65 536: 51.0 / 93.3 / 95.4 / 44.7; 120 + 26 rays 22.6 / 45.4 / 51.1 / 27.9; native rays at 4 096 envs 1.95 / 3.57 / 4.04 /
+        //  2.46, at 512 envs 1.56 / 2.24 / 2.44 / 2.10: on a regular terrain mesh the staged kernel from the binned kernel's range on.  Irregular terrain
+        //  mesh: 4 096 envs 22.1 / 25.4 / 21.6 / 21.3; 16 384: 39.7 / 35.8 / 35.9 / 23.8; 65 536: 49.7 / 47.9 / 59.9 / 25.2; native rays at 512 envs 1.52 / 1.41 / 1.62 /
+        //  1.42: staged from two heightmap rays per terrain cell, as before.)
+        else if (valid_rays(c) < ROVER_AUTO_LANE_ENV_RAYS_F16 || 2 * c->cull_farok[0] >= c->cull_cells[0] ||
+                 (uint64_t)c->cfg.num_envs * (uint64_t)c->P >= 2ull * (uint64_t)c->cull_cells[0]) return 4;
     }
     return 3;
 }
@@ -462,6 +469,7 @@ int rover_create(const rover_cfg* cfg, rover_ctx** out) {
     if (const char* v = getenv("ROVER_RAYCAST_VARIANT")) { int x = atoi(v); c->variant = (x >= 1 && x <= 4) ? x : 0; }
     if (const char* v = getenv("ROVER_CULL_LAZY")) c->cull_lazy = atoi(v);
     if (const char* v = getenv("ROVER_CULLH_ETA")) { const double x = atof(v); if (x >= 0.02 && x <= 0.5) c->cull_eta_h = x; }
+    if (const char* v = getenv("ROVER_CULLH_SPLIT")) { const double x = atof(v); if (x >= 0.5 && x <= 64.0) c->cull_split_h = x; }
     if (const char* v = getenv("ROVER_CULL_QUEUE_MB")) { const long mb = atol(v); if (mb >= 1) c->cull_budget = (uint64_t)mb << 20; }
     if (const char* v = getenv("ROVER_BIN_LOW_BITS")) { int b = atoi(v); if (b >= 8 && b <= 12) c->low_bits_opt = (uint32_t)b; }
     if (const char* v = getenv("ROVER_RAYCAST_RUN")) { int r = atoi(v); if (r >= 1 && r <= 4096) c->run = (uint32_t)r; }
@@ -610,7 +618,7 @@ int rover_set_knn_map(rover_ctx* c, int which, const int32_t* map_idx, int32_t X
             (e = hipMemcpy(d_newid, newid.data(), (uint64_t)T * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemset(d_cnt, 0, 8 * sizeof(uint32_t))) != hipSuccess ||
             (e = launch_cull_build(d_idx, d_tris, d_verts, n_cells, (uint32_t)K, K8, (uint32_t)T, T_int, (uint32_t)V, d_order, d_newid, d_cidx,
-                                   d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h), (uint32_t)Y, cell,
+                                   d_ctab, d_ctab_h, d_rtab, d_qrow, d_qrow_h, d_far, d_far_h, d_nz, d_cnt, cull_proof_h(c->cull_eta_h, c->cull_split_h), (uint32_t)Y, cell,
                                    shift_x, shift_y, lt, lth, nullptr)) != hipSuccess ||
             (e = hipDeviceSynchronize()) != hipSuccess ||
             (e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost)) != hipSuccess) {
@@ -786,7 +794,7 @@ static CullArgs cull_args(const rover_ctx* c, uint32_t n_valid) {
     a.ctab0 = h ? c->cull_ctab_h[0] : c->cull_ctab[0]; a.ctab1 = h ? c->cull_ctab_h[1] : c->cull_ctab[1];
     a.rtab0 = c->cull_rtab[0]; a.rtab1 = c->cull_rtab[1];
     a.half = h ? 1 : 0;
-    const CullProofH ph = cull_proof_h(c->cull_eta_h);
+    const CullProofH ph = cull_proof_h(c->cull_eta_h, c->cull_split_h);
     a.c_a_h = ph.c_a; a.tau2_h = ph.tau2;
     a.far0 = h ? c->cull_far_h[0] : c->cull_far[0]; a.far1 = h ? c->cull_far_h[1] : c->cull_far[1];
     a.near0 = a.far0 + 2ull * (uint64_t)c->cull_cells[0]; a.near1 = a.far1 + 2ull * (uint64_t)c->cull_cells[1];
@@ -836,12 +844,9 @@ static bool lane_env_order(const rover_ctx* c, int variant) {
            64ull * (uint64_t)c->cfg.num_envs < (uint64_t)c->cull_cells[0];
 }
 
-// variant 4 behind the sort: the rocks part of the sorted list through the staged kernel too?  f32 arithmetic: yes (round 6: 4-byte test-(B)
-// records and test (A) by heading for the flat body rays — one launch 0.33 ms against 0.23 + 0.14).  As shipped: on an irregular rocks mesh only.
-static bool lane_rocks_too(const rover_ctx* c) {
-    if (c->lane_rocks >= 0) return c->lane_rocks != 0;
-    return c->precision != 2 || 2 * c->cull_farok[1] < c->cull_cells[1];
-}
+// variant 4 behind the sort: the rocks part of the sorted list through the staged kernel too?  Yes, since round 6, in either arithmetic: f32 — 4-byte
+// test-(B) records, one launch 0.31 ms against 0.23 + 0.14; as shipped 91.0 against 87.2 M env-steps/s (and 96.9 with the round's proof constants).
+static bool lane_rocks_too(const rover_ctx* c) { return c->lane_rocks < 0 ? true : c->lane_rocks != 0; }
 
 // the ray-cast launch(es) of a step for the variant in force, on the ray records / sorted list in the workspace
 static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t s) {
@@ -865,7 +870,7 @@ static int run_raycast(rover_ctx* c, int variant, uint32_t n_valid, hipStream_t 
             l.lvl[w] = t.lvl; l.lrec[w] = t.lrec; l.lid[w] = t.lid; l.rtab[w] = c->cull_rtab[w]; l.pp[w] = c->lane_pp[w];
         }
         {
-            const CullProofH ph = cull_proof_h(c->cull_eta_h);
+            const CullProofH ph = cull_proof_h(c->cull_eta_h, c->cull_split_h);
             l.half = lh ? 1 : 0; l.c_a_h = ph.c_a; l.k2_far = cull_far_k2(l.half, ph);
         }
         l.run = effective_run(c); l.out = c->d_dist_out; l.stats = c->d_cull_stats;

@@ -96,12 +96,15 @@ template <> struct CullK<1> {
 // lowers kappa = 2 e / eta and with it (B)'s thresholds: fewer candidates by orientation, more cells with a cone).  Everything
 // else follows: alpha = eta + 1e-3, beta = 1 + 2 alpha, (beta rho + alpha |h|)^2 <= (beta^2 + 2 alpha beta) rho^2 +
 // (alpha^2 + alpha beta / 2) |h|^2, then the |d|^2 and f32-rounding allowances.
-CullProofH cull_proof_h(double eta) {
+CullProofH cull_proof_h(double eta, double split) {
     CullProofH k{};
+    // (beta rho + alpha |h|)^2 = beta^2 rho^2 + 2 alpha beta rho |h| + alpha^2 |h|^2 <= (beta^2 + split alpha beta) rho^2 + (alpha^2 + alpha beta / split) |h|^2
+    // for every split > 0 (2 rho |h| <= split rho^2 + |h|^2 / split); the bound is tight at |h| = split rho: rounds 3-5 used split = 2, but a ray's
+    // origin lies 5-10 radii from the triangles it could hit
     const double e = CullK<1>::e_fp16, a = eta + 1.0e-3, b = 1.0 + 2.0 * a;
     k.kappa = 2.0 * e / eta;
-    k.c_rho = (b * b + 2.0 * a * b) * 1.004 + 0.005;
-    k.c_a = (float)(0.996 * (1.0 - (a * a + 0.5 * a * b)) - 0.0005);
+    k.c_rho = (b * b + split * a * b) * 1.004 + 0.005;
+    k.c_a = (float)(0.996 * (1.0 - (a * a + a * b / split)) - 0.0005);
     k.tau2 = (float)(k.kappa * k.kappa);
     return k;
 }

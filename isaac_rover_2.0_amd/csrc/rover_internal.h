@@ -60,7 +60,7 @@ struct PrepArgs {
 
 // constants of the culled ray cast's rejection proof for the as-shipped fp16 arithmetic, derived from its one free parameter eta
 struct CullProofH { double kappa, c_rho; float c_a, tau2; };
-CullProofH cull_proof_h(double eta);
+CullProofH cull_proof_h(double eta, double split);
 
 struct LaneTables { float4* lvl; uint4* lrec; uint2* lid; };      // the staged ray cast's tables of one map for one proof (null: not built)
 

@@ -652,8 +652,8 @@ def test_rays_that_clear_their_cell_are_not_scanned():
 def test_auto_variant_and_run_selection():
     """raycast_variant 0 (auto), f32 arithmetic: the env-order kernel below 24 576 rays per step, the staged kernel (4) from there on —
     in env order (no sort) while a terrain cell holds fewer than 1.5 heightmap rays and more than 64 cells hold one rover —; as shipped: the binned kernel up to 24 576 rays,
-    above that the staged kernel in env order below 98 304 rays and behind the sort on dense ray sets (ten or more heightmap rays per terrain
-    cell), the culled one otherwise; K8 > 256 always falls back to the env-order kernel."""
+    above that the staged kernel — in env order below 98 304 rays, behind the sort beyond (on an irregular terrain mesh only from two heightmap
+    rays per terrain cell: the culled kernel below that); K8 > 256 always falls back to the env-order kernel."""
     from hip_helpers import hip_step, make_engine
     from isaac_rover_amd import synth
     scene = synth.make_scene(n_cells=64, k=16, n_stones=8)
@@ -676,10 +676,15 @@ def test_auto_variant_and_run_selection():
         assert e.info().raycast_variant == 4 and e.info().raycast_sorted == want_sorted, n
         e.close()
     wider = synth.make_scene(n_cells=256, k=16, n_stones=8)
-    sparse = make_engine(wider, distn, 2048, variant=None)   # as shipped, 129 024 rays, 1.2 heightmap rays per terrain cell: the culled kernel
-    sparse.set_option("ray_precision", 2)
+    sparse = make_engine(wider, distn, 2048, variant=None)   # as shipped, 129 024 rays, 1.2 heightmap rays per terrain cell, and — K = 16 — fewer than
+    sparse.set_option("ray_precision", 2)                    # half of the cells with a usable far bound (the mark of an irregular mesh): the culled kernel
     assert sparse.info().raycast_variant == 3
     sparse.close()
+    k200 = synth.make_scene(n_cells=96, k=200, n_stones=8)   # a regular mesh with the reference's K: most cells have a far bound
+    reg = make_engine(k200, distn, 2048, variant=None)       # as shipped, 129 024 rays, 8.2 heightmap rays per terrain cell: staged behind the sort
+    reg.set_option("ray_precision", 2)                       # since round 6 (rounds 4-5: the culled kernel below ten rays per cell)
+    assert reg.info().raycast_variant == 4 and reg.info().raycast_sorted == 1 and reg.info().raycast_rocks_staged == 1
+    reg.close()
     big = make_engine(scene, distn, 4096, variant=None)
     assert big.info().raycast_variant == 4 and big.info().raycast_sorted == 1
     big.set_option("ray_precision", 2)
